@@ -1,0 +1,184 @@
+// Flash-attention forward for the CogVideoX DiT joint [text ; video] self-attention (gfx950).
+//   head_dim 64, bf16 MFMA 32x32x16, fp32 online softmax, non-causal, no mask, N not a tile multiple.
+// Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0, reached from
+// /root/reference/inference_script.py:483-489.
+//
+// Operands come head-major from dove_qkv_post_bf16: Q' [H][Npad][64] (already multiplied by
+// scale*log2e), K' [H][Npad][64], V^T [H][64][Npad]; pad rows/columns are zero.
+// Workgroup = 4 waves = 128 query rows (32 per wave); KV tiles of 64 keys are staged K and V^T alike with
+// 16-byte global_load_lds into XOR-swizzled LDS, double-buffered, one barrier per tile.
+// Swapped products keep the softmax lane-local (guide T12): S^T = K Q^T puts one query column in each
+// lane (row max/sum = in-lane + one cross-half shuffle), P^T is re-packed to the MFMA B layout with
+// v_permlane32_swap, and O^T = V^T P^T accumulates with the same query-per-lane ownership.
+#include "common.h"
+#include "../../include/dove_hip.h"
+
+__device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                       long long N, long long Npad, long long ldo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = 16384;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  const long long q0 = (long long)blockIdx.x * 128 + wave * 32;
+
+  bf16x8 qf[4];
+  {
+    const bf16_t* qp = Qh + ((long long)h * Npad + q0 + l31) * 64 + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m = -1e30f, lsum = 0.f;
+
+  const int ntiles = (int)((N + 63) / 64);
+  const int srow = tid >> 3;                       // 0..31 (+32 for the second pass)
+  const int sc_ld = (tid & 7) ^ ((srow >> 1) & 7);  // actual 16-B chunk this lane fetches
+  const bf16_t* kbase = Kh + ((long long)h * Npad + srow) * 64 + sc_ld * 8;
+  const bf16_t* vbase = Vt + ((long long)h * 64 + srow) * Npad + sc_ld * 8;
+
+  auto stage = [&](int buf, int tile) {
+    const long long kv0 = (long long)tile * 64;
+    char* Ks = smem + buf * STAGE;
+    char* Vs = Ks + 8192;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      glds16(kbase + (kv0 + j * 32) * 64, Ks + (j * 256 + wave * 64) * 16);
+      glds16(vbase + (long long)(j * 32) * Npad + kv0, Vs + (j * 256 + wave * 64) * 16);
+    }
+  };
+
+  stage(0, 0);
+  for (int it = 0; it < ntiles; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 1 < ntiles) stage((it + 1) & 1, it + 1);
+    const char* Ks = smem + (it & 1) * STAGE;
+    const char* Vs = Ks + 8192;
+
+    // ---- S^T[kv][q] = K Q^T ----
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+      const int row = kb * 32 + l31;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int sc = (kk * 2 + hi) ^ ((row >> 1) & 7);
+        const bf16x8 kf = *(const bf16x8*)(Ks + row * 128 + sc * 16);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+    }
+    const long long kv0 = (long long)it * 64;
+    if (kv0 + 64 > N) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= N) st[kb][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (base 2; Q carries scale*log2e) ----
+    float mt = st[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mnew = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kb][r] - mnew);
+        st[kb][r] = p;
+        ps += p;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+    // ---- P^T -> bf16 MFMA B fragments: lane(q, hi) needs keys 16*k2 + 8*hi + 0..7 of each 32-key block ----
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int b = 8 * k2;
+        const uint32_t a0 = pack_bf2(st[kb][b + 0], st[kb][b + 1]);
+        const uint32_t a1 = pack_bf2(st[kb][b + 2], st[kb][b + 3]);
+        const uint32_t b0 = pack_bf2(st[kb][b + 4], st[kb][b + 5]);
+        const uint32_t b1 = pack_bf2(st[kb][b + 6], st[kb][b + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        pf[kb][k2] = make_frag(r0[0], r1[0], r0[1], r1[1]);
+      }
+    // ---- O^T[d][q] += V^T P^T ----
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int row = db * 32 + l31;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int sc = (kb * 4 + k2 * 2 + hi) ^ ((row >> 1) & 7);
+          const bf16x8 vf = *(const bf16x8*)(Vs + row * 128 + sc * 16);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][k2], o[db], 0, 0, 0);
+        }
+    }
+  }
+
+  const float l = lsum + __shfl_xor(lsum, 32);
+  const float inv = 1.0f / l;
+  const long long q = q0 + l31;
+  if (q < N) {
+    bf16_t* op = O + q * ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hi;
+        uint2 w;
+        w.x = pack_bf2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+        w.y = pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+        *(uint2*)(op + d) = w;
+      }
+  }
+}
+
+extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N,
+                                        long long Npad, int heads, int head_dim, long long ldo, void* stream) {
+  DOVE_CHECK_ARG(Qh && Kh && Vt && O, "attention_fwd: null pointer");
+  DOVE_CHECK_ARG(head_dim == 64, "attention_fwd: head_dim must be 64 (got %d)", head_dim);
+  DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128 + 0, "attention_fwd: Npad must be N rounded up to 128");
+  DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(Npad / 128), heads);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)Qh,
+                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
+  return DOVE_OK;
+}

@@ -1,0 +1,216 @@
+// Small HBM-bound glue kernels of the DOVE hot path (gfx950): layout changes between the reference's
+// [B,C,T,H,W] boundary tensors and the internal channels-last bf16 layout, Downsample3D's temporal
+// average pool, the VAE posterior sample, get_velocity, DiT patchify/unpatchify and the M=1 linears
+// (timestep embedding MLP and AdaLN modulation vectors, constant for a fixed sr_noise_step).
+// Reference call sites: /root/reference/inference_script.py:407-409 (encode+sample), :483-493
+// (transformer + get_velocity), :500-501 (decode + range map).
+#include "common.h"
+#include "../../include/dove_hip.h"
+
+__device__ __forceinline__ float load_any(const void* p, long long i, int dt) {
+  return dt == DOVE_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void store_any(void* p, long long i, int dt, float v) {
+  if (dt == DOVE_F32) ((float*)p)[i] = v;
+  else ((bf16_t*)p)[i] = f2bf(v);
+}
+
+// ---- [C,T,H,W] (fp32|bf16) -> [T,H,W,Cp] bf16, channels >= C zero-filled, y = x*scale + shift ----
+__global__ void cl_from_ncthw_kernel(const void* __restrict__ x, int dt, int C, long long npix, int Cp,
+                                     float scale, float shift, bf16_t* __restrict__ y) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  bf16_t* yr = y + p * Cp;
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      f[e] = c < C ? load_any(x, (long long)c * npix + p, dt) * scale + shift : 0.f;
+    }
+    *(uint4*)(yr + c0) = pack8(f);
+  }
+}
+
+extern "C" int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, float scale, float shift,
+                                   void* y, void* stream) {
+  DOVE_CHECK_ARG(x && y, "cl_from_ncthw: null pointer");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "cl_from_ncthw: bad dtype %d", dtype);
+  DOVE_CHECK_ARG(Cp % 8 == 0 && Cp >= C && C > 0 && npix > 0, "cl_from_ncthw: need Cp %% 8 == 0, Cp >= C");
+  hipLaunchKernelGGL(cl_from_ncthw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     dtype, C, npix, Cp, scale, shift, (bf16_t*)y);
+  DOVE_CHECK_LAUNCH("dove_cl_from_ncthw");
+  return DOVE_OK;
+}
+
+// ---- [T,H,W,ld] bf16 -> [C,T,H,W] (fp32|bf16), y = clamp(x*scale + shift, lo, hi) ----
+__global__ void ncthw_from_cl_kernel(const bf16_t* __restrict__ x, long long ld, int C, long long npix, float scale,
+                                     float shift, float lo, float hi, void* __restrict__ y, int dt) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const bf16_t* xr = x + p * ld;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    const uint2 v = *(const uint2*)(xr + c0);
+    const float f[4] = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                        __uint_as_float(v.y & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < C) store_any(y, (long long)(c0 + e) * npix + p, dt, fminf(fmaxf(f[e] * scale + shift, lo), hi));
+  }
+}
+
+extern "C" int dove_ncthw_from_cl(const void* x, long long ld, int C, long long npix, float scale, float shift,
+                                   float lo, float hi, void* y, int dtype, void* stream) {
+  DOVE_CHECK_ARG(x && y, "ncthw_from_cl: null pointer");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "ncthw_from_cl: bad dtype %d", dtype);
+  DOVE_CHECK_ARG(ld % 4 == 0 && ld >= ((C + 3) / 4) * 4 && C > 0 && npix > 0, "ncthw_from_cl: ld must be a multiple of 4 covering C");
+  hipLaunchKernelGGL(ncthw_from_cl_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ld, C, npix, scale, shift, lo, hi, y, dtype);
+  DOVE_CHECK_LAUNCH("dove_ncthw_from_cl");
+  return DOVE_OK;
+}
+
+// ---- Downsample3D temporal pool: odd T keeps frame 0 and averages pairs (1,2),(3,4)..; even T pairs (0,1).. ----
+__global__ void avgpool_time_kernel(const bf16_t* __restrict__ x, int T, long long frame8, bf16_t* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-element chunk within a frame
+  if (i >= frame8) return;
+  const int to = blockIdx.y;
+  const int odd = T & 1;
+  const uint4* xs = (const uint4*)x;
+  uint4* ys = (uint4*)y;
+  if (odd && to == 0) {
+    ys[i] = xs[i];
+    return;
+  }
+  const int t0 = odd ? 1 + 2 * (to - 1) : 2 * to;
+  float a[8], b[8];
+  unpack8(xs[(long long)t0 * frame8 + i], a);
+  unpack8(xs[(long long)(t0 + 1) * frame8 + i], b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.5f * (a[e] + b[e]);
+  ys[(long long)to * frame8 + i] = pack8(a);
+}
+
+extern "C" int dove_avgpool_time_bf16(const void* x, int T, long long frame_elems, void* y, void* stream) {
+  DOVE_CHECK_ARG(x && y, "avgpool_time: null pointer");
+  DOVE_CHECK_ARG(T >= 2 && frame_elems % 8 == 0 && frame_elems > 0, "avgpool_time: need T >= 2 and frame_elems %% 8 == 0");
+  const int To = (T & 1) ? 1 + (T - 1) / 2 : T / 2;
+  const long long f8 = frame_elems / 8;
+  hipLaunchKernelGGL(avgpool_time_kernel, dim3((unsigned)((f8 + 255) / 256), To), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, T, f8, (bf16_t*)y);
+  DOVE_CHECK_LAUNCH("dove_avgpool_time_bf16");
+  return DOVE_OK;
+}
+
+// ---- DiagonalGaussianDistribution: split channels-last moments into [2L,T,h,w] params, and sample ----
+__global__ void posterior_kernel(const bf16_t* __restrict__ mom, long long ld, int L, long long npix,
+                                 const void* __restrict__ noise, int ndt, void* __restrict__ out, int odt) {
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  for (int c = 0; c < L; ++c) {
+    const float mean = bf2f(mom[p * ld + c]);
+    float lv = bf2f(mom[p * ld + L + c]);
+    lv = fminf(fmaxf(lv, -30.f), 20.f);
+    const float eps = load_any(noise, (long long)c * npix + p, ndt);
+    store_any(out, (long long)c * npix + p, odt, mean + __expf(0.5f * lv) * eps);
+  }
+}
+
+extern "C" int dove_posterior_sample(const void* moments, long long ld, int latent_channels, long long npix,
+                                      const void* noise, int noise_dtype, void* out, int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(moments && noise && out, "posterior_sample: null pointer");
+  DOVE_CHECK_ARG(ld >= 2 * latent_channels && npix > 0, "posterior_sample: bad ld");
+  hipLaunchKernelGGL(posterior_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)moments, ld, latent_channels, npix, noise, noise_dtype, out, out_dtype);
+  DOVE_CHECK_LAUNCH("dove_posterior_sample");
+  return DOVE_OK;
+}
+
+// ---- out = a*x + b*y (CogVideoXDPMScheduler.get_velocity / add_noise) ----
+__global__ void axpby_kernel(const void* x, const void* y, void* out, int dt, long long n, float a, float b) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_any(out, i, dt, a * load_any(x, i, dt) + b * load_any(y, i, dt));
+}
+
+extern "C" int dove_axpby(const void* x, const void* y, void* out, int dtype, long long n, float a, float b,
+                           void* stream) {
+  DOVE_CHECK_ARG(x && y && out && n > 0, "axpby: null pointer / empty");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "axpby: bad dtype %d", dtype);
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, out,
+                     dtype, n, a, b);
+  DOVE_CHECK_LAUNCH("dove_axpby");
+  return DOVE_OK;
+}
+
+// ---- CogVideoXPatchEmbed gather: [T,C,h,w] -> tokens [(T/pt)*(h/p)*(w/p)][C*pt*p*p], feature order (c,t,ph,pw) ----
+__global__ void patchify_kernel(const void* __restrict__ x, int dt, int T, int C, int H, int W, int pt, int p,
+                                bf16_t* __restrict__ tok, long long ld, int dir, void* __restrict__ y) {
+  const int gh = H / p, gw = W / p;
+  const int F = C * pt * p * p;
+  const long long total = (long long)(T / pt) * gh * gw * F;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int f = (int)(i % F);
+  const long long n = i / F;
+  const int pw = f % p, ph = (f / p) % p, tt = (f / (p * p)) % pt, c = f / (p * p * pt);
+  const int iw = (int)(n % gw), ih = (int)((n / gw) % gh), it = (int)(n / ((long long)gw * gh));
+  const long long src = (((long long)(it * pt + tt) * C + c) * H + ih * p + ph) * W + iw * p + pw;
+  if (dir == 0) tok[n * ld + f] = f2bf(load_any(x, src, dt));
+  else store_any(y, src, dt, bf2f(tok[n * ld + f]));
+}
+
+extern "C" int dove_patchify(const void* x, int dtype, int T, int C, int H, int W, int pt, int p, void* tokens,
+                              long long ld, void* stream) {
+  DOVE_CHECK_ARG(x && tokens, "patchify: null pointer");
+  DOVE_CHECK_ARG(T % pt == 0 && H % p == 0 && W % p == 0 && ld >= (long long)C * pt * p * p, "patchify: shape not divisible by patch");
+  const long long total = (long long)(T / pt) * (H / p) * (W / p) * C * pt * p * p;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     dtype, T, C, H, W, pt, p, (bf16_t*)tokens, ld, 0, nullptr);
+  DOVE_CHECK_LAUNCH("dove_patchify");
+  return DOVE_OK;
+}
+
+extern "C" int dove_unpatchify(const void* tokens, long long ld, int T, int C, int H, int W, int pt, int p, void* y,
+                                int dtype, void* stream) {
+  DOVE_CHECK_ARG(y && tokens, "unpatchify: null pointer");
+  DOVE_CHECK_ARG(T % pt == 0 && H % p == 0 && W % p == 0 && ld >= (long long)C * pt * p * p, "unpatchify: shape not divisible by patch");
+  const long long total = (long long)(T / pt) * (H / p) * (W / p) * C * pt * p * p;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     nullptr, dtype, T, C, H, W, pt, p, (bf16_t*)const_cast<void*>(tokens), ld, 1, y);
+  DOVE_CHECK_LAUNCH("dove_unpatchify");
+  return DOVE_OK;
+}
+
+// ---- M = 1 linear: y[j] = b[j] + sum_k W[j][k] * act(x[k]); one wave per output row ----
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ W, const float* __restrict__ b,
+                                                   const float* __restrict__ x, int in_f, int out_f, int act,
+                                                   float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= out_f) return;
+  const bf16_t* wr = W + (long long)j * in_f;
+  float acc = 0.f;
+  for (int k0 = lane * 8; k0 < in_f; k0 += 512) {
+    float w[8];
+    unpack8(*(const uint4*)(wr + k0), w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xv = x[k0 + e];
+      if (act == 1) xv = silu_f(xv);
+      acc += w[e] * xv;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) y[j] = acc + (b ? b[j] : 0.f);
+}
+
+extern "C" int dove_gemv_bf16(const void* W, const float* bias, const float* x, int in_features, int out_features,
+                               int act_in, float* y, void* stream) {
+  DOVE_CHECK_ARG(W && x && y, "gemv: null pointer");
+  DOVE_CHECK_ARG(in_features % 8 == 0 && in_features > 0 && out_features > 0, "gemv: in_features must be a multiple of 8");
+  hipLaunchKernelGGL(gemv_kernel, dim3((out_features + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W,
+                     bias, x, in_features, out_features, act_in, y);
+  DOVE_CHECK_LAUNCH("dove_gemv_bf16");
+  return DOVE_OK;
+}

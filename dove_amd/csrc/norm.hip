@@ -1,0 +1,340 @@
+// HBM-bound normalisation kernels of the DOVE hot path (gfx950): 16-byte vector loads, wave-shuffle
+// and LDS tree reductions, fp32 statistics (fp64 final combine), bf16 storage.
+//   * GroupNorm(32) statistics over one frame-batch [T,H,W,C]    (encoder GN, decoder SpatialNorm3D)
+//   * GroupNorm apply (+ latent-conditioned scale/shift of SpatialNorm3D) + SiLU
+//   * LayerNorm + AdaLN-Zero modulation, text / video rows with different (shift, scale)
+//   * per-head QK LayerNorm + 3D RoPE + softmax pre-scale + head-major re-layout (Q, K, V^T)
+// Reference call sites: /root/reference/inference_script.py:408,500 (VAE), :483-489 (DiT); the
+// arithmetic itself lives in diffusers.
+#include "common.h"
+#include "../../include/dove_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics: partial (sum, sumsq) per block and group, then an fp64 combine.
+// Thread layout: cpp = C/8 chunk columns x (256/cpp) pixel lanes; deterministic (no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, long long npix, int C,
+                                                         int cpp_log, float* __restrict__ partial) {
+  __shared__ float red[256 * 17];
+  __shared__ float chan[2 * 2048];
+  const int tid = threadIdx.x;
+  const int cpp = 1 << cpp_log;
+  const int q = tid & (cpp - 1), sub = tid >> cpp_log;
+  const int nsub = 256 >> cpp_log;
+  float s[8], ss[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+  for (long long p = (long long)blockIdx.x * nsub + sub; p < npix; p += (long long)gridDim.x * nsub) {
+    const uint4 v = *(const uint4*)(x + p * C + q * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+  }
+  // red[(q*nsub + sub)*17 + k], k = 0..15 : (sum e0..7, sumsq e0..7); 17-stride breaks bank conflicts
+  float* r = red + (q * nsub + sub) * 17;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { r[e] = s[e]; r[8 + e] = ss[e]; }
+  __syncthreads();
+  // per-channel block sums: 2*C outputs
+  for (int o = tid; o < 2 * C; o += 256) {
+    const int ch = o >> 1, which = o & 1;
+    const int qq = ch >> 3, e = ch & 7;
+    float acc = 0.f;
+    for (int k = 0; k < nsub; ++k) acc += red[(qq * nsub + k) * 17 + which * 8 + e];
+    chan[o] = acc;
+  }
+  __syncthreads();
+  const int cpg = C / 32;
+  if (tid < 64) {
+    const int g = tid >> 1, which = tid & 1;
+    float acc = 0.f;
+    for (int k = 0; k < cpg; ++k) acc += chan[(g * cpg + k) * 2 + which];
+    partial[(long long)blockIdx.x * 64 + tid] = acc;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count, float eps,
+                                   float* __restrict__ stats) {
+  const int tid = threadIdx.x;  // 64 threads: (group, which)
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += (double)partial[(long long)b * 64 + tid];
+  __shared__ double sh[64];
+  sh[tid] = acc;
+  __syncthreads();
+  if (tid < 32) {
+    const double mean = sh[tid * 2] / count;
+    double var = sh[tid * 2 + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[tid * 2] = (float)mean;
+    stats[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws,
+                                          int ws_blocks, float* stats, void* stream) {
+  DOVE_CHECK_ARG(x && partial_ws && stats, "groupnorm_stats: null pointer");
+  DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_stats: C (%d) must be a power of two in [32,2048]", C);
+  DOVE_CHECK_ARG(npix > 0 && ws_blocks > 0, "groupnorm_stats: empty input");
+  int cpp_log = 0;
+  while ((1 << cpp_log) < C / 8) ++cpp_log;
+  DOVE_CHECK_ARG(cpp_log <= 8, "groupnorm_stats: C too large");
+  const int nsub = 256 >> cpp_log;
+  long long want = (npix + nsub - 1) / nsub;
+  int blocks = (int)(want < ws_blocks ? want : ws_blocks);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, npix, C, cpp_log, (float*)partial_ws);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(partial)");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)partial_ws, blocks,
+                     (double)npix * (double)(C / 32), eps, stats);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
+  return DOVE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm apply (+ SpatialNorm3D conditioning) + SiLU.
+//   y = silu( ((x - mean_g) * rstd_g * gamma_c + beta_c) [ * Y[z(p)][c] + B[z(p)][c] ] )
+// `yb` is the [Tz, hz, wz, 2C] table conv_y(zq) || conv_b(zq) computed on the LATENT grid by the igemm
+// kernel; the nearest-neighbour resize of zq to f's (T,H,W) becomes a gather index (never materialised).
+// ------------------------------------------------------------------------------------------------
+struct GnApplyArgs {
+  const bf16_t* x; bf16_t* y; const float* stats; const float* gamma; const float* beta;
+  const bf16_t* yb;
+  int T, H, W, C, cpp_log;
+  int hz, wz, sshift;
+  int tmap[32];
+  int act;
+};
+
+// grid = (rows of H, T): each block walks image rows, threads = (C/8 channel chunks) x (256/(C/8)) pixels
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyArgs a) {
+  const int tid = threadIdx.x;
+  const int cpp = 1 << a.cpp_log;
+  const int q = tid & (cpp - 1), sub = tid >> a.cpp_log;
+  const int nsub = 256 >> a.cpp_log;
+  const int cpg = a.C / 32;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = q * 8 + e, g = ch / cpg;
+    const float mean = a.stats[g * 2], rstd = a.stats[g * 2 + 1];
+    sc[e] = rstd * a.gamma[ch];
+    sh[e] = a.beta[ch] - mean * sc[e];
+  }
+  const int t = blockIdx.y;
+  const int tz = a.tmap[t];
+  for (int h = blockIdx.x; h < a.H; h += gridDim.x) {
+    const long long rowbase = ((long long)t * a.H + h) * a.W;
+    const long long zrow = ((long long)tz * a.hz + (h >> a.sshift)) * a.wz;
+    for (int w = sub; w < a.W; w += nsub) {
+      const long long p = rowbase + w;
+      float f[8];
+      unpack8(*(const uint4*)(a.x + p * a.C + q * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = f[e] * sc[e] + sh[e];
+      if (a.yb) {
+        const bf16_t* yb = a.yb + (zrow + (w >> a.sshift)) * (2 * a.C) + q * 8;
+        float fy[8], fb[8];
+        unpack8(*(const uint4*)yb, fy);
+        unpack8(*(const uint4*)(yb + a.C), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * fy[e] + fb[e];
+      }
+      if (a.act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+      }
+      *(uint4*)(a.y + p * a.C + q * 8) = pack8(f);
+    }
+  }
+}
+
+extern "C" int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, int W, int C, const float* stats,
+                                          const float* gamma, const float* beta, int silu, const void* yb, int hz,
+                                          int wz, int sshift, const int* tmap, void* stream) {
+  DOVE_CHECK_ARG(x && y && stats && gamma && beta, "groupnorm_apply: null pointer");
+  DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_apply: C (%d) must be a power of two in [32,2048]", C);
+  DOVE_CHECK_ARG(T > 0 && T <= 32 && H > 0 && W > 0, "groupnorm_apply: need 0 < T <= 32 frames per batch (got %d), H, W > 0", T);
+  GnApplyArgs a;
+  a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.stats = stats; a.gamma = gamma; a.beta = beta; a.yb = (const bf16_t*)yb;
+  a.T = T; a.H = H; a.W = W; a.C = C; a.act = silu;
+  int cpp_log = 0;
+  while ((1 << cpp_log) < C / 8) ++cpp_log;
+  a.cpp_log = cpp_log;
+  a.hz = hz; a.wz = wz; a.sshift = sshift;
+  for (int i = 0; i < 32; ++i) a.tmap[i] = 0;
+  if (yb) {
+    DOVE_CHECK_ARG(tmap, "groupnorm_apply: spatial norm needs a frame map");
+    DOVE_CHECK_ARG(sshift >= 0 && sshift <= 8 && (hz << sshift) >= H && (wz << sshift) >= W, "groupnorm_apply: latent grid too small");
+    for (int i = 0; i < T; ++i) a.tmap[i] = tmap[i];
+  }
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(H < 4096 ? H : 4096, T), dim3(256), 0, (hipStream_t)stream, a);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_apply_bf16");
+  return DOVE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim D (affine) followed by AdaLN modulation y = LN(x)*(1+scale)+shift,
+// with (shift, scale) chosen by row class: rows < split use mod[0] (text), else mod[1] (video).
+// mod layout: [2 classes][2 (shift, scale)][D] fp32; mod == nullptr -> plain LayerNorm.
+// One wave per row, row kept in registers (D <= 4096), two-pass mean/variance in fp32.
+// ------------------------------------------------------------------------------------------------
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                     long long rows, int D, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mod, long long split) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * D;
+  float f[NIT][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < D) {
+      unpack8(*(const uint4*)(xr + c0), f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += f[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < D) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; v += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+  const float* shift = mod ? mod + (row < split ? 0 : 2 * (long long)D) : nullptr;
+  const float* scale = mod ? shift + D : nullptr;
+  bf16_t* yr = y + row * D;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    if (c0 < D) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (f[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+        if (mod) t = t * (1.0f + scale[c0 + e]) + shift[c0 + e];
+        o[e] = t;
+      }
+      *(uint4*)(yr + c0) = pack8(o);
+    }
+  }
+}
+
+extern "C" int dove_layernorm_modulate_bf16(const void* x, void* y, long long rows, int D, float eps,
+                                             const float* gamma, const float* beta, const float* mod,
+                                             long long split, void* stream) {
+  DOVE_CHECK_ARG(x && y && gamma && beta, "layernorm_modulate: null pointer");
+  DOVE_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 4096, "layernorm_modulate: D (%d) must be a multiple of 8, <= 4096", D);
+  DOVE_CHECK_ARG(rows > 0, "layernorm_modulate: empty input");
+  const int nit = (D + 511) / 512;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(N)                                                                                        \
+  hipLaunchKernelGGL((ln_mod_kernel<N>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, D, eps, \
+                     gamma, beta, mod, split)
+  switch (nit) {
+    case 1: LN_LAUNCH(1); break;
+    case 2: LN_LAUNCH(2); break;
+    case 3: LN_LAUNCH(3); break;
+    case 4: LN_LAUNCH(4); break;
+    case 5: LN_LAUNCH(5); break;
+    case 6: LN_LAUNCH(6); break;
+    case 7: LN_LAUNCH(7); break;
+    default: LN_LAUNCH(8); break;
+  }
+#undef LN_LAUNCH
+  DOVE_CHECK_LAUNCH("dove_layernorm_modulate_bf16");
+  return DOVE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// qkv_post: split the fused QKV projection [N, 3*D] into head-major attention operands.
+//   Q' [H][Npad][64] = RoPE(LN64(q)) * (softmax_scale * log2 e)      (rows >= text_len get RoPE)
+//   K' [H][Npad][64] = RoPE(LN64(k))
+//   V^T[H][64][Npad] = v transposed (so the PV MFMA reads its A operand like K)
+// One lane owns one (token, head) 64-vector: LayerNorm and the interleaved-pair rotation are lane-local.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict__ qkv, long long N, long long Npad,
+                                                       int heads, int text_len, const float* __restrict__ gq,
+                                                       const float* __restrict__ bq, const float* __restrict__ gk,
+                                                       const float* __restrict__ bk, const float* __restrict__ cosT,
+                                                       const float* __restrict__ sinT, float qscale, float eps,
+                                                       bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh,
+                                                       bf16_t* __restrict__ Vt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y;
+  const int which = blockIdx.z;  // 0 q, 1 k, 2 v
+  const long long n = ((long long)blockIdx.x * 4 + wave) * 64 + lane;
+  if (n >= N) return;
+  const int D = heads * 64;
+  const bf16_t* src = qkv + n * (3LL * D) + (long long)which * D + h * 64;
+  float f[64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) unpack8(*(const uint4*)(src + i * 8), f + i * 8);
+  if (which == 2) {
+    bf16_t* dst = Vt + ((long long)h * 64) * Npad + n;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) dst[(long long)d * Npad] = f2bf(f[d]);
+    return;
+  }
+  const float* gam = which == 0 ? gq : gk;
+  const float* bet = which == 0 ? bq : bk;
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) s += f[d];
+  const float mean = s * (1.0f / 64.0f);
+  float v = 0.f;
+#pragma unroll
+  for (int d = 0; d < 64; ++d) { const float t = f[d] - mean; v += t * t; }
+  const float rstd = rsqrtf(v * (1.0f / 64.0f) + eps);
+#pragma unroll
+  for (int d = 0; d < 64; ++d) f[d] = (f[d] - mean) * rstd * gam[d] + bet[d];
+  if (n >= text_len && cosT) {
+    // diffusers rounds LN output to the model dtype before apply_rotary_emb's fp32 math; keep fp32 here
+    const float* cr = cosT + (n - text_len) * 64;
+    const float* sr = sinT + (n - text_len) * 64;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const float a = f[2 * i], b = f[2 * i + 1];
+      f[2 * i] = a * cr[2 * i] - b * sr[2 * i];
+      f[2 * i + 1] = b * cr[2 * i + 1] + a * sr[2 * i + 1];
+    }
+  }
+  const float sc = which == 0 ? qscale : 1.0f;
+  bf16_t* dst = (which == 0 ? Qh : Kh) + ((long long)h * Npad + n) * 64;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f[i * 8 + e] * sc;
+    *(uint4*)(dst + i * 8) = pack8(o);
+  }
+}
+
+extern "C" int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
+                                   const float* gq, const float* bq, const float* gk, const float* bk,
+                                   const float* cosT, const float* sinT, float qscale, float eps, void* Qh, void* Kh,
+                                   void* Vt, void* stream) {
+  DOVE_CHECK_ARG(qkv && Qh && Kh && Vt && gq && bq && gk && bk, "qkv_post: null pointer");
+  DOVE_CHECK_ARG(head_dim == 64, "qkv_post: head_dim must be 64 (got %d)", head_dim);
+  DOVE_CHECK_ARG(N > 0 && Npad >= N && Npad % 128 == 0, "qkv_post: Npad must be a multiple of 128 and >= N");
+  DOVE_CHECK_ARG((cosT == nullptr) == (sinT == nullptr), "qkv_post: cos/sin must both be given or both be null");
+  dim3 grid((unsigned)((N + 255) / 256), heads, 3);
+  hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
+                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh, (bf16_t*)Vt);
+  DOVE_CHECK_LAUNCH("dove_qkv_post_bf16");
+  return DOVE_OK;
+}

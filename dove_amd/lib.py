@@ -1,0 +1,99 @@
+"""ctypes binding of libdove_hip.so (include/dove_hip.h).  No CPU fallback: every op raises if the
+library is missing or the call fails -- the product path never routes through torch math or the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdove_hip.so")
+_lib = None
+
+F32, BF16 = 0, 1
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("cache", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("resid", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
+        ("t_in", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("cin", C.c_int),
+        ("t_out", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("cout_pad", C.c_int), ("cout_store", C.c_int),
+        ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
+        ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
+        ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
+    ]
+
+
+_VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> argtypes; the symbol list doubles as the export check in tests/test_abi.py
+SIGNATURES = {
+    "dove_conv_igemm_bf16": [C.POINTER(ConvDesc), _VP],
+    "dove_groupnorm_stats_bf16": [_VP, _LL, _I, _F, _VP, _I, _VP, _VP],
+    "dove_groupnorm_apply_bf16": [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, C.POINTER(C.c_int), _VP],
+    "dove_layernorm_modulate_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP, _VP, _LL, _VP],
+    "dove_qkv_post_bf16": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP],
+    "dove_attention_fwd_bf16": [_VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP],
+    "dove_cl_from_ncthw": [_VP, _I, _I, _LL, _I, _F, _F, _VP, _VP],
+    "dove_ncthw_from_cl": [_VP, _LL, _I, _LL, _F, _F, _F, _F, _VP, _I, _VP],
+    "dove_avgpool_time_bf16": [_VP, _I, _LL, _VP, _VP],
+    "dove_posterior_sample": [_VP, _LL, _I, _LL, _VP, _I, _VP, _I, _VP],
+    "dove_axpby": [_VP, _VP, _VP, _I, _LL, _F, _F, _VP],
+    "dove_patchify": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _LL, _VP],
+    "dove_unpatchify": [_VP, _LL, _I, _I, _I, _I, _I, _I, _VP, _I, _VP],
+    "dove_gemv_bf16": [_VP, _VP, _VP, _I, _I, _I, _VP, _VP],
+}
+PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
+         "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)])}
+
+
+def load():
+    """Load libdove_hip.so (built by ``__graft_entry__.build()`` / dove_amd/csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(dove_amd has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = C.c_int
+    for name, (res, argt) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argt
+        fn.restype = res
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().dove_last_error().decode()}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def dt_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"dove_amd supports float32 / bfloat16 boundary tensors, got {t.dtype}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dove_amd ops need tensors on the HIP device (`cuda`); there is no CPU path")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("dove_amd ops need contiguous tensors")

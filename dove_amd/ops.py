@@ -1,0 +1,253 @@
+"""torch-tensor front end of the C-ABI operators (allocation + argument marshalling only; all arithmetic is
+in libdove_hip.so).  Activations are channels-last bf16: [T,H,W,C] (VAE) or [N,C] (DiT tokens)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import lib as L
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class PackedConv:
+    """Weights repacked for the implicit-GEMM kernel: [taps][cout_pad][cin_pad] bf16, bias fp32 [cout_pad]."""
+    w: torch.Tensor
+    bias: torch.Tensor | None
+    kt: int
+    kh: int
+    kw: int
+    cin: int
+    cin_pad: int
+    cout: int
+    cout_pad: int
+
+    @property
+    def cout_store(self) -> int:
+        return _ru(self.cout, 4)
+
+
+def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> PackedConv:
+    """weight: Conv3d [Cout,Cin,kt,kh,kw], Conv2d [Cout,Cin,kh,kw] or Linear [Cout,Cin] (any float dtype)."""
+    w = weight.detach()
+    if w.dim() == 2:
+        w = w[:, :, None, None, None]
+    elif w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    cin_pad = _ru(cin, 32) if cin <= 32 or cin % 64 else cin
+    cout_pad = _ru(cout, 32)
+    wp = torch.zeros(kt * kh * kw, cout_pad, cin_pad, dtype=torch.bfloat16, device=device)
+    wp[:, :cout, :cin] = w.to(device=device, dtype=torch.float32).permute(2, 3, 4, 0, 1).reshape(kt * kh * kw, cout, cin).to(torch.bfloat16)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(cout_pad, dtype=torch.float32, device=device)
+        bp[:cout] = bias.detach().to(device=device, dtype=torch.float32)
+    return PackedConv(wp.contiguous(), bp, kt, kh, kw, cin, cin_pad, cout, cout_pad)
+
+
+def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
+         up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
+         gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
+         out: torch.Tensor | None = None) -> torch.Tensor:
+    """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo]."""
+    L.require_cuda(x, cache, resid, gate, out)
+    assert x.dtype == torch.bfloat16 and x.dim() == 4, (x.dtype, x.shape)
+    T, H, W, Cx = x.shape
+    if Cx != pc.cin_pad:
+        raise RuntimeError(f"conv: input has {Cx} channels, packed weight expects {pc.cin_pad}")
+    ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
+    pw = (pc.kw - 1) // 2 if pad[1] is None else pad[1]
+    if t_out is None:
+        t_out = T
+    if hw_out is None:
+        hw_out = (H << up, W << up) if stride == 1 else ((H + 1 - pc.kh) // stride + 1, (W + 1 - pc.kw) // stride + 1)
+    if ldo is None:
+        ldo = pc.cout_store
+    if out is None:
+        out = torch.empty(t_out, hw_out[0], hw_out[1], ldo, dtype=torch.bfloat16, device=x.device)
+    else:
+        assert out.shape == (t_out, hw_out[0], hw_out[1], ldo) and out.dtype == torch.bfloat16
+    if cache is not None:
+        assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
+    d = L.ConvDesc()
+    d.x, d.cache, d.w = x.data_ptr(), (cache.data_ptr() if cache is not None else None), pc.w.data_ptr()
+    d.bias = pc.bias.data_ptr() if pc.bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.gate = gate.data_ptr() if gate is not None else None
+    d.out = out.data_ptr()
+    d.t_in, d.h_in, d.w_in, d.cin = T, H, W, Cx
+    d.t_out, d.h_out, d.w_out = t_out, hw_out[0], hw_out[1]
+    d.cout_pad, d.cout_store = pc.cout_pad, pc.cout_store
+    d.kt, d.kh, d.kw, d.stride, d.pad_h, d.pad_w = pc.kt, pc.kh, pc.kw, stride, ph, pw
+    d.up, d.tmode, d.act = up, tmode, act
+    d.ldo = ldo
+    d.ldr = resid.shape[-1] if resid is not None else 0
+    d.gate_split = gate_split
+    if resid is not None:
+        assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
+    L.check(L.load().dove_conv_igemm_bf16(C.byref(d), L.stream_ptr()), "dove_conv_igemm_bf16")
+    return out
+
+
+def linear(x: torch.Tensor, pc: PackedConv, **kw) -> torch.Tensor:
+    """x [N, cin_pad] -> [N, ldo]."""
+    N = x.shape[0]
+    out = kw.pop("out", None)
+    resid = kw.pop("resid", None)
+    y = conv(x.view(1, 1, N, x.shape[1]), pc, resid=None if resid is None else resid.view(1, 1, N, resid.shape[1]),
+             out=None if out is None else out.view(1, 1, N, out.shape[1]), **kw)
+    return y.view(N, y.shape[-1])
+
+
+_gn_ws: dict = {}
+
+
+def _ws(device):
+    key = str(device)
+    if key not in _gn_ws:
+        _gn_ws[key] = torch.empty(2048 * 64, dtype=torch.float32, device=device)
+    return _gn_ws[key]
+
+
+def groupnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """x [T,H,W,C] (one frame-batch) -> stats [32,2] (mean, rstd) fp32."""
+    L.require_cuda(x)
+    assert x.dtype == torch.bfloat16
+    Cc = x.shape[-1]
+    stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
+    ws = _ws(x.device)
+    L.check(L.load().dove_groupnorm_stats_bf16(L.ptr(x), x.numel() // Cc, Cc, eps, L.ptr(ws), 2048, L.ptr(stats),
+                                               L.stream_ptr()), "dove_groupnorm_stats_bf16")
+    return stats
+
+
+def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
+    """y = silu?(GN(x) [* Y + B]) with the SpatialNorm3D table yb [Tz,hz,wz,2C] gathered by nearest resize."""
+    L.require_cuda(x, stats, gamma, beta, yb, out)
+    T, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    hz = wz = 0
+    tm = None
+    if yb is not None:
+        assert yb.dtype == torch.bfloat16 and yb.shape[-1] == 2 * Cc and tmap is not None and len(tmap) == T
+        hz, wz = yb.shape[1], yb.shape[2]
+        tm = (C.c_int * T)(*tmap)
+    L.check(L.load().dove_groupnorm_apply_bf16(L.ptr(x), L.ptr(out), T, H, W, Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                               int(silu), L.ptr(yb), hz, wz, sshift, tm, L.stream_ptr()),
+            "dove_groupnorm_apply_bf16")
+    return out
+
+
+def layernorm_modulate(x, gamma, beta, eps, mod=None, split=0, out=None):
+    L.require_cuda(x, gamma, beta, mod, out)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    if mod is not None:
+        assert mod.dtype == torch.float32 and mod.shape == (2, 2, x.shape[1])
+    L.check(L.load().dove_layernorm_modulate_bf16(L.ptr(x), L.ptr(out), x.shape[0], x.shape[1], eps, L.ptr(gamma),
+                                                  L.ptr(beta), L.ptr(mod), split, L.stream_ptr()),
+            "dove_layernorm_modulate_bf16")
+    return out
+
+
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt):
+    L.require_cuda(qkv, gq, bq, gk, bk, cos, sin, Qh, Kh, Vt)
+    L.check(L.load().dove_qkv_post_bf16(L.ptr(qkv), N, Npad, heads, 64, text_len, L.ptr(gq), L.ptr(bq), L.ptr(gk), L.ptr(bk),
+                                        L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt),
+                                        L.stream_ptr()), "dove_qkv_post_bf16")
+
+
+def attention(Qh, Kh, Vt, N, Npad, heads, out):
+    L.require_cuda(Qh, Kh, Vt, out)
+    L.check(L.load().dove_attention_fwd_bf16(L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), L.ptr(out), N, Npad, heads, 64, out.shape[1],
+                                             L.stream_ptr()), "dove_attention_fwd_bf16")
+    return out
+
+
+def cl_from_ncthw(x: torch.Tensor, cp: int, scale=1.0, shift=0.0) -> torch.Tensor:
+    """[C,T,H,W] fp32/bf16 -> [T,H,W,cp] bf16 (zero-padded channels)."""
+    L.require_cuda(x)
+    Cc, T, H, W = x.shape
+    y = torch.empty(T, H, W, cp, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_cl_from_ncthw(L.ptr(x), L.dt_code(x), Cc, T * H * W, cp, scale, shift, L.ptr(y), L.stream_ptr()),
+            "dove_cl_from_ncthw")
+    return y
+
+
+def ncthw_from_cl(x: torch.Tensor, Cc: int, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf) -> torch.Tensor:
+    """[T,H,W,ld] bf16 -> [Cc,T,H,W] dtype, y = clamp(x*scale+shift, lo, hi)."""
+    L.require_cuda(x)
+    T, H, W, ld = x.shape
+    y = torch.empty(Cc, T, H, W, dtype=dtype, device=x.device)
+    L.check(L.load().dove_ncthw_from_cl(L.ptr(x), ld, Cc, T * H * W, scale, shift, lo, hi, L.ptr(y), L.dt_code(y),
+                                        L.stream_ptr()), "dove_ncthw_from_cl")
+    return y
+
+
+def avgpool_time(x: torch.Tensor) -> torch.Tensor:
+    L.require_cuda(x)
+    T, H, W, Cc = x.shape
+    if T == 1:
+        return x
+    To = 1 + (T - 1) // 2 if T % 2 else T // 2
+    y = torch.empty(To, H, W, Cc, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_avgpool_time_bf16(L.ptr(x), T, H * W * Cc, L.ptr(y), L.stream_ptr()), "dove_avgpool_time_bf16")
+    return y
+
+
+def posterior_sample(moments_cl: torch.Tensor, latent_channels: int, noise: torch.Tensor, dtype) -> torch.Tensor:
+    """moments [T,h,w,>=2L] bf16 + noise [L,T,h,w] -> sample [L,T,h,w] dtype."""
+    L.require_cuda(moments_cl, noise)
+    T, h, w, ld = moments_cl.shape
+    out = torch.empty(latent_channels, T, h, w, dtype=dtype, device=noise.device)
+    L.check(L.load().dove_posterior_sample(L.ptr(moments_cl), ld, latent_channels, T * h * w, L.ptr(noise), L.dt_code(noise),
+                                           L.ptr(out), L.dt_code(out), L.stream_ptr()), "dove_posterior_sample")
+    return out
+
+
+def axpby(x, y, a: float, b: float):
+    L.require_cuda(x, y)
+    assert x.shape == y.shape and x.dtype == y.dtype
+    out = torch.empty_like(x)
+    L.check(L.load().dove_axpby(L.ptr(x), L.ptr(y), L.ptr(out), L.dt_code(x), x.numel(), a, b, L.stream_ptr()), "dove_axpby")
+    return out
+
+
+def patchify(x: torch.Tensor, pt: int, p: int, ld: int) -> torch.Tensor:
+    """[T,C,h,w] -> tokens [Nv, ld] bf16 (features beyond C*pt*p*p zero)."""
+    L.require_cuda(x)
+    T, Cc, H, W = x.shape
+    nv = (T // pt) * (H // p) * (W // p)
+    feat = Cc * pt * p * p
+    tok = (torch.zeros if ld > feat else torch.empty)(nv, ld, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_patchify(L.ptr(x), L.dt_code(x), T, Cc, H, W, pt, p, L.ptr(tok), ld, L.stream_ptr()), "dove_patchify")
+    return tok
+
+
+def unpatchify(tok: torch.Tensor, T, Cc, H, W, pt, p, dtype) -> torch.Tensor:
+    L.require_cuda(tok)
+    y = torch.empty(T, Cc, H, W, dtype=dtype, device=tok.device)
+    L.check(L.load().dove_unpatchify(L.ptr(tok), tok.shape[1], T, Cc, H, W, pt, p, L.ptr(y), L.dt_code(y), L.stream_ptr()),
+            "dove_unpatchify")
+    return y
+
+
+def gemv(W: torch.Tensor, bias, x: torch.Tensor, act_in: int = 0) -> torch.Tensor:
+    """y = W @ act(x) + b for one vector; W [out,in] bf16, x fp32 [in] -> fp32 [out]."""
+    L.require_cuda(W, bias, x)
+    assert W.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.numel() == W.shape[1]
+    y = torch.empty(W.shape[0], dtype=torch.float32, device=x.device)
+    L.check(L.load().dove_gemv_bf16(L.ptr(W), L.ptr(bias), L.ptr(x), W.shape[1], W.shape[0], act_in, L.ptr(y), L.stream_ptr()),
+            "dove_gemv_bf16")
+    return y

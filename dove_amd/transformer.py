@@ -1,0 +1,180 @@
+"""CogVideoXTransformer3DModel facade over the HIP operators.
+
+``pipe.transformer(hidden_states=[B,T,16,h,w], encoder_hidden_states=[B,L,4096], timestep=[B],
+image_rotary_emb=(cos,sin), return_dict=False)[0]`` as called at /root/reference/inference_script.py:483-489,
+computing diffusers' CogVideoX1.5 DiT forward: patch embed, 42 x {LayerNormZero, joint
+[text;video] attention with per-head QK LayerNorm + 3D RoPE on video rows, gated residual, LayerNormZero,
+GELU(tanh) MLP, gated residual}, norm_final, AdaLayerNorm, proj_out, un-patchify.
+
+The residual stream is ONE token-major bf16 buffer [N = L + Nv, D] (text rows first); every per-block operator
+runs over all N rows with row-class dependent modulation / gates, so text and video never need a concat.
+Timestep-dependent vectors (time-embedding MLP, 2x42+1 AdaLN projections) are M=1 GEMVs cached per timestep
+(sr_noise_step is constant, ref :535).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .config import AttrDict
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class CogVideoXTransformer3DModel:
+    def __init__(self, config: dict, state_dict: dict, device="cuda", dtype=torch.bfloat16):
+        self.config = AttrDict(config)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        c = self.config
+        self.heads, self.hd = c["num_attention_heads"], c["attention_head_dim"]
+        if self.hd != 64:
+            raise NotImplementedError("HIP attention kernels are built for head_dim 64")
+        self.D = self.heads * self.hd
+        self.L = c["num_layers"]
+        self.p, self.pt = c["patch_size"], c["patch_size_t"]
+        if self.pt is None:
+            raise NotImplementedError("patch_size_t=None (CogVideoX 1.0) is not on DOVE's path")
+        if not c.get("use_rotary_positional_embeddings", True) or c.get("use_learned_positional_embeddings", False):
+            raise NotImplementedError("only the RoPE configuration of CogVideoX1.5 is implemented")
+        self.eps = c.get("norm_eps", 1e-5)
+        self._mod_cache = {}
+        self._bufs = {}
+        self._pack(state_dict)
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def _pack(self, sd):
+        dev = self.device
+        f32 = lambda k: sd[k].to(dev, torch.float32).contiguous()          # noqa: E731
+        b16 = lambda k: sd[k].to(dev, torch.bfloat16).contiguous()         # noqa: E731
+        lin = lambda n: ops.pack_conv(sd[n + ".weight"], sd.get(n + ".bias"), dev)   # noqa: E731
+        self.pe_proj = lin("patch_embed.proj")
+        self.pe_text = lin("patch_embed.text_proj")
+        self.te = [(b16(f"time_embedding.linear_{i}.weight"), f32(f"time_embedding.linear_{i}.bias")) for i in (1, 2)]
+        self.blocks = []
+        for i in range(self.L):
+            b = f"transformer_blocks.{i}."
+            wqkv = torch.cat([sd[b + f"attn1.{n}.weight"] for n in ("to_q", "to_k", "to_v")], dim=0)
+            bqkv = torch.cat([sd[b + f"attn1.{n}.bias"] for n in ("to_q", "to_k", "to_v")], dim=0)
+            self.blocks.append(dict(
+                mod1=(b16(b + "norm1.linear.weight"), f32(b + "norm1.linear.bias")),
+                ln1=(f32(b + "norm1.norm.weight"), f32(b + "norm1.norm.bias")),
+                qkv=ops.pack_conv(wqkv, bqkv, dev),
+                nq=(f32(b + "attn1.norm_q.weight"), f32(b + "attn1.norm_q.bias")),
+                nk=(f32(b + "attn1.norm_k.weight"), f32(b + "attn1.norm_k.bias")),
+                out=lin(b + "attn1.to_out.0"),
+                mod2=(b16(b + "norm2.linear.weight"), f32(b + "norm2.linear.bias")),
+                ln2=(f32(b + "norm2.norm.weight"), f32(b + "norm2.norm.bias")),
+                ff1=lin(b + "ff.net.0.proj"),
+                ff2=lin(b + "ff.net.2"),
+            ))
+        self.norm_final = (f32("norm_final.weight"), f32("norm_final.bias"))
+        self.mod_out = (b16("norm_out.linear.weight"), f32("norm_out.linear.bias"))
+        self.norm_out = (f32("norm_out.norm.weight"), f32("norm_out.norm.bias"))
+        self.proj_out = lin("proj_out")
+
+    # ---- timestep-dependent constants ----------------------------------------------------------------
+    def _modulation(self, t: int):
+        """emb = time_embedding(sinusoid(t)); per block the six AdaLN-Zero chunks (shift, scale, gate, enc_shift,
+        enc_scale, enc_gate) regrouped as mod[class][shift|scale][D] and gate[class][D], class 0 = text rows."""
+        if t in self._mod_cache:
+            return self._mod_cache[t]
+        D, c = self.D, self.config
+        half = D // 2
+        expo = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - c.get("freq_shift", 0))
+        ang = float(t) * torch.exp(expo)
+        temb = torch.cat([torch.sin(ang), torch.cos(ang)])
+        if c.get("flip_sin_to_cos", True):
+            temb = torch.cat([temb[half:], temb[:half]])
+        # the reference casts the sinusoid to the model dtype before linear_1
+        temb = temb.to(self.dtype).to(torch.float32).to(self.device)
+        e1 = ops.gemv(self.te[0][0], self.te[0][1], temb, act_in=0)
+        emb = ops.gemv(self.te[1][0], self.te[1][1], e1, act_in=1)
+        out = []
+        for blk in self.blocks:
+            item = {}
+            for key, gname, mname in (("mod1", "gate1", "m1"), ("mod2", "gate2", "m2")):
+                v = ops.gemv(blk[key][0], blk[key][1], emb, act_in=1).view(6, D)
+                item[mname] = torch.stack([torch.stack([v[3], v[4]]), torch.stack([v[0], v[1]])]).contiguous()
+                g = torch.zeros(2, _ru(D, 32), dtype=torch.float32, device=self.device)
+                g[0, :D], g[1, :D] = v[5], v[2]
+                item[gname] = g
+            out.append(item)
+        v = ops.gemv(self.mod_out[0], self.mod_out[1], emb, act_in=1).view(2, D)   # (shift, scale)
+        final = torch.stack([torch.stack([v[0], v[1]]), torch.stack([v[0], v[1]])]).contiguous()
+        self._mod_cache = {t: (out, final)}
+        return self._mod_cache[t]
+
+    def _buffers(self, N):
+        """Persistent head-major attention operands; pad rows/columns stay zero across calls."""
+        npad = _ru(N, 128)
+        key = (N,)
+        if key not in self._bufs:
+            z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)   # noqa: E731
+            self._bufs = {key: (npad, z(self.heads, npad, 64), z(self.heads, npad, 64), z(self.heads, 64, npad))}
+        return self._bufs[key]
+
+    # ---- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None,
+                 image_rotary_emb=None, attention_kwargs=None, return_dict: bool = True):
+        if image_rotary_emb is None:
+            raise ValueError("image_rotary_emb is required (use_rotary_positional_embeddings=True)")
+        B = hidden_states.shape[0]
+        ts = [int(v) for v in timestep.reshape(-1).tolist()]
+        if len(ts) == 1:
+            ts = ts * B
+        outs = [self._forward_one(hidden_states[b], encoder_hidden_states[b], ts[b], image_rotary_emb) for b in range(B)]
+        out = torch.stack(outs)
+        if return_dict:
+            class _O:  # Transformer2DModelOutput-like
+                sample = out
+            return _O()
+        return (out,)
+
+    forward = __call__
+
+    def _forward_one(self, hidden, text, t, rope):
+        D, Lh = self.D, self.heads
+        T, Cc, H, W = hidden.shape
+        p, pt = self.p, self.pt
+        hidden = hidden.to(self.device).contiguous()
+        text = text.to(self.device, torch.bfloat16).contiguous()
+        cos, sin = (r.to(self.device, torch.float32).contiguous() for r in rope)
+        Lt = text.shape[0]
+        nv = (T // pt) * (H // p) * (W // p)
+        assert cos.shape == (nv, self.hd), (cos.shape, nv)
+        N = Lt + nv
+        blocks_mod, final_mod = self._modulation(t)
+        npad, Qh, Kh, Vt = self._buffers(N)
+
+        hs = torch.empty(N, D, dtype=torch.bfloat16, device=self.device)
+        tok = ops.patchify(hidden, pt, p, self.pe_proj.cin_pad)
+        ops.linear(text, self.pe_text, out=hs[:Lt])
+        ops.linear(tok, self.pe_proj, out=hs[Lt:])
+        qscale = (self.hd ** -0.5) * math.log2(math.e)
+        for blk, md in zip(self.blocks, blocks_mod):
+            n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], self.eps, md["m1"], Lt)
+            qkv = ops.linear(n1, blk["qkv"])
+            ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
+                         1e-6, Qh, Kh, Vt)
+            att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1)          # reuse n1's storage for the attention output
+            ops.linear(att, blk["out"], resid=hs, gate=md["gate1"], gate_split=Lt, out=hs)
+            n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
+            f1 = ops.linear(n2, blk["ff1"], act=1)
+            ops.linear(f1, blk["ff2"], resid=hs, gate=md["gate2"], gate_split=Lt, out=hs)
+        xv = hs[Lt:]
+        xv = ops.layernorm_modulate(xv, self.norm_final[0], self.norm_final[1], self.eps)
+        xv = ops.layernorm_modulate(xv, self.norm_out[0], self.norm_out[1], self.eps, final_mod, 0)
+        o = ops.linear(xv, self.proj_out)
+        return ops.unpatchify(o, T, Cc, H, W, pt, p, self.dtype)

@@ -1,0 +1,241 @@
+"""AutoencoderKLCogVideoX facade over the HIP operators.
+
+Exposes what /root/reference/inference_script.py touches on ``pipe.vae`` (``.device``, ``.dtype``,
+``.config.scaling_factor``, ``.config.block_out_channels``, ``.encode(x).latent_dist.sample()``,
+``.decode(z).sample``, ``.enable_slicing()``, ``.enable_tiling()``; :407-409,467,500,644-645) and computes
+what diffusers' 3D causal VAE computes: frame-batched (8 px-frames / 2 latent
+frames) encoder/decoder with per-conv temporal caches, GroupNorm statistics scoped to one frame-batch.
+
+Internal layout is channels-last bf16 [T,H,W,C]; the graph below only allocates tensors and calls the C-ABI
+operators of libdove_hip.so (dove_amd.ops).  B > 1 is looped (the reference always runs B = 1).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .config import AttrDict
+
+
+def frame_batches(num_frames: int, batch: int):
+    """diffusers `_encode`/`_decode` batch rule: 33 @8 -> 9,8,8,8 ; 9 @2 -> 3,2,2,2."""
+    n = max(num_frames // batch, 1)
+    rem = num_frames % batch
+    return [(batch * i + (0 if i == 0 else rem), min(batch * (i + 1) + rem, num_frames)) for i in range(n)]
+
+
+def spatial_norm_tmap(t_f: int, t_z: int):
+    """Frame index of zq used for frame t of f under SpatialNorm3D's nearest resize (odd T>1 splits frame 0)."""
+    if t_f > 1 and t_f % 2 == 1:
+        if t_z == 1:
+            return [0] * t_f
+        return [0] + [1 + ((t - 1) * (t_z - 1)) // (t_f - 1) for t in range(1, t_f)]
+    return [(t * t_z) // t_f for t in range(t_f)]
+
+
+class DiagonalGaussianDistribution:
+    """Posterior over latents; moments are kept channels-last per batch element, sampled on the GPU."""
+
+    def __init__(self, moments_cl, latent_channels, dtype):
+        self._m = moments_cl          # list of [T,h,w,2L] bf16
+        self._L = latent_channels
+        self._dtype = dtype
+
+    @property
+    def parameters(self):
+        return torch.stack([ops.ncthw_from_cl(m, 2 * self._L, self._dtype) for m in self._m])
+
+    @property
+    def mean(self):
+        return self.parameters[:, : self._L]
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None, noise=None):
+        """mean + exp(0.5*clamp(logvar,-30,20)) * N(0,1).  ``noise`` ([B,L,T,h,w]) may be injected for
+        reproducible parity runs; otherwise it is drawn like diffusers' randn_tensor (global RNG of the device)."""
+        T, h, w, _ = self._m[0].shape
+        B = len(self._m)
+        if noise is None:
+            noise = torch.randn(B, self._L, T, h, w, generator=generator, device=self._m[0].device, dtype=self._dtype)
+        noise = noise.to(self._m[0].device).contiguous()
+        return torch.stack([ops.posterior_sample(m, self._L, noise[b], self._dtype) for b, m in enumerate(self._m)])
+
+
+class _Out:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class AutoencoderKLCogVideoX:
+    def __init__(self, config: dict, state_dict: dict, device="cuda", dtype=torch.bfloat16):
+        self.config = AttrDict(config)
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.use_slicing = False
+        self.use_tiling = False
+        c = self.config
+        self.boc = list(c["block_out_channels"])
+        self.layers = c.get("layers_per_block", 3)
+        self.eps = c.get("norm_eps", 1e-6)
+        self.lat = c["latent_channels"]
+        self.n_tdown = int(math.log2(c.get("temporal_compression_ratio", 4)))
+        self.enc_batch = c.get("num_sample_frames_batch_size", 8)
+        self.dec_batch = c.get("num_latent_frames_batch_size", 2)
+        if c.get("norm_num_groups", 32) != 32:
+            raise NotImplementedError("HIP GroupNorm kernels are built for 32 groups")
+        self._pack(state_dict)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def _pack(self, sd):
+        dev = self.device
+        self.pc, self.aff = {}, {}
+        for k in sd:
+            if k.endswith(".conv.weight") and ".conv_y." not in k and ".conv_b." not in k:
+                n = k[: -len(".conv.weight")]
+                self.pc[n] = ops.pack_conv(sd[k], sd[n + ".conv.bias"], dev)
+            elif k.endswith(".conv_shortcut.weight"):
+                n = k[: -len(".weight")]
+                self.pc[n] = ops.pack_conv(sd[k], sd[n + ".bias"], dev)
+            elif k.endswith(".conv_y.conv.weight"):
+                n = k[: -len(".conv_y.conv.weight")]  # spatial norm: one [2C, L] 1x1x1 conv producing Y || B
+                w = torch.cat([sd[k], sd[n + ".conv_b.conv.weight"]], dim=0)
+                b = torch.cat([sd[n + ".conv_y.conv.bias"], sd[n + ".conv_b.conv.bias"]], dim=0)
+                self.pc[n + ".yb"] = ops.pack_conv(w, b, dev)
+                self.aff[n] = (sd[n + ".norm_layer.weight"].to(dev, torch.float32).contiguous(),
+                               sd[n + ".norm_layer.bias"].to(dev, torch.float32).contiguous())
+            elif k.endswith(".weight") and sd[k].dim() == 1 and ".norm_layer." not in k:
+                n = k[: -len(".weight")]
+                self.aff[n] = (sd[k].to(dev, torch.float32).contiguous(), sd[n + ".bias"].to(dev, torch.float32).contiguous())
+
+    # ---- toggles kept for API parity (ref :644-645) ---------------------------------------------
+    def enable_slicing(self):
+        self.use_slicing = True
+
+    def disable_slicing(self):
+        self.use_slicing = False
+
+    def enable_tiling(self, *a, **k):
+        self.use_tiling = True
+
+    def disable_tiling(self):
+        self.use_tiling = False
+
+    def to(self, *a, **k):
+        return self
+
+    # ---- building blocks ---------------------------------------------------------------------------
+    def _cconv(self, x, name, cache, **kw):
+        """CogVideoXCausalConv3d with conv_cache: the front halo is the last kt-1 input frames of the previous batch."""
+        pc = self.pc[name]
+        prev = cache.get(name)
+        if pc.kt > 1:
+            k = pc.kt - 1
+            if x.shape[0] >= k:
+                new = x[-k:].clone()
+            else:  # fewer frames than the halo: slide the padded window
+                pad = prev if prev is not None else x[:1].expand(k, -1, -1, -1)
+                new = torch.cat([pad, x], dim=0)[-k:].clone()
+            cache[name] = new
+        return ops.conv(x, pc, cache=prev if pc.kt > 1 else None, **kw)
+
+    def _norm_silu(self, x, name, zq=None):
+        stats = ops.groupnorm_stats(x, self.eps)
+        g, b = self.aff[name]
+        if zq is None:
+            return ops.groupnorm_apply(x, stats, g, b, silu=True)
+        yb = ops.conv(zq, self.pc[name + ".yb"])            # [Tz,hz,wz,2C] on the latent grid
+        ratio = x.shape[1] // zq.shape[1]
+        assert x.shape[1] == zq.shape[1] * ratio and x.shape[2] == zq.shape[2] * ratio and ratio & (ratio - 1) == 0
+        return ops.groupnorm_apply(x, stats, g, b, silu=True, yb=yb, sshift=ratio.bit_length() - 1,
+                                   tmap=spatial_norm_tmap(x.shape[0], zq.shape[0]))
+
+    def _resnet(self, x, name, cache, zq=None):
+        h = self._norm_silu(x, name + ".norm1", zq)
+        h = self._cconv(h, name + ".conv1", cache)
+        h = self._norm_silu(h, name + ".norm2", zq)
+        if name + ".conv_shortcut" in self.pc:
+            x = ops.conv(x, self.pc[name + ".conv_shortcut"])
+        return self._cconv(h, name + ".conv2", cache, resid=x)
+
+    def _downsample(self, x, name, compress_time):
+        if compress_time:
+            x = ops.avgpool_time(x)
+        return ops.conv(x, self.pc[name], stride=2, pad=(0, 0))
+
+    def _upsample(self, x, name, compress_time):
+        T = x.shape[0]
+        if compress_time and T > 1:
+            tmode, t_out = (2, 2 * T - 1) if T % 2 == 1 else (1, 2 * T)
+        else:
+            tmode, t_out = 0, T
+        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1))
+
+    def _encoder(self, x, cache):
+        h = self._cconv(x, "encoder.conv_in", cache)
+        nb = len(self.boc)
+        for i in range(nb):
+            for j in range(self.layers):
+                h = self._resnet(h, f"encoder.down_blocks.{i}.resnets.{j}", cache)
+            if i < nb - 1:
+                h = self._downsample(h, f"encoder.down_blocks.{i}.downsamplers.0", i < self.n_tdown)
+        for j in range(2):
+            h = self._resnet(h, f"encoder.mid_block.resnets.{j}", cache)
+        h = self._norm_silu(h, "encoder.norm_out")
+        return self._cconv(h, "encoder.conv_out", cache)
+
+    def _decoder(self, z, cache):
+        h = self._cconv(z, "decoder.conv_in", cache)
+        for j in range(2):
+            h = self._resnet(h, f"decoder.mid_block.resnets.{j}", cache, zq=z)
+        nb = len(self.boc)
+        for i in range(nb):
+            for j in range(self.layers + 1):
+                h = self._resnet(h, f"decoder.up_blocks.{i}.resnets.{j}", cache, zq=z)
+            if i < nb - 1:
+                h = self._upsample(h, f"decoder.up_blocks.{i}.upsamplers.0", i < self.n_tdown)
+        h = self._norm_silu(h, "decoder.norm_out", zq=z)
+        return self._cconv(h, "decoder.conv_out", cache)
+
+    # ---- public API -----------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """x [B,3,F,H,W] in [-1,1] -> .latent_dist (posterior over [B,L,1+(F-1)/4,H/8,W/8])."""
+        if x.dim() != 5:
+            raise ValueError("expected [B,C,F,H,W]")
+        if self.use_tiling and (x.shape[-1] > self.config.get("sample_width", 720) // 2 or
+                                x.shape[-2] > self.config.get("sample_height", 480) // 2):
+            raise NotImplementedError("VAE spatial tiling (--is_vae_st) is a SURVEY 8(f) follow-up; disable_tiling() "
+                                      "or run untiled (288 GB HBM holds the untiled 720p/1080p activations)")
+        x = x.to(self.device).contiguous()
+        cin_pad = self.pc["encoder.conv_in"].cin_pad
+        moments = []
+        for b in range(x.shape[0]):
+            x_cl = ops.cl_from_ncthw(x[b], cin_pad)
+            cache, outs = {}, []
+            for s, e in frame_batches(x_cl.shape[0], self.enc_batch):
+                outs.append(self._encoder(x_cl[s:e], cache))
+            moments.append(torch.cat(outs, dim=0) if len(outs) > 1 else outs[0])
+        dist = DiagonalGaussianDistribution(moments, self.lat, self.dtype)
+        return _Out(latent_dist=dist) if return_dict else (dist,)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True, _range01: bool = False, _prescale: float = 1.0):
+        """z [B,L,T,h,w] (already divided by scaling_factor) -> .sample [B,3,1+4(T-1),8h,8w]."""
+        z = z.to(self.device).contiguous()
+        cin_pad = self.pc["decoder.conv_in"].cin_pad
+        cout = self.config["out_channels"]
+        post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
+        vids = []
+        for b in range(z.shape[0]):
+            z_cl = ops.cl_from_ncthw(z[b], cin_pad, scale=_prescale)
+            cache, outs = {}, []
+            for s, e in frame_batches(z_cl.shape[0], self.dec_batch):
+                o = self._decoder(z_cl[s:e], cache)
+                outs.append(ops.ncthw_from_cl(o, cout, self.dtype, **post))
+            vids.append(torch.cat(outs, dim=1) if len(outs) > 1 else outs[0])
+        sample = torch.stack(vids)
+        return _Out(sample=sample) if return_dict else (sample,)

@@ -1,0 +1,116 @@
+/* libdove_hip.so -- C ABI of the MI355X-native (gfx950) operator library behind DOVE's one-step video-SR path.
+ *
+ * The reference (zhengchen1999/DOVE) has no FFI of its own: `inference_script.py::process_video`
+ * (/root/reference/inference_script.py:394-503) drives a diffusers `CogVideoXPipeline`, and every FLOP is a
+ * torch operator invoked inside diffusers modules.  The entry points below are what those modules would bind
+ * instead of the torch operators -- each one cites the reference call site whose arithmetic it carries
+ * (the module names are diffusers'; SURVEY.md App. A restates them).  INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *  - plain C: raw device pointers, sizes, a `hipStream_t` passed as `void*`; no torch / C++ types.
+ *  - every function returns 0 on success, a negative DOVE_E* code otherwise; `dove_last_error()` holds the message
+ *    (thread-local).  No exceptions cross the ABI.
+ *  - all tensor memory is owned by the caller; launches are asynchronous on the given stream.
+ *  - activations: channels-last bf16 ([T,H,W,C] for the VAE, [N,C] token-major for the DiT); statistics,
+ *    biases, norm affine parameters and modulation vectors are fp32.
+ */
+#ifndef DOVE_HIP_H
+#define DOVE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOVE_ABI_VERSION 1
+
+/* dtype codes for boundary tensors */
+#define DOVE_F32 0
+#define DOVE_BF16 1
+
+const char* dove_last_error(void);
+int dove_abi_version(void);
+/* name / CU count / total memory of HIP device `dev`; name_len bytes available in `name` */
+int dove_device_info(int dev, char* name, int name_len, int* cu_count, long long* total_mem);
+
+/* Implicit-GEMM convolution / linear layer (bf16 in, fp32 accumulate on MFMA, bf16 out).
+ * Carries: CogVideoXCausalConv3d, Downsample3D / Upsample3D convs, resnet 1x1x1 shortcut, SpatialNorm conv_y/conv_b
+ * (vae.encode / decode_latents, /root/reference/inference_script.py:408,500) and every nn.Linear of
+ * CogVideoXTransformer3DModel (/root/reference/inference_script.py:483-489).
+ *   x      [t_in, h_in, w_in, cin]      cin multiple of 32 (zero-padded channels)
+ *   cache  [kt-1, h_in, w_in, cin] or NULL: temporal front halo = last frames of the previous frame-batch's
+ *          input (diffusers `conv_cache`); NULL replicates frame 0.
+ *   w      [kt*kh*kw][cout_pad][cin]    packed, cout_pad multiple of 32, padding rows zero
+ *   out    [t_out, h_out, w_out, ldo]   channels [0, cout_store) written (cout_store multiple of 4)
+ *   input row for output row oh and tap dh: (oh*stride + dh - pad_h) >> up   (`up`=1 folds a nearest x2 upsample)
+ *   tmode (kt==1 only): 0 t_in=t, 1 t_in=t>>1, 2 t_in = t==0 ? 0 : 1+((t-1)>>1)   (Upsample3D time doubling)
+ *   epilogue: v = acc + bias; act==1: gelu(tanh); resid: v = resid + (gate ? gate[class][c] * v : v), where
+ *   class = (flat output pixel index < gate_split) ? 0 : 1 and gate is [2][cout_pad] fp32 (AdaLN-Zero gates). */
+typedef struct dove_conv_desc {
+  const void* x;
+  const void* cache;
+  const void* w;
+  const float* bias;
+  const void* resid;
+  const float* gate;
+  void* out;
+  int t_in, h_in, w_in, cin;
+  int t_out, h_out, w_out, cout_pad, cout_store;
+  int kt, kh, kw, stride, pad_h, pad_w, up, tmode, act;
+  long long ldo, ldr, gate_split;
+} dove_conv_desc;
+int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
+
+/* nn.GroupNorm(32, C, eps) statistics over one frame-batch [npix, C] (diffusers CogVideoXResnetBlock3D norm1/norm2,
+ * encoder.norm_out, and the norm_layer inside CogVideoXSpatialNorm3D).  stats = [32][2] (mean, rstd) fp32.
+ * partial_ws: >= ws_blocks*64 floats of scratch. */
+int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws, int ws_blocks,
+                              float* stats, void* stream);
+/* y = silu?( GN(x) [ * yb[z][0:C] + yb[z][C:2C] ] ): GroupNorm apply, optional SpatialNorm3D conditioning from the
+ * [Tz,hz,wz,2C] table conv_y(zq)||conv_b(zq) on the latent grid (z = (tmap[t], h>>sshift, w>>sshift), i.e. the
+ * nearest-neighbour resize of zq), optional SiLU. */
+int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, int W, int C, const float* stats,
+                              const float* gamma, const float* beta, int silu, const void* yb, int hz, int wz,
+                              int sshift, const int* tmap, void* stream);
+
+/* CogVideoXLayerNormZero / norm_final / AdaLayerNorm: y = LN(x)*gamma+beta, then *(1+scale)+shift with
+ * mod = [2 row classes][shift|scale][D] fp32 (rows < split: class 0 = text); mod NULL -> plain LayerNorm. */
+int dove_layernorm_modulate_bf16(const void* x, void* y, long long rows, int D, float eps, const float* gamma,
+                                 const float* beta, const float* mod, long long split, void* stream);
+
+/* Attention pre-processing of the fused QKV projection [N, 3*heads*64]: per-head LayerNorm(64) on q,k
+ * (attn1.norm_q / norm_k), interleaved-pair RoPE on rows >= text_len (apply_rotary_emb), q *= qscale,
+ * head-major outputs Qh,Kh [heads][Npad][64] and Vt [heads][64][Npad] (pad must be pre-zeroed). */
+int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
+                       const float* gq, const float* bq, const float* gk, const float* bk, const float* cosT,
+                       const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, void* stream);
+
+/* F.scaled_dot_product_attention (no mask, non-causal) on the operands above; Qh carries scale*log2(e).
+ * O [N][ldo] token-major, head h at columns [64h, 64h+64). */
+int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
+                            int heads, int head_dim, long long ldo, void* stream);
+
+/* layout glue at the [B,C,T,H,W] boundary (B = 1) */
+int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, float scale, float shift, void* y,
+                       void* stream);
+int dove_ncthw_from_cl(const void* x, long long ld, int C, long long npix, float scale, float shift, float lo,
+                       float hi, void* y, int dtype, void* stream);
+/* CogVideoXDownsample3D temporal average pool (odd T keeps the first frame) */
+int dove_avgpool_time_bf16(const void* x, int T, long long frame_elems, void* y, void* stream);
+/* DiagonalGaussianDistribution.sample(): out[c] = mean + exp(0.5*clamp(logvar,-30,20)) * noise  (ref :409) */
+int dove_posterior_sample(const void* moments, long long ld, int latent_channels, long long npix, const void* noise,
+                          int noise_dtype, void* out, int out_dtype, void* stream);
+/* out = a*x + b*y : CogVideoXDPMScheduler.get_velocity / add_noise (ref :457,491-493) */
+int dove_axpby(const void* x, const void* y, void* out, int dtype, long long n, float a, float b, void* stream);
+/* CogVideoXPatchEmbed gather / transformer un-patchify between [T,C,h,w] and tokens [Nv][C*pt*p*p] */
+int dove_patchify(const void* x, int dtype, int T, int C, int H, int W, int pt, int p, void* tokens, long long ld,
+                  void* stream);
+int dove_unpatchify(const void* tokens, long long ld, int T, int C, int H, int W, int pt, int p, void* y, int dtype,
+                    void* stream);
+/* M = 1 linear with optional SiLU on the input (time_embedding MLP, norm*.linear modulation vectors) */
+int dove_gemv_bf16(const void* W, const float* bias, const float* x, int in_features, int out_features, int act_in,
+                   float* y, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOVE_HIP_H */

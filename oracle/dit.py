@@ -1,0 +1,193 @@
+"""Oracle: CogVideoX1.5 DiT forward, RoPE tables, DPM scheduler constants.  TEST INFRASTRUCTURE ONLY.
+
+Restates what ``pipe.transformer(...)`` (/root/reference/inference_script.py:483-489),
+``prepare_rotary_positional_embeddings`` -> diffusers ``get_3d_rotary_pos_embed``
+(/root/reference/inference_script.py:364-392) and ``pipe.scheduler.get_velocity``
+(/root/reference/inference_script.py:491-493) compute (parity unpinned,
+see oracle/__init__.py).  Weights: flat dict keyed by diffusers state-dict names (App. E).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---- RoPE ------------------------------------------------------------------------------------
+def rope_1d(dim: int, n: int, theta: float = 10000.0):
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float32)[: dim // 2] / dim))
+    ang = torch.outer(torch.arange(n, dtype=torch.float32), freqs)
+    return ang.cos().repeat_interleave(2, dim=1).float(), ang.sin().repeat_interleave(2, dim=1).float()
+
+
+def rope_3d(head_dim: int, grid_t: int, grid_h: int, grid_w: int, theta: float = 10000.0):
+    """get_3d_rotary_pos_embed(grid_type="slice") -> (cos, sin), each [grid_t*grid_h*grid_w, head_dim]."""
+    dt, dh = head_dim // 4, head_dim // 8 * 3
+    dw = dh
+    ct, st = rope_1d(dt, grid_t, theta)
+    ch, sh = rope_1d(dh, grid_h, theta)
+    cw, sw = rope_1d(dw, grid_w, theta)
+
+    def comb(a, b, c):
+        a = a[:, None, None, :].expand(-1, grid_h, grid_w, -1)
+        b = b[None, :, None, :].expand(grid_t, -1, grid_w, -1)
+        c = c[None, None, :, :].expand(grid_t, grid_h, -1, -1)
+        return torch.cat([a, b, c], dim=-1).reshape(grid_t * grid_h * grid_w, -1)
+
+    return comb(ct, ch, cw), comb(st, sh, sw)
+
+
+def apply_rope(x, cos, sin):
+    """x [B,H,S,D]; interleaved pairs (use_real_unbind_dim=-1); fp32 math then cast back."""
+    xr, xi = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    rot = torch.stack([-xi, xr], dim=-1).flatten(3)
+    return (x.float() * cos + rot.float() * sin).to(x.dtype)
+
+
+# ---- scheduler -------------------------------------------------------------------------------
+def alphas_cumprod(cfg: dict) -> torch.Tensor:
+    """CogVideoXDPMScheduler.__init__: scaled-linear betas (float64), SNR shift,
+    zero-terminal-SNR rescale."""
+    n = cfg.get("num_train_timesteps", 1000)
+    b0, b1 = cfg.get("beta_start", 0.00085), cfg.get("beta_end", 0.012)
+    sched = cfg.get("beta_schedule", "scaled_linear")
+    if sched == "scaled_linear":
+        betas = torch.linspace(b0 ** 0.5, b1 ** 0.5, n, dtype=torch.float64) ** 2
+    elif sched == "linear":
+        betas = torch.linspace(b0, b1, n, dtype=torch.float64)
+    else:
+        raise NotImplementedError(sched)
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    s = cfg.get("snr_shift_scale", 1.0)
+    ac = ac / (s + (1 - s) * ac)
+    if cfg.get("rescale_betas_zero_snr", True):
+        r = ac.sqrt()
+        r0, rT = r[0].clone(), r[-1].clone()
+        r = (r - rT) * r0 / (r0 - rT)
+        ac = r ** 2
+    return ac.to(torch.float32)
+
+
+def get_velocity(ac, sample, noise, t: int):
+    """velocity = sqrt(a)*noise - sqrt(1-a)*sample, with alpha cast to sample.dtype BEFORE the sqrt."""
+    a = ac.to(sample.dtype)[t]
+    return (a ** 0.5) * noise - ((1 - a) ** 0.5) * sample
+
+
+# ---- DiT -------------------------------------------------------------------------------------
+def timestep_sinusoid(t: torch.Tensor, dim: int, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class OracleDiT:
+    def __init__(self, cfg: dict, weights: dict, dtype=torch.float32):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.w = {k: v.to(dtype) for k, v in weights.items()}
+        self.heads = cfg["num_attention_heads"]
+        self.hd = cfg["attention_head_dim"]
+        self.D = self.heads * self.hd
+        self.L = cfg["num_layers"]
+        self.p = cfg["patch_size"]
+        self.pt = cfg["patch_size_t"]
+        self.eps = cfg.get("norm_eps", 1e-5)
+
+    def lin(self, x, name):
+        return F.linear(x, self.w[name + ".weight"], self.w.get(name + ".bias"))
+
+    def ln(self, x, name, eps):
+        return F.layer_norm(x, (x.shape[-1],), self.w[name + ".weight"], self.w[name + ".bias"], eps)
+
+    @torch.no_grad()
+    def forward(self, hidden, text, timestep, rope, trace: dict | None = None):
+        """hidden [B,T,C,h,w]; text [B,L,4096]; timestep [B] long; rope (cos,sin) [Nv,hd] -> [B,T,C,h,w]."""
+        dt = self.dtype
+        B, T, C, H, W = hidden.shape
+        p, pt, D = self.p, self.pt, self.D
+        hidden, text = hidden.to(dt), text.to(dt)
+        temb = timestep_sinusoid(timestep, D, self.cfg.get("flip_sin_to_cos", True),
+                                 self.cfg.get("freq_shift", 0)).to(dt)
+        emb = self.lin(F.silu(self.lin(temb, "time_embedding.linear_1")), "time_embedding.linear_2")
+        semb = F.silu(emb)
+        # patch embed
+        x = hidden.permute(0, 1, 3, 4, 2).reshape(B, T // pt, pt, H // p, p, W // p, p, C)
+        x = x.permute(0, 1, 3, 5, 7, 2, 4, 6).flatten(4, 7).flatten(1, 3)
+        x = self.lin(x, "patch_embed.proj")
+        e = self.lin(text, "patch_embed.text_proj")
+        Lt = e.shape[1]
+        cos, sin = rope
+        if trace is not None:
+            trace["embed"] = torch.cat([e, x], 1).clone()
+        for i in range(self.L):
+            pre = f"transformer_blocks.{i}."
+            sh, sc, g, esh, esc, eg = self.lin(semb, pre + "norm1.linear").chunk(6, dim=1)
+            nx = self.ln(x, pre + "norm1.norm", self.eps) * (1 + sc)[:, None] + sh[:, None]
+            ne = self.ln(e, pre + "norm1.norm", self.eps) * (1 + esc)[:, None] + esh[:, None]
+            h = torch.cat([ne, nx], dim=1)
+            N = h.shape[1]
+            q = self.lin(h, pre + "attn1.to_q").view(B, N, self.heads, self.hd).transpose(1, 2)
+            k = self.lin(h, pre + "attn1.to_k").view(B, N, self.heads, self.hd).transpose(1, 2)
+            v = self.lin(h, pre + "attn1.to_v").view(B, N, self.heads, self.hd).transpose(1, 2)
+            q = self.ln(q, pre + "attn1.norm_q", 1e-6)
+            k = self.ln(k, pre + "attn1.norm_k", 1e-6)
+            q = torch.cat([q[:, :, :Lt], apply_rope(q[:, :, Lt:], cos, sin)], dim=2)
+            k = torch.cat([k[:, :, :Lt], apply_rope(k[:, :, Lt:], cos, sin)], dim=2)
+            o = F.scaled_dot_product_attention(q, k, v)
+            o = o.transpose(1, 2).reshape(B, N, D)
+            o = self.lin(o, pre + "attn1.to_out.0")
+            x = x + g[:, None] * o[:, Lt:]
+            e = e + eg[:, None] * o[:, :Lt]
+            sh, sc, g, esh, esc, eg = self.lin(semb, pre + "norm2.linear").chunk(6, dim=1)
+            nx = self.ln(x, pre + "norm2.norm", self.eps) * (1 + sc)[:, None] + sh[:, None]
+            ne = self.ln(e, pre + "norm2.norm", self.eps) * (1 + esc)[:, None] + esh[:, None]
+            h = torch.cat([ne, nx], dim=1)
+            f = self.lin(F.gelu(self.lin(h, pre + "ff.net.0.proj"), approximate="tanh"), pre + "ff.net.2")
+            x = x + g[:, None] * f[:, Lt:]
+            e = e + eg[:, None] * f[:, :Lt]
+            if trace is not None:
+                trace[f"block{i}"] = torch.cat([e, x], 1).clone()
+        x = self.ln(x, "norm_final", self.eps)
+        shift, scale = self.lin(semb, "norm_out.linear").chunk(2, dim=1)
+        x = self.ln(x, "norm_out.norm", self.eps) * (1 + scale)[:, None] + shift[:, None]
+        x = self.lin(x, "proj_out")
+        x = x.reshape(B, (T + pt - 1) // pt, H // p, W // p, -1, pt, p, p)
+        x = x.permute(0, 1, 5, 4, 2, 6, 3, 7).flatten(6, 7).flatten(4, 5).flatten(1, 2)
+        return x
+
+
+# ---- the whole op ------------------------------------------------------------------------------
+@torch.no_grad()
+def process_video(vae, dit, sched_cfg, video, text, noise, sr_noise_step=399, scaling_factor=0.7,
+                  trace: dict | None = None):
+    """Restatement of /root/reference/inference_script.py:394-503 on oracle modules, with the VAE
+    posterior noise injected (the reference draws it from the global RNG).  video [B,3,F,H,W] in
+    [-1,1] -> [B,3,F,H,W] in [0,1]."""
+    dt = vae.dtype
+    params = vae.encode(video)
+    latent = vae.sample(params, noise) * scaling_factor
+    pt = dit.pt
+    ncopy = latent.shape[2] % pt
+    latent = torch.cat([latent[:, :, :1].repeat(1, 1, ncopy, 1, 1), latent], dim=2)
+    assert latent.shape[2] % pt == 0
+    B, C, T, h, w = latent.shape
+    latent = latent.permute(0, 2, 1, 3, 4)
+    rope = rope_3d(dit.hd, (T + pt - 1) // pt, h // dit.p, w // dit.p)
+    ts = torch.full((B,), sr_noise_step, dtype=torch.long)
+    v = dit.forward(latent, text.to(dt).expand(B, -1, -1), ts, rope, trace)
+    x0 = get_velocity(alphas_cumprod(sched_cfg), v, latent, sr_noise_step)
+    if ncopy > 0:
+        x0 = x0[:, ncopy:]
+    if trace is not None:
+        trace["latent"] = latent.clone()
+        trace["v"] = v.clone()
+        trace["x0"] = x0.clone()
+    z = x0.permute(0, 2, 1, 3, 4) * (1.0 / scaling_factor)
+    out = vae.decode(z)
+    return (out * 0.5 + 0.5).clamp(0.0, 1.0)

@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE: torch restatement of every operator in include/dove_hip.h, with the same Python
+signatures as dove_amd.ops.  Two uses:
+  * `-m "not gpu"`: monkeypatched over dove_amd.ops so the host graphs (VAE frame-batching + conv caches,
+    SpatialNorm frame maps, DiT row classes, modulation regrouping, layouts) can be checked against the oracle
+    on CPU -- the HIP library is never involved there and no product code imports this file;
+  * `-m gpu`: the per-operator expected value for the HIP kernels on identical inputs.
+Semantics follow the kernels: fp32 arithmetic, bf16 rounding at operator outputs."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from dove_amd.ops import PackedConv, pack_conv  # noqa: F401  (pure torch packing, shared)
+
+BF = torch.bfloat16
+
+
+def _frame_index(t, tmode):
+    return t if tmode == 0 else (t >> 1 if tmode == 1 else (0 if t == 0 else 1 + ((t - 1) >> 1)))
+
+
+def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, resid=None,
+         gate=None, gate_split=0, act=0, ldo=None, out=None):
+    T, H, W, Cx = x.shape
+    assert Cx == pc.cin_pad
+    ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
+    pw = (pc.kw - 1) // 2 if pad[1] is None else pad[1]
+    t_out = T if t_out is None else t_out
+    if hw_out is None:
+        hw_out = (H << up, W << up) if stride == 1 else ((H + 1 - pc.kh) // stride + 1, (W + 1 - pc.kw) // stride + 1)
+    ldo = pc.cout_store if ldo is None else ldo
+    xf = x.float()
+    if pc.kt > 1:
+        k = pc.kt - 1
+        front = cache.float() if cache is not None else xf[:1].expand(k, -1, -1, -1)
+        xf = torch.cat([front, xf], dim=0)
+    else:
+        xf = xf[[_frame_index(t, tmode) for t in range(t_out)]]
+    if up:
+        xf = xf.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    He, We = xf.shape[1], xf.shape[2]
+    # explicit zero padding so that output (oh, ow) reads input oh*stride + dh - pad
+    need_h = (hw_out[0] - 1) * stride + pc.kh - ph
+    need_w = (hw_out[1] - 1) * stride + pc.kw - pw
+    xp = F.pad(xf.permute(3, 0, 1, 2)[None], (pw, max(need_w - We, 0), ph, max(need_h - He, 0)))
+    w = pc.w.float().view(pc.kt, pc.kh, pc.kw, pc.cout_pad, pc.cin_pad).permute(3, 4, 0, 1, 2)
+    y = F.conv3d(xp, w, None, stride=(1, stride, stride))[0]            # [cout_pad, T, H, W]
+    y = y[:, :t_out, : hw_out[0], : hw_out[1]].permute(1, 2, 3, 0)
+    if pc.bias is not None:
+        y = y + pc.bias.float()
+    if act == 1:
+        y = F.gelu(y, approximate="tanh")
+    y = y[..., : pc.cout_store]
+    if resid is not None:
+        r = resid.float().reshape(t_out, hw_out[0], hw_out[1], -1)[..., : pc.cout_store]
+        if gate is not None:
+            npx = t_out * hw_out[0] * hw_out[1]
+            cls = (torch.arange(npx) >= gate_split).long().view(t_out, hw_out[0], hw_out[1])
+            g = gate.float()[:, : pc.cout_store][cls]
+            y = r + g * y
+        else:
+            y = r + y
+    if out is None:
+        out = torch.zeros(t_out, hw_out[0], hw_out[1], ldo, dtype=BF)
+    out[..., : pc.cout_store] = y.to(BF)
+    return out
+
+
+def linear(x, pc, **kw):
+    N = x.shape[0]
+    out = kw.pop("out", None)
+    resid = kw.pop("resid", None)
+    y = conv(x.view(1, 1, N, x.shape[1]), pc, resid=None if resid is None else resid.view(1, 1, N, resid.shape[1]),
+             out=None if out is None else out.view(1, 1, N, out.shape[1]), **kw)
+    return y.view(N, y.shape[-1])
+
+
+def groupnorm_stats(x, eps):
+    Cc = x.shape[-1]
+    xf = x.double().reshape(-1, 32, Cc // 32)
+    mean = xf.mean(dim=(0, 2))
+    var = (xf * xf).mean(dim=(0, 2)) - mean * mean
+    return torch.stack([mean, 1.0 / torch.sqrt(var.clamp_min(0) + eps)], dim=1).float()
+
+
+def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
+    T, H, W, Cc = x.shape
+    cpg = Cc // 32
+    mean = stats[:, 0].repeat_interleave(cpg)
+    rstd = stats[:, 1].repeat_interleave(cpg)
+    sc = rstd * gamma.float()
+    sh = beta.float() - mean * sc
+    y = x.float() * sc + sh
+    if yb is not None:
+        ti = torch.tensor(tmap, dtype=torch.long)
+        hi = torch.arange(H) >> sshift
+        wi = torch.arange(W) >> sshift
+        g = yb.float()[ti][:, hi][:, :, wi]
+        y = y * g[..., :Cc] + g[..., Cc:]
+    if silu:
+        y = F.silu(y)
+    y = y.to(BF)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def layernorm_modulate(x, gamma, beta, eps, mod=None, split=0, out=None):
+    y = F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps)
+    if mod is not None:
+        cls = (torch.arange(x.shape[0]) >= split).long()
+        m = mod.float()[cls]          # [N, 2, D]
+        y = y * (1 + m[:, 1]) + m[:, 0]
+    y = y.to(BF)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt):
+    D = heads * 64
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64) for i in range(3))
+    q = F.layer_norm(q, (64,), gq.float(), bq.float(), eps)
+    k = F.layer_norm(k, (64,), gk.float(), bk.float(), eps)
+
+    def rope(t):
+        tv = t[text_len:]
+        xr, xi = tv.reshape(tv.shape[0], heads, 32, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], dim=-1).flatten(2)
+        return torch.cat([t[:text_len], tv * cos.float()[:, None] + rot * sin.float()[:, None]], dim=0)
+
+    if cos is not None:
+        q, k = rope(q), rope(k)
+    Qh[:, :N] = (q * qscale).permute(1, 0, 2).to(BF)
+    Kh[:, :N] = k.permute(1, 0, 2).to(BF)
+    Vt[:, :, :N] = v.permute(1, 2, 0).to(BF)
+
+
+def attention(Qh, Kh, Vt, N, Npad, heads, out):
+    q, k, v = Qh.float()[:, :N], Kh.float()[:, :N], Vt.float()[:, :, :N]
+    s = torch.einsum("hqd,hkd->hqk", q, k) * math.log(2.0)       # Qh carries scale*log2(e)
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("hqk,hdk->hqd", p, v)                        # [H, N, 64]
+    out[:N, : heads * 64] = o.permute(1, 0, 2).reshape(N, heads * 64).to(BF)
+    return out
+
+
+def cl_from_ncthw(x, cp, scale=1.0, shift=0.0):
+    Cc, T, H, W = x.shape
+    y = torch.zeros(T, H, W, cp, dtype=BF)
+    y[..., :Cc] = (x.float() * scale + shift).permute(1, 2, 3, 0).to(BF)
+    return y
+
+
+def ncthw_from_cl(x, Cc, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf):
+    return (x.float()[..., :Cc] * scale + shift).clamp(lo, hi).permute(3, 0, 1, 2).contiguous().to(dtype)
+
+
+def avgpool_time(x):
+    T = x.shape[0]
+    if T == 1:
+        return x
+    xf = x.float()
+    if T % 2:
+        return torch.cat([xf[:1], 0.5 * (xf[1::2] + xf[2::2])], dim=0).to(BF)
+    return (0.5 * (xf[0::2] + xf[1::2])).to(BF)
+
+
+def posterior_sample(moments_cl, latent_channels, noise, dtype):
+    L = latent_channels
+    m = moments_cl.float()
+    mean, lv = m[..., :L].permute(3, 0, 1, 2), m[..., L:2 * L].permute(3, 0, 1, 2).clamp(-30.0, 20.0)
+    return (mean + torch.exp(0.5 * lv) * noise.float()).to(dtype)
+
+
+def axpby(x, y, a, b):
+    return (a * x.float() + b * y.float()).to(x.dtype)
+
+
+def patchify(x, pt, p, ld):
+    T, Cc, H, W = x.shape
+    t = x.float().reshape(T // pt, pt, Cc, H // p, p, W // p, p).permute(0, 3, 5, 2, 1, 4, 6).reshape(-1, Cc * pt * p * p)
+    tok = torch.zeros(t.shape[0], ld, dtype=BF)
+    tok[:, : t.shape[1]] = t.to(BF)
+    return tok
+
+
+def unpatchify(tok, T, Cc, H, W, pt, p, dtype):
+    t = tok.float()[:, : Cc * pt * p * p].reshape(T // pt, H // p, W // p, Cc, pt, p, p)
+    return t.permute(0, 4, 3, 1, 5, 2, 6).reshape(T, Cc, H, W).to(dtype)
+
+
+def gemv(W, bias, x, act_in=0):
+    xv = F.silu(x.float()) if act_in == 1 else x.float()
+    y = W.float() @ xv
+    return y + bias.float() if bias is not None else y
+
+
+ALL = ["conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+       "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
+
+
+def install(monkeypatch):
+    """Route dove_amd.ops through this emulation (CPU tests of the host graph only)."""
+    import sys
+
+    import dove_amd.ops as real
+
+    me = sys.modules[__name__]
+    for n in ALL:
+        monkeypatch.setattr(real, n, getattr(me, n))

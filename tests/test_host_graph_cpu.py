@@ -1,0 +1,132 @@
+"""CPU check of the HOST graphs (no HIP involved): dove_amd's VAE / DiT / process_video orchestration with
+dove_amd.ops replaced by the torch emulation of the operators (tests/emu_ops.py) must reproduce the oracle.
+This pins frame-batching + conv caches, SpatialNorm frame maps, upsample/downsample geometry, weight packing,
+AdaLN chunk regrouping, row classes, patchify order and the scheduler before any GPU time is spent."""
+import os
+
+import pytest
+import torch
+
+import emu_ops
+from dove_amd import config, weights
+from dove_amd.inference import process_video, run_clip
+from dove_amd.pipeline import CogVideoXPipeline
+from oracle import dit as odit
+from oracle.vae import OracleVAE
+
+
+def psnr(a, b):
+    mse = ((a.float() - b.float()) ** 2).flatten(2).mean(dim=-1) if a.dim() > 2 else ((a.float() - b.float()) ** 2).mean()
+    return float((10 * torch.log10(1.0 / (mse + 1e-8))).mean())
+
+
+@pytest.fixture()
+def tiny(monkeypatch):
+    emu_ops.install(monkeypatch)
+    v, t, s = config.tiny_configs()
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=7, device="cpu")
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), 7)
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), 7)
+    return pipe, (v, t, s), wv, wt
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("F,H,W", [(9, 32, 48), (17, 32, 32), (1, 32, 32), (5, 48, 32)])
+def test_vae_encode_decode_vs_oracle(tiny, F, H, W):
+    pipe, (v, t, s), wv, wt = tiny
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, F, H, W).clamp(-1, 1)
+    ov = OracleVAE(v, wv)
+    p_ref = ov.encode(x)
+    p = pipe.vae.encode(x.to(torch.bfloat16)).latent_dist.parameters
+    assert p.shape == p_ref.shape
+    assert rel(p, p_ref) < 0.06
+    z = torch.randn(1, 16, p.shape[2], H // 8, W // 8)
+    d_ref = ov.decode(z)
+    d = pipe.vae.decode(z.to(torch.bfloat16)).sample
+    assert d.shape == d_ref.shape
+    if F % 8 == 1:
+        assert d.shape == (1, 3, F, H, W)
+    assert rel(d, d_ref) < 0.06
+
+
+def test_dit_vs_oracle(tiny):
+    pipe, (v, t, s), wv, wt = tiny
+    torch.manual_seed(1)
+    hidden = torch.randn(1, 4, 16, 8, 12)
+    text = torch.randn(1, 226, t["text_embed_dim"])
+    rope = odit.rope_3d(64, 2, 4, 6)
+    ts = torch.tensor([399])
+    ref = odit.OracleDiT(t, wt).forward(hidden, text, ts, rope)
+    got = pipe.transformer(hidden_states=hidden.to(torch.bfloat16), encoder_hidden_states=text.to(torch.bfloat16),
+                           timestep=ts, image_rotary_emb=rope, return_dict=False)[0]
+    assert got.shape == ref.shape
+    assert rel(got, ref) < 0.05
+
+
+def test_rope_tables_match_oracle():
+    from dove_amd.rope import get_3d_rotary_pos_embed
+    c, s = get_3d_rotary_pos_embed(64, None, (45, 80), 5, grid_type="slice", max_size=(45, 80))
+    rc, rs = odit.rope_3d(64, 5, 45, 80)
+    assert c.shape == (18000, 64) and torch.equal(c, rc) and torch.equal(s, rs)
+
+
+def test_scheduler_constants():
+    from dove_amd.scheduler import CogVideoXDPMScheduler
+    _, _, s = config.default_configs()
+    sch = CogVideoXDPMScheduler.from_config(s, timestep_spacing="trailing")
+    assert torch.allclose(sch.alphas_cumprod, odit.alphas_cumprod(s))
+    assert abs(float(sch.alphas_cumprod[399]) - 0.3935440575) < 1e-6
+    t = torch.tensor([399])
+    assert sch._coeffs(t, torch.bfloat16) == (0.625, 0.78125)                # bf16 cast before sqrt (8a row 9)
+    a, b = sch._coeffs(t, torch.float32)
+    assert abs(a - 0.6273309) < 1e-6 and abs(b - 0.7787528) < 1e-6
+    s3 = dict(s, snr_shift_scale=3.0)
+    assert abs(float(CogVideoXDPMScheduler(**s3).alphas_cumprod[399]) - 0.17861523) < 1e-6
+
+
+def test_process_video_vs_oracle(tiny, golden_dir):
+    pipe, (v, t, s), wv, wt = tiny
+    torch.manual_seed(2)
+    F, H, W = 9, 32, 48
+    video = torch.rand(1, 3, F, H, W) * 2 - 1
+    noise = torch.randn(1, 16, 3, H // 8, W // 8)
+    text = torch.randn(226, t["text_embed_dim"]).to(torch.bfloat16)
+    got = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
+    ref32 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise)
+    refbf = odit.process_video(OracleVAE(v, wv, torch.bfloat16), odit.OracleDiT(t, wt, torch.bfloat16), s, video,
+                               text[None], noise)
+    assert got.shape == ref32.shape == (1, 3, F, H, W)
+    assert float(got.min()) >= 0.0 and float(got.max()) <= 1.0
+    p_got, p_bf = psnr(got, ref32), psnr(refbf.float(), ref32)
+    # the fused-kernel rounding points must be at least as close to fp32 as the reference's bf16 path (minus 0.05 dB)
+    assert p_got >= p_bf - 0.05, (p_got, p_bf)
+    assert p_got > 30.0, p_got
+
+
+def test_run_clip_chunks_cover_and_match_single_calls(tiny):
+    pipe, (v, t, s), wv, wt = tiny
+    torch.manual_seed(3)
+    video = torch.rand(1, 3, 33, 16, 48) * 2 - 1
+    text = torch.randn(226, t["text_embed_dim"]).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    out, wc = run_clip(pipe, video, chunk_len=17, overlap_t=8, tile_size_hw=(16, 32), overlap_hw=(0, 16), empty_prompt_embedding=text, generator=g)
+    from dove_amd import tiling
+    tiling.check_coverage(wc)
+    assert out.shape == video.shape and float(out.min()) >= 0 and float(out.max()) <= 1
+
+
+def test_tokenizer_path_is_loud(tiny):
+    pipe = tiny[0]
+    with pytest.raises(NotImplementedError):
+        process_video(pipe, torch.zeros(1, 3, 1, 16, 16), prompt="a cat")
+
+
+def test_ops_fail_loudly_without_gpu():
+    """No CPU fallback in the product: real ops refuse host tensors."""
+    from dove_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.avgpool_time(torch.zeros(2, 4, 4, 32, dtype=torch.bfloat16))
