@@ -1,0 +1,247 @@
+"""-m gpu: every HIP operator, called through the C-ABI (dove_amd.ops -> ctypes -> libdove_hip.so), against
+the torch restatement of the same operator (tests/emu_ops.py) on identical seeded inputs.
+Tolerance (written here, floating point): both sides accumulate in fp32 from the same bf16 operands and round
+the result to bf16 once, so they may differ by accumulation order + 1 bf16 ulp:
+    |hip - ref| <= 1.6e-2*|ref| + 4e-3*max|ref|."""
+import math
+
+import pytest
+import torch
+
+import emu_ops as E
+from dove_amd import ops
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def close(name, got, ref, rtol=1.6e-2, afrac=4e-3):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs()
+    tol = rtol * ref.abs() + afrac * ref.abs().max() + 1e-6
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(f"{name}: {int(bad.sum())}/{bad.numel()} elements off; max err {float(err.max()):.4g} "
+                             f"(ref max {float(ref.abs().max()):.4g}); first bad idx {idx} got {float(got[tuple(idx)]):.5g} "
+                             f"ref {float(ref[tuple(idx)]):.5g}")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def pack(cout, cin, k, seed=1, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, cin, *k, generator=g) * (cin * math.prod(k)) ** -0.5
+    b = torch.randn(cout, generator=g) * 0.1 if bias else None
+    return E.pack_conv(w, b, "cpu"), ops.pack_conv(w, b, "cuda")
+
+
+CONV_CASES = [
+    # name, cin, cout, k, T, H, W, kwargs
+    ("c3d_128_128", 128, 128, (3, 3, 3), 3, 20, 24, {}),
+    ("c3d_128_128_cache", 128, 128, (3, 3, 3), 2, 9, 17, {"cache": True}),
+    ("c3d_3_128", 3, 128, (3, 3, 3), 2, 16, 16, {}),
+    ("c3d_128_256", 128, 256, (3, 3, 3), 2, 10, 12, {"cache": True}),
+    ("c3d_512_32", 512, 32, (3, 3, 3), 3, 6, 10, {}),
+    ("c3d_128_3", 128, 3, (3, 3, 3), 2, 16, 24, {"cache": True}),
+    ("c3d_16_512", 16, 512, (3, 3, 3), 3, 5, 7, {}),
+    ("c3d_64_64_T1", 64, 64, (3, 3, 3), 1, 8, 8, {}),
+    ("c3d_96_64", 96, 64, (3, 3, 3), 2, 8, 8, {}),
+    ("c111_128_256", 128, 256, (1, 1, 1), 3, 9, 11, {}),
+    ("c111_16_1024", 16, 1024, (1, 1, 1), 3, 4, 6, {}),
+    ("c2d_down_even", 128, 128, (3, 3), 3, 16, 20, {"stride": 2, "pad": (0, 0)}),
+    ("c2d_down_odd", 64, 64, (3, 3), 2, 15, 9, {"stride": 2, "pad": (0, 0)}),
+    ("c2d_up", 128, 128, (3, 3), 3, 6, 9, {"up": 1, "pad": (1, 1)}),
+    ("c2d_up_t1", 128, 128, (3, 3), 2, 6, 8, {"up": 1, "pad": (1, 1), "tmode": 1, "t_out": 4}),
+    ("c2d_up_t2", 256, 256, (3, 3), 3, 5, 8, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
+    ("c3d_resid", 128, 128, (3, 3, 3), 2, 12, 16, {"resid": True}),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case):
+    name, cin, cout, k, T, H, W, kw = case
+    pc_c, pc_g = pack(cout, cin, k)
+    x = torch.zeros(T, H, W, pc_c.cin_pad, dtype=BF)
+    x[..., :cin] = rnd(T, H, W, cin, seed=2)
+    kw = dict(kw)
+    use_cache, use_resid = kw.pop("cache", False), kw.pop("resid", False)
+    cache = resid = None
+    if use_cache:
+        cache = torch.zeros(k[0] - 1, H, W, pc_c.cin_pad, dtype=BF)
+        cache[..., :cin] = rnd(cache.shape[0], H, W, cin, seed=3)
+    if use_resid:
+        resid = rnd(*E.conv(x, pc_c, cache=cache, **kw).shape, seed=4)
+    ref = E.conv(x, pc_c, cache=cache, resid=resid, **kw)
+    got = ops.conv(x.cuda(), pc_g, cache=None if cache is None else cache.cuda(),
+                   resid=None if resid is None else resid.cuda(), **kw)
+    torch.cuda.synchronize()
+    close(name, got, ref)
+
+
+LIN_CASES = [
+    ("lin_3072_9216", 300, 3072, 9216, {}),
+    ("lin_128_3072", 260, 128, 3072, {}),
+    ("lin_4096_3072", 226, 4096, 3072, {}),
+    ("lin_gelu", 200, 256, 1024, {"act": 1}),
+    ("lin_3072_128", 333, 3072, 128, {}),
+    ("lin_gate", 300, 1024, 256, {"gate": True}),
+    ("lin_12288_3072_gate_inplace", 270, 12288, 3072, {"gate": True, "inplace": True}),
+    ("lin_M1", 1, 256, 256, {}),
+    ("lin_M129", 129, 256, 64, {}),
+]
+
+
+@pytest.mark.parametrize("case", LIN_CASES, ids=[c[0] for c in LIN_CASES])
+def test_linear(case):
+    name, N, cin, cout, kw = case
+    pc_c, pc_g = pack(cout, cin, ())
+    x = rnd(N, cin, seed=5)
+    kw = dict(kw)
+    gate = resid = None
+    inplace = kw.pop("inplace", False)
+    if kw.pop("gate", False):
+        g = torch.Generator().manual_seed(6)
+        gate = torch.randn(2, pc_c.cout_pad, generator=g)
+        resid = rnd(N, cout, seed=7)
+        kw.update(gate_split=N // 3)
+    ref = E.linear(x, pc_c, resid=resid, gate=gate, **kw)
+    rg = None if resid is None else resid.cuda()
+    got = ops.linear(x.cuda(), pc_g, resid=rg, gate=None if gate is None else gate.cuda(), out=rg if inplace else None, **kw)
+    torch.cuda.synchronize()
+    close(name, got, ref)
+
+
+@pytest.mark.parametrize("C,T,H,W", [(128, 3, 20, 24), (256, 2, 9, 13), (512, 3, 6, 5), (32, 2, 8, 8), (64, 1, 40, 40)])
+def test_groupnorm_stats_apply(C, T, H, W):
+    x = (rnd(T, H, W, C, seed=8).float() * 1.7 + 0.9).to(BF)
+    g = torch.Generator().manual_seed(9)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    st_ref = E.groupnorm_stats(x, 1e-6)
+    st = ops.groupnorm_stats(x.cuda(), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.allclose(st.cpu(), st_ref, rtol=2e-4, atol=2e-5), (st.cpu() - st_ref).abs().max()
+    ref = E.groupnorm_apply(x, st_ref, gamma, beta, silu=True)
+    got = ops.groupnorm_apply(x.cuda(), st, gamma.cuda(), beta.cuda(), silu=True)
+    torch.cuda.synchronize()
+    close(f"gn_apply_{C}", got, ref)
+
+
+@pytest.mark.parametrize("C,Tf,Tz,hz,wz,sshift", [(128, 5, 3, 4, 6, 2), (512, 3, 3, 5, 4, 0), (256, 4, 2, 3, 5, 1), (128, 9, 3, 2, 3, 3)])
+def test_spatial_norm_apply(C, Tf, Tz, hz, wz, sshift):
+    from dove_amd.vae import spatial_norm_tmap
+    H, W = hz << sshift, wz << sshift
+    x = rnd(Tf, H, W, C, seed=10)
+    yb = rnd(Tz, hz, wz, 2 * C, seed=11)
+    g = torch.Generator().manual_seed(12)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    st = E.groupnorm_stats(x, 1e-6)
+    tmap = spatial_norm_tmap(Tf, Tz)
+    ref = E.groupnorm_apply(x, st, gamma, beta, silu=True, yb=yb, sshift=sshift, tmap=tmap)
+    got = ops.groupnorm_apply(x.cuda(), st.cuda(), gamma.cuda(), beta.cuda(), silu=True, yb=yb.cuda(), sshift=sshift, tmap=tmap)
+    torch.cuda.synchronize()
+    close(f"sn_apply_{C}", got, ref)
+
+
+@pytest.mark.parametrize("N,D,mod", [(300, 3072, True), (129, 256, True), (77, 3072, False), (5, 4096, True), (64, 512, False)])
+def test_layernorm_modulate(N, D, mod):
+    x = (rnd(N, D, seed=13).float() * 2 + 0.3).to(BF)
+    g = torch.Generator().manual_seed(14)
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    m = 0.3 * torch.randn(2, 2, D, generator=g) if mod else None
+    ref = E.layernorm_modulate(x, gamma, beta, 1e-5, m, N // 4)
+    got = ops.layernorm_modulate(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5, None if m is None else m.cuda(), N // 4)
+    torch.cuda.synchronize()
+    close(f"ln_{N}_{D}", got, ref)
+
+
+@pytest.mark.parametrize("N,heads,text_len", [(738, 48, 226), (300, 4, 226), (130, 2, 0), (64, 1, 10), (1000, 3, 226)])
+def test_qkv_post_and_attention(N, heads, text_len):
+    D = heads * 64
+    npad = (N + 127) // 128 * 128
+    qkv = rnd(N, 3 * D, seed=15)
+    g = torch.Generator().manual_seed(16)
+    gq, bq, gk, bk = (1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g),
+                      1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g))
+    ang = torch.rand(N - text_len, 32, generator=g) * 6.28
+    cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
+    qscale = 0.125 * math.log2(math.e)
+    z = lambda *s: torch.zeros(*s, dtype=BF)   # noqa: E731
+    Qr, Kr, Vr = z(heads, npad, 64), z(heads, npad, 64), z(heads, 64, npad)
+    E.qkv_post(qkv, N, npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, 1e-6, Qr, Kr, Vr)
+    Qg, Kg, Vg = z(heads, npad, 64).cuda(), z(heads, npad, 64).cuda(), z(heads, 64, npad).cuda()
+    ops.qkv_post(qkv.cuda(), N, npad, heads, text_len, gq.cuda(), bq.cuda(), gk.cuda(), bk.cuda(), cos.cuda(), sin.cuda(),
+                 qscale, 1e-6, Qg, Kg, Vg)
+    torch.cuda.synchronize()
+    close("qkv_post.Q", Qg, Qr)
+    close("qkv_post.K", Kg, Kr)
+    close("qkv_post.Vt", Vg, Vr)
+    ref = E.attention(Qr, Kr, Vr, N, npad, heads, torch.zeros(N, D, dtype=BF))
+    got = ops.attention(Qr.cuda(), Kr.cuda(), Vr.cuda(), N, npad, heads, torch.zeros(N, D, dtype=BF, device="cuda"))
+    torch.cuda.synchronize()
+    # P is rounded to bf16 before PV in the kernel (flash attention): allow 2 ulp
+    close(f"attention_{N}_{heads}", got, ref, rtol=3e-2, afrac=8e-3)
+
+
+def test_attention_spiked_rows():
+    """online-softmax rescale path: one key dominates late in the sequence (guide rule 26)."""
+    N, heads = 520, 2
+    npad = 640
+    g = torch.Generator().manual_seed(17)
+    Q = torch.zeros(heads, npad, 64, dtype=BF)
+    K = torch.zeros(heads, npad, 64, dtype=BF)
+    V = torch.zeros(heads, 64, npad, dtype=BF)
+    Q[:, :N] = (torch.randn(heads, N, 64, generator=g) * 0.3).to(BF)
+    K[:, :N] = (torch.randn(heads, N, 64, generator=g) * 0.3).to(BF)
+    V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
+    K[:, 400] = (Q[:, 7].float() * 40).to(BF)      # huge score for query 7 at key 400 (7th KV tile)
+    K[:, 3] = (Q[:, 300].float() * 30).to(BF)      # and an early spike for query 300
+    ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
+    torch.cuda.synchronize()
+    close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
+
+
+def test_layout_and_glue():
+    x = torch.randn(3, 4, 10, 12, generator=torch.Generator().manual_seed(18))
+    for xx in (x, x.to(BF)):
+        close("cl_from_ncthw", ops.cl_from_ncthw(xx.cuda(), 32, 0.5, 0.25), E.cl_from_ncthw(xx, 32, 0.5, 0.25))
+    cl = rnd(4, 10, 12, 4, seed=19)
+    for dt in (torch.float32, BF):
+        close("ncthw_from_cl", ops.ncthw_from_cl(cl.cuda(), 3, dt, 0.5, 0.5, 0.0, 1.0), E.ncthw_from_cl(cl, 3, dt, 0.5, 0.5, 0.0, 1.0))
+    cl32 = rnd(3, 5, 6, 32, seed=20)
+    close("ncthw_from_cl32", ops.ncthw_from_cl(cl32.cuda(), 32, BF), E.ncthw_from_cl(cl32, 32, BF))
+    for T in (2, 5, 8, 9):
+        v = rnd(T, 6, 5, 64, seed=21)
+        close(f"avgpool_{T}", ops.avgpool_time(v.cuda()), E.avgpool_time(v))
+    mom = rnd(3, 5, 6, 32, seed=22)
+    noise = torch.randn(16, 3, 5, 6, generator=torch.Generator().manual_seed(23))
+    close("posterior", ops.posterior_sample(mom.cuda(), 16, noise.cuda(), BF), E.posterior_sample(mom, 16, noise, BF))
+    a, b = rnd(1000, seed=24), rnd(1000, seed=25)
+    close("axpby", ops.axpby(a.cuda(), b.cuda(), 0.625, -0.78125), E.axpby(a, b, 0.625, -0.78125))
+    h = rnd(4, 16, 6, 10, seed=26)
+    tok_ref = E.patchify(h, 2, 2, 128)
+    tok = ops.patchify(h.cuda(), 2, 2, 128)
+    close("patchify", tok, tok_ref)
+    close("unpatchify", ops.unpatchify(tok, 4, 16, 6, 10, 2, 2, BF), E.unpatchify(tok_ref, 4, 16, 6, 10, 2, 2, BF))
+    Wm = rnd(700, 512, seed=27, scale=0.05)
+    bias = torch.randn(700, generator=torch.Generator().manual_seed(28))
+    xv = torch.randn(512, generator=torch.Generator().manual_seed(29))
+    for act in (0, 1):
+        got = ops.gemv(Wm.cuda(), bias.cuda(), xv.cuda(), act)
+        ref = E.gemv(Wm, bias, xv, act)
+        assert torch.allclose(got.cpu(), ref, rtol=1e-4, atol=1e-4), (got.cpu() - ref).abs().max()
+    torch.cuda.synchronize()
+
+
+def test_invalid_arguments_raise():
+    pc_c, pc_g = pack(64, 64, (3, 3, 3))
+    with pytest.raises(RuntimeError, match="channels"):
+        ops.conv(torch.zeros(1, 4, 4, 32, dtype=BF, device="cuda"), pc_g)
+    with pytest.raises(RuntimeError, match="power of two"):
+        ops.groupnorm_stats(torch.zeros(1, 4, 4, 96, dtype=BF, device="cuda"), 1e-6)
