@@ -1,0 +1,204 @@
+"""bench.py -- SR frames/s of the one-step DOVE path on synthetic 33x720x1280 clips (BASELINE.json configs[1]).
+
+One "step" = one `process_video` call on one [1,3,33,720,1280] clip already resident in HBM: VAE encode ->
+posterior sample -> 42-layer DiT at t=399 -> get_velocity -> VAE decode -> [0,1] range map, all through the C-ABI
+HIP operators (full CogVideoX1.5-5B architecture, deterministic random-init weights, bf16 storage / fp32
+accumulate).  N GPUs = N independent clips (the reference's chunk farm: no data-path collective; weak scaling).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = implicit-GEMM conv/linear on MFMA, achieved from
+HIP events recorded around every launch inside the timed region) and `cpu_baseline` (the torch-CPU oracle timed
+on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dove_amd import config, flops, ops  # noqa: E402
+from dove_amd.inference import process_video  # noqa: E402
+from dove_amd.pipeline import CogVideoXPipeline  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak ~2.5 PF
+
+
+def synth_lr_clip(F=33, H=180, W=320, seed=42, device="cuda"):
+    """Synthetic LR clip (uint8-valued): moving low-frequency sinusoids + noise, image-like statistics."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    vid = torch.full((F, 3, H, W), 127.5)
+    for c in range(3):
+        for _ in range(8):
+            fx, fy, ph, amp = torch.rand(4, generator=g)
+            for f in range(F):
+                vid[f, c] += 40 * amp * torch.sin(6.2832 * (fx * 6 * (xx + f) / W + fy * 6 * yy / H + ph))
+    vid += 4 * torch.randn(F, 3, H, W, generator=g)
+    return vid.clamp(0, 255).round().to(device)
+
+
+def prepare_clip(lr, upscale=4):
+    """Script-level pre-processing (ref :672-679): bilinear xN, /255*2-1, [1,3,F,H,W].  Outside the timed region."""
+    F, C, H, W = lr.shape
+    up = torch.nn.functional.interpolate(lr, size=(H * upscale, W * upscale), mode="bilinear", align_corners=False)
+    return (up / 255.0 * 2.0 - 1.0).permute(1, 0, 2, 3)[None].contiguous()
+
+
+def cpu_baseline(text):
+    """Oracle (clean-room port of the reference's diffusers CPU path) on a bounded sample, all host cores, fp32."""
+    from dove_amd import weights
+    from oracle import dit as odit
+    from oracle.vae import OracleVAE
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    v, t, s = config.small_configs(num_layers=2)
+    F, H, W = 9, 96, 160
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), 5)
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), 5)
+    g = torch.Generator().manual_seed(0)
+    video = torch.rand(1, 3, F, H, W, generator=g) * 2 - 1
+    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=g)
+    vae, dit = OracleVAE(v, wv), odit.OracleDiT(t, wt)
+    t0 = time.time()
+    ref = odit.process_video(vae, dit, s, video, text.float()[None], noise)
+    dt = time.time() - t0
+    fl = flops.clip_macs(v, t, F, H, W)["flop"]
+    _, tfull, _ = config.default_configs()
+    per_frame = flops.clip_macs(v, tfull, 33, 720, 1280)["flop"] / 33
+    base = {"value": fl / dt / per_frame, "unit": "SR frames/s (headline-equivalent: sample TFLOP/s / 35.78 TFLOP per 720p frame)",
+            "cores": cores, "kind": "port", "seconds": dt, "tflops": fl / dt / 1e12,
+            "sample": f"oracle fp32 process_video on a {F}x{H}x{W} clip, CogVideoX1.5 VAE + 2 DiT layers, {fl/1e12:.2f} TFLOP"}
+    return base, (v, t, s, video, noise, ref)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=33)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT layers (result marked invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from safetensors.torch import load_file
+    text = load_file(os.path.join(ROOT, "tests", "golden", "empty_prompt_embedding.safetensors"))["prompt_embedding"]
+
+    v, t, s = config.default_configs()
+    if args.layers is not None:
+        t["num_layers"] = args.layers
+    t_build = time.time()
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=1234, device=dev, init_device=dev)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build
+
+    up = 4
+    video = prepare_clip(synth_lr_clip(args.frames, args.height // up, args.width // up, seed=42 + rank, device=dev), up)
+    T = 1 + (args.frames - 1) // 4
+    noise = torch.randn(1, 16, T, args.height // 8, args.width // 8, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+
+    def step():
+        return process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    records = []
+    ops.set_profiler(records)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_profiler(None)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    assert out.shape == (1, 3, args.frames, args.height, args.width) and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        macs = flops.clip_macs(v, t, args.frames, args.height, args.width)
+        ms_step = elapsed / args.steps * 1e3
+        value = world * args.steps * args.frames / elapsed
+        # dominant kernel: igemm conv/linear.  achieved = sum(algorithmic flops) / sum(launch durations) over the timed region
+        tot_fl = sum(r[1] for r in records)
+        tot_ms = sum(r[2].elapsed_time(r[3]) for r in records)
+        by = {}
+        for key, fl, e0, e1 in records:
+            k = f"cin{key[0]}_cout{key[1]}_taps{key[2]}"
+            a = by.setdefault(k, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1)
+            a[2] += 1
+        top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("igemm_hbm_bytes_per_launch")
+        res = {
+            "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.frames}x{args.height}x{args.width} HR clip (LR {args.height//up}x{args.width//up}, 4x), "
+                                   f"one-step t=399, CogVideoX1.5-5B VAE + {t['num_layers']}-layer DiT random-init, 1 clip per GPU (BASELINE configs[1])",
+                       "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15},
+            "frames_per_s_per_gpu": value / world,
+            "whole_path_tflops_per_gpu": macs["flop"] * args.steps / elapsed / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3d/conv2d/linear, bf16 MFMA 32x32x16)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": traffic, "launches": len(records), "avg_launch_ms": tot_ms / max(len(records), 1),
+                         "avg_launch_gflop": tot_fl / max(len(records), 1) / 1e9,
+                         "share_of_step_time": tot_ms / (elapsed * 1e3),
+                         "top_classes": {k: {"ms": a[1] / args.steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // args.steps}
+                                         for k, a in top}},
+            "model_build_s": t_build,
+        }
+        if args.layers is not None:
+            res["invalid"] = "debug run with a truncated DiT"
+        if world == 1 and not args.no_cpu_baseline:
+            base, (sv, st, ss, svid, snoise, sref) = cpu_baseline(text)
+            res["cpu_baseline"] = base
+            # PSNR of the HIP path vs the fp32 oracle on the same bounded sample (same weights / noise / text)
+            del pipe
+            torch.cuda.empty_cache()
+            small = CogVideoXPipeline.from_config(sv, st, ss, seed=5, device=dev)
+            got = process_video(small, svid.to(dev), empty_prompt_embedding=text, posterior_noise=snoise.to(dev)).float().cpu()
+            mse = ((got - sref) ** 2).flatten(3).mean(-1)
+            res["psnr_vs_oracle_db"] = float((10 * torch.log10(1.0 / (mse + 1e-8))).mean())
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,16 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
     return PackedConv(wp.contiguous(), bp, kt, kh, kw, cin, cin_pad, cout, cout_pad)
 
 
+_profiler = None
+
+
+def set_profiler(records: list | None):
+    """bench.py hook: when a list is installed, every igemm launch appends (key, algorithmic_flops, ev_start, ev_end)
+    with HIP events recorded on the launch stream."""
+    global _profiler
+    _profiler = records
+
+
 def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
@@ -94,7 +104,14 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
     if gate is not None:
         assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
+    if _profiler is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.load().dove_conv_igemm_bf16(C.byref(d), L.stream_ptr()), "dove_conv_igemm_bf16")
+    if _profiler is not None:
+        e1.record()
+        flops = 2.0 * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
+        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1))
     return out
 
 
