@@ -18,6 +18,10 @@
 // double-buffered with one barrier per K-step.  MFMA operands are swapped (A = weights, B = pixels) so
 // each lane ends up with 4 consecutive output channels of one pixel -> 8-byte epilogue stores.
 // Epilogue: +bias, GELU(tanh), residual add, row-class-dependent gate (AdaLN-Zero), bf16 store.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/dove_hip.h"
 
@@ -37,6 +41,7 @@ struct IgemmArgs {
   long long ldo, ldr;
   long long gate_split;
   int tw_log2, tiles_w, tiles_h, tiles_n;
+  int debug;  // timing ablations only (DOVE_IGEMM_ABLATE): 1 skip A loads, 2 skip B loads, 4 skip MFMA
 };
 
 template <int BN, int BK>
@@ -215,6 +220,473 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (up == 0: every conv except the upsample-fused one, and every linear).
+// Same tiling / swizzle / MFMA order as igemm_kernel, but the staging is rebuilt around
+// `buffer_load_dwordx4 ... lds` through wave-uniform buffer descriptors (PMC on v1: 9.8 VALU + 7.6 SALU
+// instructions per MFMA, all of it 64-bit im2col address math):
+//   * per-thread row byte offsets inside a frame and a 9-bit tap-validity mask are computed ONCE;
+//   * per K-step a load costs v_and/v_cmp/v_add/v_cndmask: invalid (padding / tail) lanes get an
+//     out-of-range offset and the descriptor's bounds check returns zeros -- no zero page, no branches;
+//   * tap / channel-chunk / frame advance is scalar state (SGPR adds), the K offset rides in soffset;
+//   * ds_read addresses are per-lane constants + compile-time (buffer, operand) immediates (loop unrolled x2).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int BN, int BK>
+struct FastCfg {
+  static constexpr int BM = 128;
+  static constexpr int CPR = BK / 8;
+  static constexpr int CPR_LOG = (BK == 64) ? 3 : 2;
+  static constexpr int RPG = 256 / CPR;
+  static constexpr int NA = BM / RPG;
+  static constexpr int B_SLOTS = BN * CPR;
+  static constexpr int NB = (B_SLOTS + 255) / 256;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  static constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN;
+  static constexpr int PT = (BM / WM) / 32, CT = (BN / WN) / 32;
+  static constexpr int KK = BK / 16;
+};
+
+template <int BN, int BK>
+__global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
+  using Cf = FastCfg<BN, BK>;
+  constexpr int NA = Cf::NA, NB = Cf::NB, PT = Cf::PT, CT = Cf::CT, KK = Cf::KK, STAGE = Cf::STAGE, A_BYTES = Cf::A_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const int wm = wave / Cf::WN, wn = wave % Cf::WN;
+
+  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
+  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
+  const int thi = rest % a.tiles_h;
+  const int t = rest / a.tiles_h;
+  const int n0 = tn * BN;
+  const int TWm = (1 << a.tw_log2) - 1;
+  const int oh0 = thi * (128 >> a.tw_log2), ow0 = twi << a.tw_log2;
+
+  // ---- one-time per-thread staging geometry ----
+  const int cs = tid & (Cf::CPR - 1);
+  const int rsub = tid >> Cf::CPR_LOG;
+  const int c = (BK == 64) ? (cs ^ ((rsub >> 1) & 7)) : (cs ^ ((rsub >> 2) & 3));
+  int rowoff[NA];
+  unsigned mask[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int m = j * Cf::RPG + rsub;
+    const int oh = oh0 + (m >> a.tw_log2), ow = ow0 + (m & TWm);
+    const bool mv = (oh < a.H_out) && (ow < a.W_out);
+    const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
+    rowoff[j] = ((ih0 * a.W_in + iw0) * a.Cin + c * 8) * 2;
+    unsigned mk = 0;
+    for (int dh = 0; dh < a.kh; ++dh)
+      for (int dw = 0; dw < a.kw; ++dw) {
+        const bool ok = mv && ((unsigned)(ih0 + dh) < (unsigned)a.H_in) && ((unsigned)(iw0 + dw) < (unsigned)a.W_in);
+        mk |= (ok ? 1u : 0u) << (dh * a.kw + dw);
+      }
+    mask[j] = mk;
+  }
+  int boff_g[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) boff_g[j] = ((j * Cf::RPG + rsub) * a.Cin + c * 8) * 2;
+
+  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
+  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
+  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);     // bytes of this block's weight rows per tap
+  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;            // elements between taps
+  const int kc_per_tap = a.Cin / BK;
+  const int nk = a.kt * a.kh * a.kw * kc_per_tap;
+
+  // ---- scalar K-walk state (the NEXT K-step to stage); everything below lives in SGPRs ----
+  auto frame_ptr = [&](int dt) -> const bf16_t* {
+    if (a.kt > 1) {
+      const int fv = t + dt - (a.kt - 1);
+      if (fv >= 0) return a.x + fv * frame_elems;
+      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
+      return a.x;
+    }
+    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
+    return a.x + tin * frame_elems;
+  };
+  int s_kc = 0, s_dw = 0, s_dh = 0, s_dt = 0;
+  const bf16_t* s_fp = frame_ptr(0);
+  const bf16_t* s_wp = a.w + (long long)n0 * a.Cin;
+  int s_tapdelta = 0;
+  unsigned s_tapbit = 1u;
+
+  auto stage = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+    const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)s_fp, (short)0, (int)frame_bytes, 0x00020000);
+    const auto srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)s_wp, (short)0, (int)wtap_bytes, 0x00020000);
+    const int soff = s_kc * (BK * 2);
+    if (!(a.debug & 1)) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned voff = (mask[j] & s_tapbit) ? (unsigned)(rowoff[j] + s_tapdelta) : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + BUF * STAGE + (j * 256 + wave * 64) * 16), 16, voff, soff, 0, 0);
+    }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (j * 256 + wave * 64 < Cf::B_SLOTS && !(a.debug & 2))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (lds_ptr_t)(smem + BUF * STAGE + A_BYTES + (j * 256 + wave * 64) * 16), 16,
+                                                 (unsigned)boff_g[j], soff, 0, 0);
+    }
+    // advance to the next K-step (tap / frame changes are rare: every Cin/BK steps)
+    if (++s_kc == kc_per_tap) {
+      s_kc = 0;
+      s_wp += wtap_stride;
+      if (++s_dw == a.kw) {
+        s_dw = 0;
+        if (++s_dh == a.kh) {
+          s_dh = 0;
+          ++s_dt;
+          if (s_dt < a.kt) s_fp = frame_ptr(s_dt);
+        }
+      }
+      s_tapdelta = ((s_dh * a.W_in + s_dw) * a.Cin) * 2;
+      s_tapbit = 1u << (s_dh * a.kw + s_dw);
+    }
+  };
+
+  // ---- per-lane LDS fragment offsets (constant over the K loop) ----
+  const int hi = lane >> 5, l31 = lane & 31;
+  int aoff[PT][KK], boff[CT][KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int chunk = kk * 2 + hi;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const int row = wm * (Cf::BM / Cf::WM) + p * 32 + l31;
+      const int sc = (BK == 64) ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+      aoff[p][kk] = row * (BK * 2) + sc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      const int row = wn * (BN / Cf::WN) + i * 32 + l31;
+      const int sc = (BK == 64) ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+      boff[i][kk] = row * (BK * 2) + sc * 16;
+    }
+  }
+
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+
+  auto compute = [&](auto bufc) {
+    constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      bf16x8 xf[PT], wf[CT];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) xf[p] = *(const bf16x8*)(smem + BUF * STAGE + aoff[p][kk]);
+#pragma unroll
+      for (int i = 0; i < CT; ++i) wf[i] = *(const bf16x8*)(smem + BUF * STAGE + A_BYTES + boff[i][kk]);
+      if (a.debug & 4) {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) { asm volatile("" ::"v"(wf[i]), "v"(xf[p])); }
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
+    }
+  };
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  stage(B0{});
+  int it = 0;
+  for (; it + 2 <= nk; it += 2) {          // K-steps in pairs: LDS buffer index is a compile-time constant
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(B1{});
+    compute(B0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 2 < nk) stage(B0{});
+    compute(B1{});
+  }
+  if (nk & 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    compute(B0{});
+  }
+
+  // ---- epilogue (identical to igemm_kernel) ----
+#pragma unroll
+  for (int p = 0; p < PT; ++p) {
+    const int m = wm * (Cf::BM / Cf::WM) + p * 32 + l31;
+    const int oh = oh0 + (m >> a.tw_log2), ow = ow0 + (m & TWm);
+    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
+    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
+    const float* gate = a.gate ? (a.gate + (pix < a.gate_split ? 0 : a.Cout_pad)) : nullptr;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = n0 + wn * (BN / Cf::WN) + i * 32 + 8 * g + 4 * hi;
+        if (cb >= a.Cout_st) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][g * 4 + e];
+        if (a.bias) {
+          const f32x4 b = *(const f32x4*)(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+        }
+        if (a.resid) {
+          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
+          float r[4] = {__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u),
+                        __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
+          if (gate) {
+            const f32x4 gg = *(const f32x4*)(gate + cb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r[e] + gg[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          }
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(a.out + pix * a.ldo + cb) = o;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 (x kt) stride-1 convolution with an LDS HALO tile -- the kernel that carries the VAE resnets
+// (71 % of the clip's FLOPs).  Ablation of the fast path on MI355X: global->LDS staging + ds_reads alone
+// (no MFMA) already cost 76 % of the launch; the per-CU vector-memory path (~64 B/clk) is the limiter at
+// 64 FLOP per staged byte.  Here one workgroup owns 8 x 32 output pixels x 128 output channels and walks K as
+//   for dt (temporal tap) / for kc (32-channel chunk):   stage the (8+2) x (32+2) input halo ONCE
+//     for the 9 spatial taps:                              stage only the 128 x 32 weight tile
+// so the activations are fetched once per 9 taps (204 FLOP per staged byte, 3.2x better) and each wave's
+// 128 x 64 register tile needs 6 fragment reads per 8 MFMAs (was 8 per 8).
+// A fragments for tap (dh, dw) are the same halo rows shifted by dh*34 + dw: one tile row = 32 consecutive
+// halo rows, which keeps the XOR-swizzled ds_read_b128 conflict-free for ANY shift (16-lane groups always
+// see 16 distinct row indices mod 16).  Halo staging addresses are per-thread constants (image-border and
+// tail lanes use the descriptor's out-of-range -> 0 rule); the halo of the next (dt, kc) group trickles in
+// one 4 KB round per K-step behind the weight tiles.
+// ------------------------------------------------------------------------------------------------
+namespace halo {
+constexpr int TH = 8, TW = 32, HWID = TW + 2, HHGT = TH + 2, HPIX = HWID * HHGT;  // 340 halo pixels
+constexpr int BK = 32, ROWB = BK * 2;                                                 // 64-byte LDS rows
+constexpr int A_ROUNDS = (HPIX * 4 + 255) / 256;                                      // 6 rounds of 256 x 16 B
+constexpr int A_BYTES = A_ROUNDS * 256 * 16;                                          // 24576 (padded tail)
+constexpr int BN = 128, B_BYTES = BN * ROWB;                                          // 8192
+constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;                                  // 73728: 2 halo + 3 weight buffers
+}  // namespace halo
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a) {
+  using namespace halo;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const int wm = wave >> 1, wn = wave & 1;      // wave tile: tile rows [4wm, 4wm+4) x couts [64wn, 64wn+64)
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
+  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
+  const int thi = rest % a.tiles_h;
+  const int t = rest / a.tiles_h;
+  const int n0 = tn * BN;
+  const int oh0 = thi * TH, ow0 = twi * TW;
+
+  // ---- per-thread constant staging offsets ----
+  unsigned voffA[A_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < A_ROUNDS; ++r) {
+    const int s = r * 256 + tid;
+    const int px = s >> 2, cs = s & 3;
+    const int c = cs ^ ((px >> 2) & 3);
+    const int hh = px / HWID, hw = px - hh * HWID;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    const bool ok = (px < HPIX) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
+  }
+  unsigned voffB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = j * 64 + (tid >> 2);
+    const int c = (tid & 3) ^ ((row >> 2) & 3);
+    voffB[j] = (unsigned)((row * a.Cin + c * 8) * 2);
+  }
+  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
+  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
+  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
+  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
+  const int kcn = a.Cin / BK;
+  const int ngroups = a.kt * kcn;          // (dt, kc) groups, 9 spatial taps each
+  const int nk = ngroups * 9;
+
+  auto frame_ptr = [&](int dt) -> const bf16_t* {
+    if (a.kt > 1) {
+      const int fv = t + dt - (a.kt - 1);
+      if (fv >= 0) return a.x + fv * frame_elems;
+      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
+      return a.x;
+    }
+    return a.x + (long long)t * frame_elems;
+  };
+
+  // staging cursors (SGPR state)
+  int h_dt = 0, h_kc = 0;                  // group whose halo is being staged
+  auto stage_halo_round = [&](auto rc, int buf) {   // one 4 KB round of group (h_dt, h_kc) into A[buf]
+    constexpr int r = decltype(rc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
+                                             h_kc * ROWB, 0, 0);
+  };
+  int b_tap = 0, b_dt = 0, b_kc = 0;       // weight tile cursor: spatial tap, temporal tap, channel chunk
+  auto stage_b = [&](auto bc) {
+    constexpr int buf = decltype(bc)::value;
+    const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
+                                               voffB[j], b_kc * ROWB, 0, 0);
+    if (++b_tap == 9) {
+      b_tap = 0;
+      if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
+    }
+  };
+
+  // per-lane constant B fragment offsets (buffer 0); buffers 1, 2 are +B_BYTES immediates
+  int boff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wn * 64 + i * 32 + l31;
+      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
+    }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+
+  // ---- prologue: whole halo of group 0 + weights of step 0 ----
+  stage_halo_round(std::integral_constant<int, 0>{}, 0);
+  stage_halo_round(std::integral_constant<int, 1>{}, 0);
+  stage_halo_round(std::integral_constant<int, 2>{}, 0);
+  stage_halo_round(std::integral_constant<int, 3>{}, 0);
+  stage_halo_round(std::integral_constant<int, 4>{}, 0);
+  stage_halo_round(std::integral_constant<int, 5>{}, 0);
+  static_assert(A_ROUNDS == 6, "prologue is written for 6 halo rounds");
+  if (++h_kc == kcn) { h_kc = 0; ++h_dt; }   // cursor -> group 1
+  stage_b(std::integral_constant<int, 0>{});
+
+  const int R0 = 4 * wm * HWID + l31;      // halo row of (tile row 4wm, column l31) before the tap shift
+  const int hi4 = hi << 2;
+
+  auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int dh = tap / 3, dw = tap % 3;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // stage the next step's weight tile (3-deep ring indexed by tap % 3) and one round of the next halo
+    if (tap < 8 || more_groups) stage_b(std::integral_constant<int, (tap + 1) % 3>{});
+    if constexpr (tap < A_ROUNDS) {
+      if (more_groups) stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1);
+    }
+    int aaddr[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int R = R0g + (p + dh) * HWID + dw;
+      aaddr[p] = (R << 6) + (((R ^ hi4) & 0xC) << 2);       // R*64 + ((hi ^ (R>>2)) & 3) * 16
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 xf[4], wf[2];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + (aaddr[p] ^ (kk << 5)));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
+    }
+  };
+
+  for (int g = 0; g < ngroups; ++g) {
+    const int R0g = R0 + (g & 1) * (A_BYTES / ROWB);   // A buffer select folded into the row index (384 rows, keeps R>>2 & 3)
+    const bool more = g + 1 < ngroups;
+    step(std::integral_constant<int, 0>{}, g, R0g, more);
+    step(std::integral_constant<int, 1>{}, g, R0g, more);
+    step(std::integral_constant<int, 2>{}, g, R0g, more);
+    step(std::integral_constant<int, 3>{}, g, R0g, more);
+    step(std::integral_constant<int, 4>{}, g, R0g, more);
+    step(std::integral_constant<int, 5>{}, g, R0g, more);
+    step(std::integral_constant<int, 6>{}, g, R0g, more);
+    step(std::integral_constant<int, 7>{}, g, R0g, more);
+    step(std::integral_constant<int, 8>{}, g, R0g, more);
+    if (++h_kc == kcn) { h_kc = 0; ++h_dt; }            // halo cursor -> group g + 2
+  }
+
+  // ---- epilogue: tile row p -> output row oh0 + 4wm + p, column ow0 + l31 ----
+  const int ow = ow0 + l31;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int oh = oh0 + 4 * wm + p;
+    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
+    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int cb = n0 + wn * 64 + i * 32 + 8 * gq + 4 * hi;
+        if (cb >= a.Cout_st) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][gq * 4 + e];
+        if (a.bias) {
+          const f32x4 b = *(const f32x4*)(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (a.resid) {
+          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(a.out + pix * a.ldo + cb) = o;
+      }
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 static bf16_t* g_zero_page[16] = {nullptr};
 
@@ -230,13 +702,27 @@ static const bf16_t* zero_page() {
   return g_zero_page[dev];
 }
 
+static int g_force_generic = -1;
+
 template <int BN, int BK>
 static int launch_igemm(const IgemmArgs& a, unsigned grid, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
+  }
+  if (g_force_generic < 0) {
+    const char* e = getenv("DOVE_IGEMM_GENERIC");   // debugging aid: route everything through the v1 kernel
+    g_force_generic = (e && e[0] == '1') ? 1 : 0;
+  }
+  // frame / weight-tap byte ranges must fit the 31-bit buffer offsets of the fast path
+  const bool fits = (long long)a.H_in * a.W_in * a.Cin * 2 < (1ll << 31) && (long long)BN * a.Cin * 2 < (1ll << 31);
+  if (a.up == 0 && fits && !g_force_generic) {
+    hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
+    DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(fast)");
+    return DOVE_OK;
   }
   hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16");
@@ -266,6 +752,11 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   a.Cin = d->cin; a.Cout_pad = d->cout_pad; a.Cout_st = d->cout_store;
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
+  {
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("DOVE_IGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.debug = ablate;
+  }
   // tile shape: 8x16 pixels for images, 1x128 for token-major (H == 1) tensors
   int twl = 7;
   if (d->h_out > 1) {
@@ -282,6 +773,29 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   const long long grid = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
   DOVE_CHECK_ARG(grid > 0 && grid < (1ll << 31), "conv_igemm: grid too large");
   hipStream_t s = (hipStream_t)stream;
+  {
+    static int no_halo = -1;
+    if (no_halo < 0) { const char* e = getenv("DOVE_IGEMM_NOHALO"); no_halo = (e && e[0] == '1') ? 1 : 0; }
+    const bool halo_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 0 && d->pad_h == 1 && d->pad_w == 1 &&
+                         d->tmode == 0 && d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == d->h_in &&
+                         d->w_out == d->w_in && d->w_out >= 16 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
+                         !no_halo && !a.debug;
+    if (halo_ok) {
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo::LDS_BYTES);
+        attr = true;
+      }
+      a.tiles_w = (d->w_out + halo::TW - 1) / halo::TW;
+      a.tiles_h = (d->h_out + halo::TH - 1) / halo::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long g2 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g2 > 0 && g2 < (1ll << 31), "conv_igemm: grid too large");
+      hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)g2), dim3(256), halo::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo)");
+      return DOVE_OK;
+    }
+  }
   const bool bk64 = (d->cin % 64 == 0);
   if (BN == 128) return bk64 ? launch_igemm<128, 64>(a, (unsigned)grid, s) : launch_igemm<128, 32>(a, (unsigned)grid, s);
   if (BN == 64) return bk64 ? launch_igemm<64, 64>(a, (unsigned)grid, s) : launch_igemm<64, 32>(a, (unsigned)grid, s);

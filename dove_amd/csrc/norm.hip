@@ -54,13 +54,16 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count, float eps,
-                                   float* __restrict__ stats) {
-  const int tid = threadIdx.x;  // 64 threads: (group, which)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count,
+                                                          float eps, float* __restrict__ stats) {
+  const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;  // 4 strided partial sums per (group, which)
   double acc = 0.0;
-  for (int b = 0; b < nblocks; ++b) acc += (double)partial[(long long)b * 64 + tid];
-  __shared__ double sh[64];
+#pragma unroll 8
+  for (int b = part; b < nblocks; b += 4) acc += (double)partial[(long long)b * 64 + j];
+  __shared__ double sh[256];
   sh[tid] = acc;
+  __syncthreads();
+  if (tid < 64) sh[tid] = (sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]);
   __syncthreads();
   if (tid < 32) {
     const double mean = sh[tid * 2] / count;
@@ -82,11 +85,11 @@ extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, f
   const int nsub = 256 >> cpp_log;
   long long want = (npix + nsub - 1) / nsub;
   int blocks = (int)(want < ws_blocks ? want : ws_blocks);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, npix, C, cpp_log, (float*)partial_ws);
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(partial)");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)partial_ws, blocks,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, blocks,
                      (double)npix * (double)(C / 32), eps, stats);
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
   return DOVE_OK;
@@ -185,50 +188,68 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
                                                      long long rows, int D, float eps,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mod, long long split) {
-  const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_t* xr = x + row * D;
-  float f[NIT][8];
-  float s = 0.f;
+  // combined affine per row class in LDS: y = (x-mean)*rstd * A[cls][c] + B[cls][c],
+  //   A = gamma*(1+scale), B = beta*(1+scale)+shift  (32 rows per block amortise the parameter reads)
+  extern __shared__ __attribute__((aligned(16))) float lnp[];
+  float* A = lnp;            // [2][D]
+  float* Bv = lnp + 2 * D;   // [2][D]
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float g = gamma[c], b = beta[c];
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c0 = (i * 64 + lane) * 8;
-    if (c0 < D) {
-      unpack8(*(const uint4*)(xr + c0), f[i]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += f[i][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
+    for (int cls = 0; cls < 2; ++cls) {
+      float sc = 0.f, sh = 0.f;
+      if (mod) { sh = mod[(long long)cls * 2 * D + c]; sc = mod[(long long)cls * 2 * D + D + c]; }
+      A[cls * D + c] = g * (1.0f + sc);
+      Bv[cls * D + c] = b * (1.0f + sc) + sh;
     }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float v = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = 0; r < 8; ++r) {
+    const long long row = (long long)blockIdx.x * 32 + wave * 8 + r;
+    if (row >= rows) break;
+    const bf16_t* xr = x + row * D;
+    float f[NIT][8];
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c0 = (i * 64 + lane) * 8;
-    if (c0 < D) {
+    for (int i = 0; i < NIT; ++i) {
+      const int c0 = (i * 64 + lane) * 8;
+      if (c0 < D) {
+        unpack8(*(const uint4*)(xr + c0), f[i]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; v += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
-  const float* shift = mod ? mod + (row < split ? 0 : 2 * (long long)D) : nullptr;
-  const float* scale = mod ? shift + D : nullptr;
-  bf16_t* yr = y + row * D;
+        for (int e = 0; e < 8; ++e) s += f[i][e];
+      } else {
 #pragma unroll
-  for (int i = 0; i < NIT; ++i) {
-    const int c0 = (i * 64 + lane) * 8;
-    if (c0 < D) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (f[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
-        if (mod) t = t * (1.0f + scale[c0 + e]) + shift[c0 + e];
-        o[e] = t;
+        for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
       }
-      *(uint4*)(yr + c0) = pack8(o);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c0 = (i * 64 + lane) * 8;
+      if (c0 < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; v += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+    const int cls = row < split ? 0 : 1;
+    bf16_t* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c0 = (i * 64 + lane) * 8;
+      if (c0 < D) {
+        const f32x4 a0 = *(const f32x4*)(A + cls * D + c0), a1 = *(const f32x4*)(A + cls * D + c0 + 4);
+        const f32x4 b0 = *(const f32x4*)(Bv + cls * D + c0), b1 = *(const f32x4*)(Bv + cls * D + c0 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (f[i][e] - mean) * rstd * a0[e] + b0[e];
+          o[4 + e] = (f[i][4 + e] - mean) * rstd * a1[e] + b1[e];
+        }
+        *(uint4*)(yr + c0) = pack8(o);
+      }
     }
   }
 }
@@ -240,10 +261,11 @@ extern "C" int dove_layernorm_modulate_bf16(const void* x, void* y, long long ro
   DOVE_CHECK_ARG(D % 8 == 0 && D > 0 && D <= 4096, "layernorm_modulate: D (%d) must be a multiple of 8, <= 4096", D);
   DOVE_CHECK_ARG(rows > 0, "layernorm_modulate: empty input");
   const int nit = (D + 511) / 512;
-  const unsigned grid = (unsigned)((rows + 3) / 4);
+  const unsigned grid = (unsigned)((rows + 31) / 32);
+  const size_t lds = (size_t)4 * D * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-#define LN_LAUNCH(N)                                                                                        \
-  hipLaunchKernelGGL((ln_mod_kernel<N>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, rows, D, eps, \
+#define LN_LAUNCH(N)                                                                                          \
+  hipLaunchKernelGGL((ln_mod_kernel<N>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, rows, D, eps, \
                      gamma, beta, mod, split)
   switch (nit) {
     case 1: LN_LAUNCH(1); break;

@@ -131,16 +131,21 @@ class AutoencoderKLCogVideoX:
     def _cconv(self, x, name, cache, **kw):
         """CogVideoXCausalConv3d with conv_cache: the front halo is the last kt-1 input frames of the previous batch."""
         pc = self.pc[name]
-        prev = cache.get(name)
-        if pc.kt > 1:
-            k = pc.kt - 1
-            if x.shape[0] >= k:
-                new = x[-k:].clone()
-            else:  # fewer frames than the halo: slide the padded window
-                pad = prev if prev is not None else x[:1].expand(k, -1, -1, -1)
-                new = torch.cat([pad, x], dim=0)[-k:].clone()
+        if pc.kt == 1:
+            return ops.conv(x, pc, **kw)
+        k = pc.kt - 1
+        fetch = getattr(cache, "fetch", None)      # dove_amd.dist.HaloCache: halo arrives from rank-1 over xGMI
+        prev = fetch(name, (k,) + tuple(x.shape[1:]), x.device) if fetch else cache.get(name)
+        if x.shape[0] >= k:
+            new = x[-k:].clone()
+        else:  # fewer frames than the halo: slide the padded window
+            pad = prev if prev is not None else x[:1].expand(k, -1, -1, -1)
+            new = torch.cat([pad, x], dim=0)[-k:].clone()
+        if fetch:
+            cache.publish(name, new)
+        else:
             cache[name] = new
-        return ops.conv(x, pc, cache=prev if pc.kt > 1 else None, **kw)
+        return ops.conv(x, pc, cache=prev, **kw)
 
     def _norm_silu(self, x, name, zq=None):
         stats = ops.groupnorm_stats(x, self.eps)

@@ -60,6 +60,12 @@ CONV_CASES = [
     ("c2d_up_t1", 128, 128, (3, 3), 2, 6, 8, {"up": 1, "pad": (1, 1), "tmode": 1, "t_out": 4}),
     ("c2d_up_t2", 256, 256, (3, 3), 3, 5, 8, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
     ("c3d_resid", 128, 128, (3, 3, 3), 2, 12, 16, {"resid": True}),
+    # LDS-halo kernel: several 8x32 tiles, ragged borders, 2 channel chunks x 3 frame taps, 2 cout tiles
+    ("c3d_halo_multi", 64, 256, (3, 3, 3), 3, 20, 70, {"cache": True}),
+    ("c2d_halo_kt1", 128, 128, (3, 3), 2, 9, 40, {}),
+    ("c3d_halo_resid", 128, 128, (3, 3, 3), 2, 17, 33, {"resid": True, "cache": True}),
+    ("c3d_halo_cin3", 3, 128, (3, 3, 3), 4, 12, 48, {}),
+    ("c3d_halo_512", 512, 512, (3, 3, 3), 2, 8, 32, {}),
 ]
 
 

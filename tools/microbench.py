@@ -32,10 +32,22 @@ def pack(cout, cin, k):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="comma list of substrings; run only matching cases")
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    only = [o for o in args.only.split(",") if o]
+    want = lambda name: (not only) or any(o in name for o in only)   # noqa: E731
     res = {}
     dev = "cuda"
+    global timeit
+    _t = timeit
+    timeit = lambda fn, iters=args.iters, warm=2: _t(fn, iters=min(iters, args.iters), warm=min(warm, 2))   # noqa: E731
 
     def conv_case(name, cin, cout, k, T, H, W, **kw):
+        if not want(name):
+            return
         pc = pack(cout, cin, k)
         x = torch.randn(T, H, W, pc.cin_pad, device=dev).to(BF)
         y = ops.conv(x, pc, **kw)
@@ -56,6 +68,8 @@ def main():
     N = 18226
     for name, cin, cout, act in (("linear qkv 3072->9216", 3072, 9216, 0), ("linear out 3072->3072", 3072, 3072, 0),
                                  ("linear ff1 3072->12288 gelu", 3072, 12288, 1), ("linear ff2 12288->3072", 12288, 3072, 0)):
+        if not want(name):
+            continue
         pc = pack(cout, cin, ())
         x = torch.randn(N, cin, device=dev).to(BF)
         y = ops.linear(x, pc, act=act)
@@ -66,6 +80,8 @@ def main():
 
     heads = 48
     npad = (N + 127) // 128 * 128
+    if only and not (want("attention") or want("gn_") or want("ln_mod") or want("qkv_post")):
+        return
     Qh = (torch.randn(heads, npad, 64, device=dev) * 0.3).to(BF)
     Kh = (torch.randn(heads, npad, 64, device=dev) * 0.3).to(BF)
     Vt = torch.randn(heads, 64, npad, device=dev).to(BF)
