@@ -6,12 +6,21 @@
 // Operands come head-major from dove_qkv_post_bf16: Q' [H][Npad][64] (already multiplied by
 // scale*log2e), K' [H][Npad][64], V^T [H][64][Npad]; pad rows/columns are zero.
 // Workgroup = 4 waves = 128 query rows (32 per wave); KV tiles of 64 keys are staged K and V^T alike with
-// 16-byte global_load_lds into XOR-swizzled LDS, double-buffered, one barrier per tile.
+// 16-byte buffer_load ... lds into XOR-swizzled LDS (per-thread constant offsets, the tile index rides in
+// soffset), double-buffered, one barrier per tile, loop unrolled x2 so every ds_read address is a per-lane
+// constant + immediate.
 // Swapped products keep the softmax lane-local (guide T12): S^T = K Q^T puts one query column in each
-// lane (row max/sum = in-lane + one cross-half shuffle), P^T is re-packed to the MFMA B layout with
-// v_permlane32_swap, and O^T = V^T P^T accumulates with the same query-per-lane ownership.
+// lane (row max/sum = in-lane + one cross-half shuffle), P^T is packed with v_cvt_pk_bf16_f32 and re-laid
+// to the MFMA B layout with v_permlane32_swap, and O^T = V^T P^T accumulates with the same query-per-lane
+// ownership.  The O rescale is skipped (wave-uniformly) on tiles where no query's running max moved.
+// v1 of this kernel was VALU-bound (PMC: 31 VALU instructions per MFMA, software bf16 rounding + 64-bit
+// address math); see profiles/r01_pmc_halo_attn.txt.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/dove_hip.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -19,12 +28,13 @@ __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
-                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                       long long N, long long Npad, long long ldo) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                          const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
+                                                          long long N, long long Npad, long long ldo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGE = 16384;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int STAGE = 16384, VOFF = 8192;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y;
   const long long q0 = (long long)blockIdx.x * 128 + wave * 32;
@@ -44,45 +54,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   float m = -1e30f, lsum = 0.f;
 
   const int ntiles = (int)((N + 63) / 64);
-  const int srow = tid >> 3;                       // 0..31 (+32 for the second pass)
-  const int sc_ld = (tid & 7) ^ ((srow >> 1) & 7);  // actual 16-B chunk this lane fetches
-  const bf16_t* kbase = Kh + ((long long)h * Npad + srow) * 64 + sc_ld * 8;
-  const bf16_t* vbase = Vt + ((long long)h * 64 + srow) * Npad + sc_ld * 8;
-
-  auto stage = [&](int buf, int tile) {
-    const long long kv0 = (long long)tile * 64;
-    char* Ks = smem + buf * STAGE;
-    char* Vs = Ks + 8192;
+  // staging: slot = j*256 + tid -> tile row j*32 + (tid>>3), swizzled 16-B chunk
+  const int srow = tid >> 3;
+  const int sc_ld = (tid & 7) ^ ((srow >> 1) & 7);
+  const auto srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long long)h * Npad * 64), (short)0, (int)(Npad * 128), 0x00020000);
+  const auto srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + (long long)h * 64 * Npad), (short)0, (int)(Npad * 128), 0x00020000);
+  unsigned vk[2], vv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    vk[j] = (unsigned)(((j * 32 + srow) * 64 + sc_ld * 8) * 2);
+    vv[j] = (unsigned)((((long long)(j * 32 + srow)) * Npad + sc_ld * 8) * 2);
+  }
+  auto stage = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      glds16(kbase + (kv0 + j * 32) * 64, Ks + (j * 256 + wave * 64) * 16);
-      glds16(vbase + (long long)(j * 32) * Npad + kv0, Vs + (j * 256 + wave * 64) * 16);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(smem + BUF * STAGE + (j * 256 + wave * 64) * 16), 16, vk[j],
+                                               tile * (64 * 128), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(smem + BUF * STAGE + VOFF + (j * 256 + wave * 64) * 16), 16, vv[j],
+                                               tile * (64 * 2), 0, 0);
     }
   };
 
-  stage(0, 0);
-  for (int it = 0; it < ntiles; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 1 < ntiles) stage((it + 1) & 1, it + 1);
-    const char* Ks = smem + (it & 1) * STAGE;
-    const char* Vs = Ks + 8192;
+  // per-lane constant fragment offsets
+  int koff[2][4], voff[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int row = b * 32 + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      koff[b][c] = row * 128 + (((c * 2 + hi) ^ sw) << 4);          // K: kv block b, d-chunk pair c
+      voff[b][c] = VOFF + row * 128 + (((c * 2 + hi) ^ sw) << 4);   // V^T: d block b, key chunk pair c (= kb*2 + k2)
+    }
+  }
 
+  auto compute = [&](auto bufc, int tile) {
+    constexpr int BUF = decltype(bufc)::value;
     // ---- S^T[kv][q] = K Q^T ----
     f32x16 st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-      const int row = kb * 32 + l31;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int sc = (kk * 2 + hi) ^ ((row >> 1) & 7);
-        const bf16x8 kf = *(const bf16x8*)(Ks + row * 128 + sc * 16);
+        const bf16x8 kf = *(const bf16x8*)(smem + BUF * STAGE + koff[kb][kk]);
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
       }
     }
-    const long long kv0 = (long long)it * 64;
+    const long long kv0 = (long long)tile * 64;
     if (kv0 + 64 > N) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -99,24 +120,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float mnew = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    m = mnew;
+    if (__any(mt > m)) {   // wave-uniform: rescale only when some query's running max moved
+      const float mnew = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+      m = mnew;
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(st[kb][r] - mnew);
+        const float p = __builtin_amdgcn_exp2f(st[kb][r] - m);
         st[kb][r] = p;
         ps += p;
       }
-    lsum = lsum * alpha + ps;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-
+    lsum += ps;
     // ---- P^T -> bf16 MFMA B fragments: lane(q, hi) needs keys 16*k2 + 8*hi + 0..7 of each 32-key block ----
     bf16x8 pf[2][2];
 #pragma unroll
@@ -134,17 +157,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       }
     // ---- O^T[d][q] += V^T P^T ----
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int row = db * 32 + l31;
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          const int sc = (kb * 4 + k2 * 2 + hi) ^ ((row >> 1) & 7);
-          const bf16x8 vf = *(const bf16x8*)(Vs + row * 128 + sc * 16);
+          const bf16x8 vf = *(const bf16x8*)(smem + BUF * STAGE + voff[db][kb * 2 + k2]);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][k2], o[db], 0, 0, 0);
         }
-    }
+  };
+
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  stage(B0{}, 0);
+  int it = 0;
+  for (; it + 2 <= ntiles; it += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stage(B1{}, it + 1);
+    compute(B0{}, it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (it + 2 < ntiles) stage(B0{}, it + 2);
+    compute(B1{}, it + 1);
+  }
+  if (ntiles & 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    compute(B0{}, ntiles - 1);
   }
 
   const float l = lsum + __shfl_xor(lsum, 32);
@@ -169,7 +209,8 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
                                         long long Npad, int heads, int head_dim, long long ldo, void* stream) {
   DOVE_CHECK_ARG(Qh && Kh && Vt && O, "attention_fwd: null pointer");
   DOVE_CHECK_ARG(head_dim == 64, "attention_fwd: head_dim must be 64 (got %d)", head_dim);
-  DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128 + 0, "attention_fwd: Npad must be N rounded up to 128");
+  DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128, "attention_fwd: Npad must be N rounded up to 128");
+  DOVE_CHECK_ARG(Npad * 128 < (1ll << 31), "attention_fwd: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
   static bool attr_set = false;
   if (!attr_set) {

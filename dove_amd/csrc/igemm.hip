@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
   int h_dt = 0, h_kc = 0;                  // group whose halo is being staged
   auto stage_halo_round = [&](auto rc, int buf) {   // one 4 KB round of group (h_dt, h_kc) into A[buf]
     constexpr int r = decltype(rc)::value;
+    if (a.debug & 1) return;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
                                              h_kc * ROWB, 0, 0);
@@ -564,10 +565,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
     constexpr int buf = decltype(bc)::value;
     const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
+    if (!(a.debug & 2)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
                                                voffB[j], b_kc * ROWB, 0, 0);
+    }
     if (++b_tap == 9) {
       b_tap = 0;
       if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
@@ -629,6 +632,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
       for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + (aaddr[p] ^ (kk << 5)));
 #pragma unroll
       for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
+      if (a.debug & 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(wf[i]), "v"(xf[p])); }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -779,7 +789,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     const bool halo_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 0 && d->pad_h == 1 && d->pad_w == 1 &&
                          d->tmode == 0 && d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == d->h_in &&
                          d->w_out == d->w_in && d->w_out >= 16 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
-                         !no_halo && !a.debug;
+                         !no_halo;
     if (halo_ok) {
       static bool attr = false;
       if (!attr) {
