@@ -110,8 +110,10 @@ class HaloCache(dict):
 
 def _run_sharded(vae, x_cl, batches, world, rank, group, fn):
     """Run ``fn(batch_tensor, cache)`` over this rank's contiguous group of frame-batches."""
-    mine = split_batches(batches, world)[rank]
-    cache = HaloCache(group, rank, world)
+    groups = split_batches(batches, world)
+    mine = groups[rank]
+    active = sum(1 for g_ in groups if g_)        # ranks beyond the number of frame-batches own nothing and exchange nothing
+    cache = HaloCache(group, rank, active)
     outs = []
     for i, (s, e) in enumerate(mine):
         first, last = i == 0, i == len(mine) - 1

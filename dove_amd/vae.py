@@ -137,7 +137,7 @@ class AutoencoderKLCogVideoX:
         fetch = getattr(cache, "fetch", None)      # dove_amd.dist.HaloCache: halo arrives from rank-1 over xGMI
         prev = fetch(name, (k,) + tuple(x.shape[1:]), x.device) if fetch else cache.get(name)
         if x.shape[0] >= k:
-            new = x[-k:].clone()
+            new = x[-k:]      # a view: conv inputs are never written again, the batch tensor simply stays alive
         else:  # fewer frames than the halo: slide the padded window
             pad = prev if prev is not None else x[:1].expand(k, -1, -1, -1)
             new = torch.cat([pad, x], dim=0)[-k:].clone()

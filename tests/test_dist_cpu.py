@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, mode, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)     # a stuck rank dumps its stack and exits instead of hanging CI
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -62,18 +64,31 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(world, mode, port):
+    port = _free_port()          # never reuse a port a previous (killed) run may still hold
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     res = []
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
-    while not q.empty():
-        res.append(q.get())
+    try:
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        while not q.empty():
+            res.append(q.get())
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
     return res
 
 
