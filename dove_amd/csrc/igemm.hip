@@ -697,6 +697,236 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 8-wave ping-pong variant of the halo kernel.  PMC on the 4-wave kernel: MFMA busy 56 % of cycles, waves
+// parked/stalled 70 % -- each wave interleaves staging, 12 ds_reads, ~30 VALU and 16 MFMAs per K-step and the
+// two co-resident workgroups of a CU only overlap by chance.  Here ONE workgroup of 8 waves owns 16 x 32 pixels
+// (two stacked 8 x 32 tiles sharing every weight tile -> 42 % fewer staged bytes) and is split in two groups
+// of 4 waves that run the same two-phase step shifted by one barrier:
+//     phase 1: issue the LDS-DMA loads for step s+2, ds_read the 12 fragments of step s into registers
+//     phase 2: 16 MFMAs from registers only
+// Every SIMD hosts one wave of each group, so while one is in its MFMA phase the other does memory work
+// (cdna_hip_programming.md "8-phase" idea, role split by stagger instead of by wave specialisation).
+// Hazards (interval k = time between barriers; group A: phase1(s)=2s, phase2(s)=2s+1; group B one later):
+//   * weight tile of step s: ring slot s%3, loads issued in phase1(s-2) of both groups; each wave drains them with a
+//     COUNTED vmcnt before the barrier ending ITS phase1(s-1) (<= interval 2s-1), leaving only the loads it has just
+//     issued in flight; first read interval 2s.  The slot is next overwritten in phase1(s+1) of group A = interval
+//     2s+2, after group B's last read (2s+1).
+//   * halo of group g+1: 5 rounds issued during steps 0..4 of group g into the other halo buffer, whose last
+//     reader (group B, last step of group g-1) finished one barrier earlier.
+// ------------------------------------------------------------------------------------------------
+namespace halo8 {
+constexpr int TH = 16, TW = 32, HWID = TW + 2, HHGT = TH + 2, HPIX = HWID * HHGT;   // 612 halo pixels
+constexpr int BK = 32, ROWB = 64;
+constexpr int A_ROUNDS = (HPIX * 4 + 511) / 512;                                      // 5 rounds of 512 x 16 B
+constexpr int A_BYTES = A_ROUNDS * 512 * 16;                                          // 40960
+constexpr int BN = 128, B_BYTES = BN * ROWB;                                          // 8192 = 512 x 16 B: one load per thread
+constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;                                  // 106496
+}  // namespace halo8
+
+__global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a) {
+  using namespace halo8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 8);
+  const int grp = wave >> 2;                   // 0: rows 0-7 (leads), 1: rows 8-15 (one phase behind)
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
+  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
+  const int thi = rest % a.tiles_h;
+  const int t = rest / a.tiles_h;
+  const int n0 = tn * BN;
+  const int oh0 = thi * TH, ow0 = twi * TW;
+
+  unsigned voffA[A_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < A_ROUNDS; ++r) {
+    const int s = r * 512 + tid;
+    const int px = s >> 2, cs = s & 3;
+    const int c = cs ^ ((px >> 2) & 3);
+    const int hh = px / HWID, hw = px - hh * HWID;
+    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    const bool ok = (px < HPIX) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
+  }
+  unsigned voffB;
+  {
+    const int row = tid >> 2;
+    const int c = (tid & 3) ^ ((row >> 2) & 3);
+    voffB = (unsigned)((row * a.Cin + c * 8) * 2);
+  }
+  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
+  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
+  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
+  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
+  const int kcn = a.Cin / BK;
+  const int ngroups = a.kt * kcn;
+  const int nk = ngroups * 9;
+
+  auto frame_ptr = [&](int dt) -> const bf16_t* {
+    if (a.kt > 1) {
+      const int fv = t + dt - (a.kt - 1);
+      if (fv >= 0) return a.x + fv * frame_elems;
+      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
+      return a.x;
+    }
+    return a.x + (long long)t * frame_elems;
+  };
+
+  int h_dt = 0, h_kc = 0;
+  auto stage_halo_round = [&](auto rc, int buf) {
+    constexpr int r = decltype(rc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 512 + wave * 64) * 16), 16, voffA[r],
+                                             h_kc * ROWB, 0, 0);
+  };
+  int b_tap = 0, b_dt = 0, b_kc = 0;
+  auto stage_b = [&](auto bc) {
+    constexpr int buf = decltype(bc)::value;
+    const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + wave * 64 * 16), 16, voffB,
+                                             b_kc * ROWB, 0, 0);
+    if (++b_tap == 9) {
+      b_tap = 0;
+      if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
+    }
+  };
+
+  int boff[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wn * 64 + i * 32 + l31;
+      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
+    }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: halo of group 0, weight tiles of steps 0 and 1 ----
+  stage_halo_round(std::integral_constant<int, 0>{}, 0);
+  stage_halo_round(std::integral_constant<int, 1>{}, 0);
+  stage_halo_round(std::integral_constant<int, 2>{}, 0);
+  stage_halo_round(std::integral_constant<int, 3>{}, 0);
+  stage_halo_round(std::integral_constant<int, 4>{}, 0);
+  static_assert(A_ROUNDS == 5, "prologue is written for 5 halo rounds");
+  if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
+  stage_b(std::integral_constant<int, 0>{});
+  if (nk > 1) stage_b(std::integral_constant<int, 1>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  if (grp == 1) barrier();                      // stagger: group B runs one phase behind group A
+
+  const int R0 = (8 * grp + 4 * wm) * HWID + l31;
+  const int hi4 = hi << 2;
+
+  auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
+    constexpr int tap = decltype(tapc)::value;
+    constexpr int dh = tap / 3, dw = tap % 3;
+    // ---------------- phase 1: staging for step s+2, fragment reads for step s ----------------
+    int issued = 0;                                    // loads this wave issues in this phase (wave-uniform)
+    if (tap < 7 || more_groups) { stage_b(std::integral_constant<int, (tap + 2) % 3>{}); ++issued; }
+    if constexpr (tap < A_ROUNDS) {
+      if (more_groups) { stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1); ++issued; }
+    }
+    bf16x8 xf[2][4], wf[2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int R = R0g + (p + dh) * HWID + dw;
+      const int ad = (R << 6) + (((R ^ hi4) & 0xC) << 2);
+      xf[0][p] = *(const bf16x8*)(smem + ad);
+      xf[1][p] = *(const bf16x8*)(smem + (ad ^ 32));
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[kk][i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
+    // drain everything issued in EARLIER steps (they had a whole step to land); this phase's own loads stay in flight.
+    // Loads retire in order, so a counted wait is exact.  Waiting here, in the memory phase, never delays MFMAs.
+    if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    barrier();
+    // ---------------- phase 2: MFMAs from registers ----------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
+    barrier();
+  };
+
+  for (int g = 0; g < ngroups; ++g) {
+    const int R0g = R0 + (g & 1) * (A_BYTES / ROWB);    // 640 rows: multiple of 16, keeps (R >> 2) & 3
+    const bool more = g + 1 < ngroups;
+    step(std::integral_constant<int, 0>{}, g, R0g, more);
+    step(std::integral_constant<int, 1>{}, g, R0g, more);
+    step(std::integral_constant<int, 2>{}, g, R0g, more);
+    step(std::integral_constant<int, 3>{}, g, R0g, more);
+    step(std::integral_constant<int, 4>{}, g, R0g, more);
+    step(std::integral_constant<int, 5>{}, g, R0g, more);
+    step(std::integral_constant<int, 6>{}, g, R0g, more);
+    step(std::integral_constant<int, 7>{}, g, R0g, more);
+    step(std::integral_constant<int, 8>{}, g, R0g, more);
+    if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
+  }
+  if (grp == 0) barrier();                      // balance the stagger barrier of group B
+
+  // ---- epilogue ----
+  const int ow = ow0 + l31;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int oh = oh0 + 8 * grp + 4 * wm + p;
+    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
+    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int cb = n0 + wn * 64 + i * 32 + 8 * gq + 4 * hi;
+        if (cb >= a.Cout_st) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][gq * 4 + e];
+        if (a.bias) {
+          const f32x4 b = *(const f32x4*)(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (a.resid) {
+          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(a.out + pix * a.ldo + cb) = o;
+      }
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 static bf16_t* g_zero_page[16] = {nullptr};
 
@@ -790,6 +1020,23 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
                          d->tmode == 0 && d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == d->h_in &&
                          d->w_out == d->w_in && d->w_out >= 16 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
                          !no_halo;
+    static int halo8 = -1;
+    if (halo8 < 0) { const char* e = getenv("DOVE_CONV_HALO8"); halo8 = (e && e[0] == '0') ? 0 : 1; }
+    if (halo_ok && halo8 && d->h_out >= 16) {
+      static bool attr8 = false;
+      if (!attr8) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        attr8 = true;
+      }
+      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
+      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
+      hipLaunchKernelGGL(conv3x3_halo8_kernel, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
+      return DOVE_OK;
+    }
     if (halo_ok) {
       static bool attr = false;
       if (!attr) {

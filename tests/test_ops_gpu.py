@@ -66,6 +66,9 @@ CONV_CASES = [
     ("c3d_halo_resid", 128, 128, (3, 3, 3), 2, 17, 33, {"resid": True, "cache": True}),
     ("c3d_halo_cin3", 3, 128, (3, 3, 3), 4, 12, 48, {}),
     ("c3d_halo_512", 512, 512, (3, 3, 3), 2, 8, 32, {}),
+    # 8-wave ping-pong halo kernel (H >= 16): 3 x 3 tiles of 16x32 with ragged edges, 2 cout tiles
+    ("c3d_halo8_tiles", 64, 256, (3, 3, 3), 2, 40, 70, {"cache": True, "resid": True}),
+    ("c3d_halo8_512", 512, 128, (3, 3, 3), 1, 16, 32, {}),
 ]
 
 
