@@ -709,22 +709,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
 // Every SIMD hosts one wave of each group, so while one is in its MFMA phase the other does memory work
 // (cdna_hip_programming.md "8-phase" idea, role split by stagger instead of by wave specialisation).
 // Hazards (interval k = time between barriers; group A: phase1(s)=2s, phase2(s)=2s+1; group B one later):
-//   * weight tile of step s: ring slot s%3, loads issued in phase1(s-2) of both groups; each wave drains them with a
-//     COUNTED vmcnt before the barrier ending ITS phase1(s-1) (<= interval 2s-1), leaving only the loads it has just
-//     issued in flight; first read interval 2s.  The slot is next overwritten in phase1(s+1) of group A = interval
-//     2s+2, after group B's last read (2s+1).
+//   * weight tile of step s: ring slot s%4, loads issued in phase1(s-3) of both groups (LDS-DMA issue->landed is
+//     ~1.1 us, longer than one step); each wave drains them with a COUNTED vmcnt before the barrier ending ITS
+//     phase1(s-1) (<= interval 2s-1), leaving the loads of steps s-2 and s-1 in flight; first read interval 2s.
+//     The slot is next overwritten in phase1(s+1) of group A = interval 2s+2, after group B's last read (2s+1).
 //   * halo of group g+1: 5 rounds issued during steps 0..4 of group g into the other halo buffer, whose last
 //     reader (group B, last step of group g-1) finished one barrier earlier.
 // ------------------------------------------------------------------------------------------------
 namespace halo8 {
 constexpr int TH = 16, TW = 32, HWID = TW + 2, HHGT = TH + 2, HPIX = HWID * HHGT;   // 612 halo pixels
 constexpr int BK = 32, ROWB = 64;
-constexpr int A_ROUNDS = (HPIX * 4 + 511) / 512;                                      // 5 rounds of 512 x 16 B
-constexpr int A_BYTES = A_ROUNDS * 512 * 16;                                          // 40960
+// Halo rows are PADDED to 80 bytes (5 x 16 B, last slot unused) instead of XOR-swizzled: slot index 5*row + chunk is
+// distinct mod 16 for any 16 rows that are distinct mod 16, so ds_read_b128 stays conflict-free, and the fragment
+// address becomes LINEAR in the row -> one base VGPR + immediate offsets for all 9 taps (zero VALU per step; timing
+// showed the memory phase is slowed ~2x by its SIMD partner's MFMA stream, so its instruction count is what matters).
+constexpr int APITCH = 80, ASLOTS = HPIX * 5;                                         // 3060 x 16 B
+constexpr int A_ROUNDS = (ASLOTS + 511) / 512;                                        // 6 rounds of 512 x 16 B
+constexpr int A_BYTES = A_ROUNDS * 512 * 16;                                          // 49152
 constexpr int BN = 128, B_BYTES = BN * ROWB;                                          // 8192 = 512 x 16 B: one load per thread
-constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;                                  // 106496
+constexpr int B_RING = 4;                                                             // weights run 3 steps ahead
+constexpr int LDS_BYTES = 2 * A_BYTES + B_RING * B_BYTES;                             // 131072
 }  // namespace halo8
 
+template <bool TIMING>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a) {
   using namespace halo8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -735,11 +742,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   const int wm = (wave >> 1) & 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
+  // tile order: cout tile fastest, then the OUTPUT FRAME, then space.  The three temporal taps make input frame f
+  // the operand of output frames f, f+1, f+2: with t fast those blocks run back-to-back on one XCD and the re-reads
+  // hit L2 / Infinity Cache instead of HBM (with t slowest FETCH_SIZE was 3x the input tensor).
   unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = rest % a.tiles_n; rest /= a.tiles_n;
-  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
-  const int thi = rest % a.tiles_h;
-  const int t = rest / a.tiles_h;
+  int t, twi, thi;
+  if (a.debug & 64) {          // A/B switch: old order (frame slowest)
+    twi = rest % a.tiles_w; rest /= a.tiles_w;
+    thi = rest % a.tiles_h;
+    t = rest / a.tiles_h;
+  } else {
+    t = rest % a.T_out; rest /= a.T_out;
+    twi = rest % a.tiles_w;
+    thi = rest / a.tiles_w;
+  }
   const int n0 = tn * BN;
   const int oh0 = thi * TH, ow0 = twi * TW;
 
@@ -747,11 +764,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
 #pragma unroll
   for (int r = 0; r < A_ROUNDS; ++r) {
     const int s = r * 512 + tid;
-    const int px = s >> 2, cs = s & 3;
-    const int c = cs ^ ((px >> 2) & 3);
+    const int px = s / 5, c = s - px * 5;            // padded rows: 5 slots per pixel, slot 4 is padding
     const int hh = px / HWID, hw = px - hh * HWID;
     const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
-    const bool ok = (px < HPIX) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+    const bool ok = (px < HPIX) && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
     voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
   }
   unsigned voffB;
@@ -781,17 +797,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   int h_dt = 0, h_kc = 0;
   auto stage_halo_round = [&](auto rc, int buf) {
     constexpr int r = decltype(rc)::value;
+    if (a.debug & 1) return;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 512 + wave * 64) * 16), 16, voffA[r],
                                              h_kc * ROWB, 0, 0);
   };
   int b_tap = 0, b_dt = 0, b_kc = 0;
-  auto stage_b = [&](auto bc) {
-    constexpr int buf = decltype(bc)::value;
+  int b_slot = 0;                          // ring slot the next staged weight tile goes to
+  auto stage_b = [&]() {
+    const int buf = b_slot;
+    b_slot = (b_slot + 1 == B_RING) ? 0 : b_slot + 1;
     const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + wave * 64 * 16), 16, voffB,
-                                             b_kc * ROWB, 0, 0);
+    if (!(a.debug & 2))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + wave * 64 * 16), 16, voffB,
+                                               b_kc * ROWB, 0, 0);
     if (++b_tap == 9) {
       b_tap = 0;
       if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
@@ -827,45 +847,72 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   stage_halo_round(std::integral_constant<int, 2>{}, 0);
   stage_halo_round(std::integral_constant<int, 3>{}, 0);
   stage_halo_round(std::integral_constant<int, 4>{}, 0);
-  static_assert(A_ROUNDS == 5, "prologue is written for 5 halo rounds");
+  stage_halo_round(std::integral_constant<int, 5>{}, 0);
+  static_assert(A_ROUNDS == 6, "prologue is written for 6 halo rounds");
   if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
-  stage_b(std::integral_constant<int, 0>{});
-  if (nk > 1) stage_b(std::integral_constant<int, 1>{});
+  stage_b();
+  if (nk > 1) stage_b();
+  if (nk > 2) stage_b();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
   if (grp == 1) barrier();                      // stagger: group B runs one phase behind group A
+  if ((a.debug & 32) && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger group
 
-  const int R0 = (8 * grp + 4 * wm) * HWID + l31;
-  const int hi4 = hi << 2;
+  const int abase0 = ((8 * grp + 4 * wm) * HWID + l31) * APITCH + hi * 16;   // byte address of (tile row 4wm, col l31), chunk hi
+
+  // TIMING build only: lane 0 of waves 0 and 4 of one workgroup logs s_memtime at 5 points of steps 18..53
+  unsigned long long* tlog = nullptr;
+  if (TIMING && blockIdx.x == 4001 && (wave & 3) == 0 && lane == 0) tlog = (unsigned long long*)a.gate + (wave >> 2) * 36 * 5;
+  int tstep = 0;
+  int rd_slot = 0, issued_prev = 0;        // ring slot read by the current step; loads issued in the previous step
+  auto stamp = [&](int k) {
+    if (TIMING && tlog && tstep >= 18 && tstep < 54) tlog[(tstep - 18) * 5 + k] = __builtin_readcyclecounter();
+  };
 
   auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
     constexpr int tap = decltype(tapc)::value;
     constexpr int dh = tap / 3, dw = tap % 3;
+    stamp(0);
     // ---------------- phase 1: staging for step s+2, fragment reads for step s ----------------
+    // LDS-DMA issue -> landed is ~1.1 us (longer than a step): weight tiles are staged THREE steps ahead (4-slot ring),
+    // halo rounds of the next group at taps 0..4.
     int issued = 0;                                    // loads this wave issues in this phase (wave-uniform)
-    if (tap < 7 || more_groups) { stage_b(std::integral_constant<int, (tap + 2) % 3>{}); ++issued; }
+    if (tap < 6 || more_groups) { stage_b(); ++issued; }
     if constexpr (tap < A_ROUNDS) {
       if (more_groups) { stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1); ++issued; }
     }
     bf16x8 xf[2][4], wf[2][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int R = R0g + (p + dh) * HWID + dw;
-      const int ad = (R << 6) + (((R ^ hi4) & 0xC) << 2);
-      xf[0][p] = *(const bf16x8*)(smem + ad);
-      xf[1][p] = *(const bf16x8*)(smem + (ad ^ 32));
+      xf[0][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH);        // immediate offsets only
+      xf[1][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH + 32);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wf[kk][i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
-    // drain everything issued in EARLIER steps (they had a whole step to land); this phase's own loads stay in flight.
+      for (int i = 0; i < 2; ++i) wf[kk][i] = *(const bf16x8*)(smem + rd_slot * B_BYTES + boff[i][kk]);
+    // Drain everything issued two or more steps ago; the loads of this step AND of the previous one stay in flight.
     // Loads retire in order, so a counted wait is exact.  Waiting here, in the memory phase, never delays MFMAs.
-    if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    {
+      const int pend = issued + issued_prev;                     // two steps of loads stay in flight
+      if (pend >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else if (pend == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else if (pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      else if (pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      issued_prev = issued;
+    }
+    stamp(1);
     barrier();
+    stamp(2);
     // ---------------- phase 2: MFMAs from registers ----------------
+    if (a.debug & 4) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(wf[kk][p & 1]), "v"(xf[kk][p])); }
+    } else {
+    if (!(a.debug & 8)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -873,11 +920,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
 #pragma unroll
         for (int p = 0; p < 4; ++p)
           acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
+    if (!(a.debug & 8)) __builtin_amdgcn_s_setprio(0);
+    }
+    stamp(3);
     barrier();
+    stamp(4);
+    ++tstep;
+    rd_slot = (rd_slot + 1 == B_RING) ? 0 : rd_slot + 1;
   };
 
   for (int g = 0; g < ngroups; ++g) {
-    const int R0g = R0 + (g & 1) * (A_BYTES / ROWB);    // 640 rows: multiple of 16, keeps (R >> 2) & 3
+    const int R0g = abase0 + (g & 1) * A_BYTES;         // per-lane byte base into this group's halo buffer
     const bool more = g + 1 < ngroups;
     step(std::integral_constant<int, 0>{}, g, R0g, more);
     step(std::integral_constant<int, 1>{}, g, R0g, more);
@@ -917,6 +970,174 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
           const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+        }
+        uint2 o;
+        o.x = pack_bf2(v[0], v[1]);
+        o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(a.out + pix * a.ldo + cb) = o;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// gemm8: the ping-pong structure of conv3x3_halo8 for plain GEMMs (every Linear of the DiT, 1x1x1 convs):
+// 512 rows x 128 output channels per 8-wave workgroup, K-step 32, 3-deep LDS rings for both operands
+// (105 FLOP per staged byte vs 64 in igemm_fast), two 4-wave groups one barrier phase apart.
+// Rows beyond M need no mask: the A descriptor's num_records ends at the last valid row -> zeros.
+// ------------------------------------------------------------------------------------------------
+namespace gemm8 {
+constexpr int BM = 512, BN = 128, BK = 32, ROWB = 64;
+constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;          // 32768, 8192
+constexpr int LDS_BYTES = 3 * (A_BYTES + B_BYTES);                // 122880
+}  // namespace gemm8
+
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(const IgemmArgs a, long long M) {
+  using namespace gemm8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 8);
+  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = rest % a.tiles_n;
+  const long long m0 = (long long)(rest / a.tiles_n) * BM;
+  const int n0 = tn * BN;
+  const int K = a.Cin;
+  const int nk = K / BK;
+
+  const long long rows_here = (M - m0) < BM ? (M - m0) : BM;
+  const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), (short)0, (int)(rows_here * K * 2), 0x00020000);
+  const auto srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)n0 * K), (short)0, (int)((long long)BN * K * 2), 0x00020000);
+  unsigned voffA[4], voffB;
+  {
+    const int rsub = tid >> 2;
+    const int c = (tid & 3) ^ ((rsub >> 2) & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voffA[j] = (unsigned)((((long long)(j * 128 + rsub)) * K + c * 8) * 2);
+    voffB = (unsigned)(((long long)rsub * K + c * 8) * 2);
+  }
+  int s_k = 0;   // next K-step to stage
+  auto stage = [&](auto slotc) {
+    constexpr int SLOT = decltype(slotc)::value;
+    const int soff = s_k * (BK * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + SLOT * A_BYTES + (j * 512 + wave * 64) * 16), 16, voffA[j], soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (lds_ptr_t)(smem + 3 * A_BYTES + SLOT * B_BYTES + wave * 64 * 16), 16, voffB, soff, 0, 0);
+    ++s_k;
+  };
+
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = grp * 256 + wm * 128 + p * 32 + l31;
+    aoff[p] = row * ROWB + ((hi ^ ((row >> 2) & 3)) << 4);          // kk = 0; kk = 1 is ^32
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = wn * 64 + i * 32 + l31;
+    boff[i] = 3 * A_BYTES + row * ROWB + ((hi ^ ((row >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  stage(std::integral_constant<int, 0>{});
+  if (nk > 1) stage(std::integral_constant<int, 1>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  barrier();
+  if (grp == 1) barrier();
+
+  auto step = [&](auto slotc, bool stage_next) {
+    constexpr int SLOT = decltype(slotc)::value;
+    if (stage_next) stage(std::integral_constant<int, (SLOT + 2) % 3>{});
+    bf16x8 xf[2][4], wf[2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      xf[0][p] = *(const bf16x8*)(smem + SLOT * A_BYTES + aoff[p]);
+      xf[1][p] = *(const bf16x8*)(smem + SLOT * A_BYTES + (aoff[p] ^ 32));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wf[0][i] = *(const bf16x8*)(smem + SLOT * B_BYTES + boff[i]);
+      wf[1][i] = *(const bf16x8*)(smem + SLOT * B_BYTES + (boff[i] ^ 32));
+    }
+    if (stage_next) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    barrier();
+    __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    barrier();
+  };
+
+  int s = 0;
+  for (; s + 3 <= nk; s += 3) {
+    step(std::integral_constant<int, 0>{}, s + 2 < nk);
+    step(std::integral_constant<int, 1>{}, s + 3 < nk);
+    step(std::integral_constant<int, 2>{}, s + 4 < nk);
+  }
+  if (nk - s >= 1) step(std::integral_constant<int, 0>{}, s + 2 < nk);
+  if (nk - s == 2) step(std::integral_constant<int, 1>{}, false);
+  if (grp == 0) barrier();
+
+  // ---- epilogue (bias, GELU, residual, AdaLN gate) ----
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const long long pix = m0 + grp * 256 + wm * 128 + p * 32 + l31;
+    if (pix >= M) continue;
+    const float* gate = a.gate ? (a.gate + (pix < a.gate_split ? 0 : a.Cout_pad)) : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = n0 + wn * 64 + i * 32 + 8 * g + 4 * hi;
+        if (cb >= a.Cout_st) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][g * 4 + e];
+        if (a.bias) {
+          const f32x4 b = *(const f32x4*)(a.bias + cb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (a.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
+        }
+        if (a.resid) {
+          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
+          float r[4] = {__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u),
+                        __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
+          if (gate) {
+            const f32x4 gg = *(const f32x4*)(gate + cb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = r[e] + gg[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          }
         }
         uint2 o;
         o.x = pack_bf2(v[0], v[1]);
@@ -1020,12 +1241,37 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
                          d->tmode == 0 && d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == d->h_in &&
                          d->w_out == d->w_in && d->w_out >= 16 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
                          !no_halo;
+    // plain GEMM (linear / 1x1x1 conv over a contiguous channels-last tensor): ping-pong gemm8 for large M
+    {
+      static int use_g8 = -1;
+      if (use_g8 < 0) { const char* e = getenv("DOVE_GEMM8"); use_g8 = (e && e[0] == '0') ? 0 : 1; }
+      const long long M = (long long)d->t_out * d->h_out * d->w_out;
+      const bool g8_ok = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
+                         d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 &&
+                         M >= 4096 && (long long)512 * d->cin * 2 < (1ll << 31) && use_g8 && !a.debug;
+      // few, very deep tiles (e.g. ff2: K = 12288, 864 tiles) run slightly better on the 2-blocks-per-CU fast kernel
+      const long long g8_tiles = ((M + gemm8::BM - 1) / gemm8::BM) * (d->cout_pad / 128);
+      if (g8_ok && (g8_tiles >= 1024 || d->cin <= 4096)) {
+        static bool attrg = false;
+        if (!attrg) {
+          (void)hipFuncSetAttribute((const void*)gemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+          attrg = true;
+        }
+        a.tiles_n = d->cout_pad / 128;
+        const long long gridg = ((M + gemm8::BM - 1) / gemm8::BM) * a.tiles_n;
+        DOVE_CHECK_ARG(gridg > 0 && gridg < (1ll << 31), "conv_igemm: grid too large");
+        hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)gridg), dim3(512), gemm8::LDS_BYTES, s, a, M);
+        DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8)");
+        return DOVE_OK;
+      }
+    }
     static int halo8 = -1;
     if (halo8 < 0) { const char* e = getenv("DOVE_CONV_HALO8"); halo8 = (e && e[0] == '0') ? 0 : 1; }
     if (halo_ok && halo8 && d->h_out >= 16) {
       static bool attr8 = false;
       if (!attr8) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
         attr8 = true;
       }
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
@@ -1033,7 +1279,12 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       a.tiles_n = d->cout_pad / 128;
       const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
-      hipLaunchKernelGGL(conv3x3_halo8_kernel, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      if (d->debug_buf) {   // timing build: per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
+        a.gate = (const float*)d->debug_buf;
+        hipLaunchKernelGGL(conv3x3_halo8_kernel<true>, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+        a.gate = nullptr;
+      } else
+      hipLaunchKernelGGL(conv3x3_halo8_kernel<false>, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
       return DOVE_OK;
     }

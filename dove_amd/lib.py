@@ -22,7 +22,7 @@ class ConvDesc(C.Structure):
         ("t_out", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("cout_pad", C.c_int), ("cout_store", C.c_int),
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
-        ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
+        ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong), ("debug_buf", C.c_void_p),
     ]
 
 

@@ -65,7 +65,7 @@ def set_profiler(records: list | None):
 def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
-         out: torch.Tensor | None = None) -> torch.Tensor:
+         out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None) -> torch.Tensor:
     """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo]."""
     L.require_cuda(x, cache, resid, gate, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 4, (x.dtype, x.shape)
@@ -100,6 +100,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     d.ldo = ldo
     d.ldr = resid.shape[-1] if resid is not None else 0
     d.gate_split = gate_split
+    d.debug_buf = debug_buf.data_ptr() if debug_buf is not None else None
     if resid is not None:
         assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
     if gate is not None:

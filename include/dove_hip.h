@@ -57,6 +57,7 @@ typedef struct dove_conv_desc {
   int t_out, h_out, w_out, cout_pad, cout_store;
   int kt, kh, kw, stride, pad_h, pad_w, up, tmode, act;
   long long ldo, ldr, gate_split;
+  void* debug_buf; /* NULL in production; tools/halo8_timing.py passes a device buffer for the phase-timing build */
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 

@@ -54,6 +54,7 @@ CONV_CASES = [
     ("c3d_96_64", 96, 64, (3, 3, 3), 2, 8, 8, {}),
     ("c111_128_256", 128, 256, (1, 1, 1), 3, 9, 11, {}),
     ("c111_16_1024", 16, 1024, (1, 1, 1), 3, 4, 6, {}),
+    ("c111_gemm8", 128, 256, (1, 1, 1), 2, 48, 64, {}),
     ("c2d_down_even", 128, 128, (3, 3), 3, 16, 20, {"stride": 2, "pad": (0, 0)}),
     ("c2d_down_odd", 64, 64, (3, 3), 2, 15, 9, {"stride": 2, "pad": (0, 0)}),
     ("c2d_up", 128, 128, (3, 3), 3, 6, 9, {"up": 1, "pad": (1, 1)}),
@@ -103,6 +104,14 @@ LIN_CASES = [
     ("lin_12288_3072_gate_inplace", 270, 12288, 3072, {"gate": True, "inplace": True}),
     ("lin_M1", 1, 256, 256, {}),
     ("lin_M129", 129, 256, 64, {}),
+    # gemm8 ping-pong kernel (M >= 4096): ragged M tail, every K-loop tail length (nk = 1, 2, 3, 4, 96), epilogues
+    ("lin8_basic", 4700, 3072, 256, {}),
+    ("lin8_gelu", 4096, 256, 1024, {"act": 1}),
+    ("lin8_gate_inplace", 5000, 1024, 128, {"gate": True, "inplace": True}),
+    ("lin8_k32", 4100, 32, 128, {}),
+    ("lin8_k64", 4100, 64, 256, {}),
+    ("lin8_k96", 4200, 96, 128, {}),
+    ("lin8_k128", 4608, 128, 3072, {}),
 ]
 
 
