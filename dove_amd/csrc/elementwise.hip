@@ -214,3 +214,52 @@ extern "C" int dove_gemv_bf16(const void* W, const float* bias, const float* x, 
   DOVE_CHECK_LAUNCH("dove_gemv_bf16");
   return DOVE_OK;
 }
+
+// ---- diffusers VAE tiling: blend_v / blend_h on channels-last tiles, in place on b ----
+//   axis 0 (rows):  b[t, y, w, :] = a[t, Ha - extent + y, w, :] * (1 - y/extent) + b[t, y, w, :] * (y/extent),  y < extent
+//   axis 1 (cols):  b[t, h, x, :] = a[t, h, Wa - extent + x, :] * (1 - x/extent) + b[t, h, x, :] * (x/extent),  x < extent
+__global__ void blend_edge_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b, int T, int Ha, int Wa, int Hb,
+                                  int Wb, int ld, int extent, int axis) {
+  const int c4 = ld / 4;                                     // 8-byte granules (decoder tiles have ld = 4)
+  const int L = axis == 0 ? Wb : Hb;                         // length of the untouched spatial axis
+  const long long total = (long long)T * extent * L * c4;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % c4);
+  long long r = i / c4;
+  const int l = (int)(r % L); r /= L;
+  const int e = (int)(r % extent);
+  const int t = (int)(r / extent);
+  long long ia, ib;
+  if (axis == 0) {
+    ia = (((long long)t * Ha + (Ha - extent + e)) * Wa + l) * ld + c * 4;
+    ib = (((long long)t * Hb + e) * Wb + l) * ld + c * 4;
+  } else {
+    ia = (((long long)t * Ha + l) * Wa + (Wa - extent + e)) * ld + c * 4;
+    ib = (((long long)t * Hb + l) * Wb + e) * ld + c * 4;
+  }
+  const uint2 va = *(const uint2*)(a + ia), vb = *(const uint2*)(b + ib);
+  const float fa[4] = {__uint_as_float(va.x << 16), __uint_as_float(va.x & 0xffff0000u), __uint_as_float(va.y << 16), __uint_as_float(va.y & 0xffff0000u)};
+  const float fb[4] = {__uint_as_float(vb.x << 16), __uint_as_float(vb.x & 0xffff0000u), __uint_as_float(vb.y << 16), __uint_as_float(vb.y & 0xffff0000u)};
+  const float wb = (float)e / (float)extent, wa = 1.0f - wb;
+  uint2 o;
+  o.x = pack_bf2(fa[0] * wa + fb[0] * wb, fa[1] * wa + fb[1] * wb);
+  o.y = pack_bf2(fa[2] * wa + fb[2] * wb, fa[3] * wa + fb[3] * wb);
+  *(uint2*)(b + ib) = o;
+}
+
+extern "C" int dove_blend_edge_bf16(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb, int ld, int extent,
+                                     int axis, void* stream) {
+  DOVE_CHECK_ARG(a && b, "blend_edge: null pointer");
+  DOVE_CHECK_ARG(ld % 4 == 0 && ld > 0, "blend_edge: ld (%d) must be a multiple of 4", ld);
+  DOVE_CHECK_ARG(axis == 0 || axis == 1, "blend_edge: axis must be 0 (rows) or 1 (cols)");
+  DOVE_CHECK_ARG(T > 0 && extent >= 0, "blend_edge: bad shape");
+  if (axis == 0) DOVE_CHECK_ARG(Wa == Wb && extent <= Ha && extent <= Hb, "blend_edge: row blend needs equal widths, extent <= heights");
+  else DOVE_CHECK_ARG(Ha == Hb && extent <= Wa && extent <= Wb, "blend_edge: col blend needs equal heights, extent <= widths");
+  if (extent == 0) return DOVE_OK;
+  const long long total = (long long)T * extent * (axis == 0 ? Wb : Hb) * (ld / 4);
+  hipLaunchKernelGGL(blend_edge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, (bf16_t*)b, T, Ha, Wa, Hb, Wb, ld, extent, axis);
+  DOVE_CHECK_LAUNCH("dove_blend_edge_bf16");
+  return DOVE_OK;
+}

@@ -269,3 +269,12 @@ def gemv(W: torch.Tensor, bias, x: torch.Tensor, act_in: int = 0) -> torch.Tenso
     L.check(L.load().dove_gemv_bf16(L.ptr(W), L.ptr(bias), L.ptr(x), W.shape[1], W.shape[0], act_in, L.ptr(y), L.stream_ptr()),
             "dove_gemv_bf16")
     return y
+
+
+def blend_edge(a: torch.Tensor, b: torch.Tensor, extent: int, axis: int) -> torch.Tensor:
+    """diffusers blend_v (axis 0) / blend_h (axis 1) on channels-last tiles [T,H,W,ld], in place on b."""
+    L.require_cuda(a, b)
+    assert a.dtype == b.dtype == torch.bfloat16 and a.shape[0] == b.shape[0] and a.shape[3] == b.shape[3]
+    L.check(L.load().dove_blend_edge_bf16(L.ptr(a), L.ptr(b), b.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2],
+                                          b.shape[3], extent, axis, L.stream_ptr()), "dove_blend_edge_bf16")
+    return b

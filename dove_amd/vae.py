@@ -205,21 +205,69 @@ class AutoencoderKLCogVideoX:
         h = self._norm_silu(h, "decoder.norm_out", zq=z)
         return self._cconv(h, "decoder.conv_out", cache)
 
+    # ---- diffusers spatial tiling (enable_tiling; SURVEY.md App. A.4, all published numbers use --is_vae_st) --------
+    def _tiling_params(self):
+        c = self.config
+        down = 2 ** (len(self.boc) - 1)
+        smin_h, smin_w = c.get("sample_height", 480) // 2, c.get("sample_width", 720) // 2
+        return dict(smin_h=smin_h, smin_w=smin_w, lmin_h=int(smin_h / down), lmin_w=int(smin_w / down), of_h=1 / 6, of_w=1 / 5)
+
+    def _tiled(self, x_cl, tile_h, tile_w, stride_h, stride_w, blend_h, blend_w, lim_h, lim_w, batch, fn):
+        """Tile loop of diffusers tiled_encode/tiled_decode on a channels-last [T,H,W,C] tensor: each tile runs the whole
+        frame-batched network with its own conv caches (GroupNorm statistics become per tile); tiles are cross-faded
+        IN PLACE with their already blended upper / left neighbours, cropped and concatenated."""
+        T, H, W, _ = x_cl.shape
+        rows = []
+        for i in range(0, H, stride_h):
+            row = []
+            for j in range(0, W, stride_w):
+                cache, parts = {}, []
+                for s, e in frame_batches(T, batch):
+                    parts.append(fn(x_cl[s:e, i:i + tile_h, j:j + tile_w].contiguous(), cache))
+                row.append(torch.cat(parts, dim=0) if len(parts) > 1 else parts[0])
+            rows.append(row)
+        out_rows = []
+        for i, row in enumerate(rows):
+            out_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    ops.blend_edge(rows[i - 1][j], tile, min(rows[i - 1][j].shape[1], tile.shape[1], blend_h), 0)
+                if j > 0:
+                    ops.blend_edge(row[j - 1], tile, min(row[j - 1].shape[2], tile.shape[2], blend_w), 1)
+                out_row.append(tile[:, :lim_h, :lim_w])
+            out_rows.append(torch.cat(out_row, dim=2))
+        return torch.cat(out_rows, dim=1).contiguous()
+
+    def _tiled_encode(self, x_cl):
+        p = self._tiling_params()
+        st_h, st_w = int(p["smin_h"] * (1 - p["of_h"])), int(p["smin_w"] * (1 - p["of_w"]))
+        bl_h, bl_w = int(p["lmin_h"] * p["of_h"]), int(p["lmin_w"] * p["of_w"])
+        return self._tiled(x_cl, p["smin_h"], p["smin_w"], st_h, st_w, bl_h, bl_w, p["lmin_h"] - bl_h, p["lmin_w"] - bl_w,
+                           self.enc_batch, self._encoder)
+
+    def _tiled_decode(self, z_cl):
+        p = self._tiling_params()
+        st_h, st_w = int(p["lmin_h"] * (1 - p["of_h"])), int(p["lmin_w"] * (1 - p["of_w"]))
+        bl_h, bl_w = int(p["smin_h"] * p["of_h"]), int(p["smin_w"] * p["of_w"])
+        return self._tiled(z_cl, p["lmin_h"], p["lmin_w"], st_h, st_w, bl_h, bl_w, p["smin_h"] - bl_h, p["smin_w"] - bl_w,
+                           self.dec_batch, self._decoder)
+
     # ---- public API -----------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """x [B,3,F,H,W] in [-1,1] -> .latent_dist (posterior over [B,L,1+(F-1)/4,H/8,W/8])."""
         if x.dim() != 5:
             raise ValueError("expected [B,C,F,H,W]")
-        if self.use_tiling and (x.shape[-1] > self.config.get("sample_width", 720) // 2 or
-                                x.shape[-2] > self.config.get("sample_height", 480) // 2):
-            raise NotImplementedError("VAE spatial tiling (--is_vae_st) is a SURVEY 8(f) follow-up; disable_tiling() "
-                                      "or run untiled (288 GB HBM holds the untiled 720p/1080p activations)")
+        tp = self._tiling_params()
+        tiled = self.use_tiling and (x.shape[-1] > tp["smin_w"] or x.shape[-2] > tp["smin_h"])
         x = x.to(self.device).contiguous()
         cin_pad = self.pc["encoder.conv_in"].cin_pad
         moments = []
         for b in range(x.shape[0]):
             x_cl = ops.cl_from_ncthw(x[b], cin_pad)
+            if tiled:
+                moments.append(self._tiled_encode(x_cl))
+                continue
             cache, outs = {}, []
             for s, e in frame_batches(x_cl.shape[0], self.enc_batch):
                 outs.append(self._encoder(x_cl[s:e], cache))
@@ -234,9 +282,14 @@ class AutoencoderKLCogVideoX:
         cin_pad = self.pc["decoder.conv_in"].cin_pad
         cout = self.config["out_channels"]
         post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
+        tp = self._tiling_params()
+        tiled = self.use_tiling and (z.shape[-1] > tp["lmin_w"] or z.shape[-2] > tp["lmin_h"])
         vids = []
         for b in range(z.shape[0]):
             z_cl = ops.cl_from_ncthw(z[b], cin_pad, scale=_prescale)
+            if tiled:
+                vids.append(ops.ncthw_from_cl(self._tiled_decode(z_cl), cout, self.dtype, **post))
+                continue
             cache, outs = {}, []
             for s, e in frame_batches(z_cl.shape[0], self.dec_batch):
                 o = self._decoder(z_cl[s:e], cache)

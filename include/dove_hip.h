@@ -107,6 +107,11 @@ int dove_patchify(const void* x, int dtype, int T, int C, int H, int W, int pt, 
                   void* stream);
 int dove_unpatchify(const void* tokens, long long ld, int T, int C, int H, int W, int pt, int p, void* y, int dtype,
                     void* stream);
+/* AutoencoderKLCogVideoX.blend_v / blend_h of the spatial-tiling path (`enable_tiling`, ref :644-645): in-place linear
+ * cross-fade of the first `extent` rows (axis 0) / columns (axis 1) of tile b with the last ones of its neighbour a;
+ * channels-last tiles [T,H,W,ld], ld multiple of 4. */
+int dove_blend_edge_bf16(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb, int ld, int extent, int axis,
+                         void* stream);
 /* M = 1 linear with optional SiLU on the input (time_embedding MLP, norm*.linear modulation vectors) */
 int dove_gemv_bf16(const void* W, const float* bias, const float* x, int in_features, int out_features, int act_in,
                    float* y, void* stream);

@@ -155,9 +155,75 @@ class OracleVAE:
         h = F.silu(self.spatial_norm(h, z, "decoder.norm_out"))
         return self.causal_conv(h, "decoder.conv_out", cache)
 
+    # ---- diffusers spatial tiling (enable_tiling; reference runs it via --is_vae_st, ref :643-645) ----
+    def tiling_params(self):
+        sh, sw = self.cfg.get("sample_height", 480), self.cfg.get("sample_width", 720)
+        down = 2 ** (len(self.boc) - 1)
+        p = dict(smin_h=sh // 2, smin_w=sw // 2, of_h=1 / 6, of_w=1 / 5)
+        p["lmin_h"], p["lmin_w"] = int(p["smin_h"] / down), int(p["smin_w"] / down)
+        return p
+
+    @staticmethod
+    def blend_v(a, b, extent):
+        extent = min(a.shape[3], b.shape[3], extent)
+        for y in range(extent):
+            b[:, :, :, y, :] = a[:, :, :, -extent + y, :] * (1 - y / extent) + b[:, :, :, y, :] * (y / extent)
+        return b
+
+    @staticmethod
+    def blend_h(a, b, extent):
+        extent = min(a.shape[4], b.shape[4], extent)
+        for x in range(extent):
+            b[:, :, :, :, x] = a[:, :, :, :, -extent + x] * (1 - x / extent) + b[:, :, :, :, x] * (x / extent)
+        return b
+
+    def _tiled(self, x, tile_h, tile_w, stride_h, stride_w, blend_h, blend_w, lim_h, lim_w, batch, fn):
+        """Shared tile loop of diffusers tiled_encode / tiled_decode: every tile runs the full frame-batched network with
+        its own conv caches; tiles are blended IN PLACE with their already-blended upper / left neighbours, cropped
+        and concatenated."""
+        rows = []
+        for i in range(0, x.shape[3], stride_h):
+            row = []
+            for j in range(0, x.shape[4], stride_w):
+                cache, parts = {}, []
+                for s, e in frame_batches(x.shape[2], batch):
+                    parts.append(fn(x[:, :, s:e, i:i + tile_h, j:j + tile_w], cache))
+                row.append(torch.cat(parts, dim=2))
+            rows.append(row)
+        out_rows = []
+        for i, row in enumerate(rows):
+            out_row = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self.blend_v(rows[i - 1][j], tile, blend_h)
+                if j > 0:
+                    tile = self.blend_h(row[j - 1], tile, blend_w)
+                out_row.append(tile[:, :, :, :lim_h, :lim_w])
+            out_rows.append(torch.cat(out_row, dim=4))
+        return torch.cat(out_rows, dim=3)
+
     @torch.no_grad()
-    def encode(self, x):
+    def tiled_encode(self, x):
+        p = self.tiling_params()
+        st_h, st_w = int(p["smin_h"] * (1 - p["of_h"])), int(p["smin_w"] * (1 - p["of_w"]))
+        bl_h, bl_w = int(p["lmin_h"] * p["of_h"]), int(p["lmin_w"] * p["of_w"])
+        return self._tiled(x.to(self.dtype), p["smin_h"], p["smin_w"], st_h, st_w, bl_h, bl_w, p["lmin_h"] - bl_h,
+                           p["lmin_w"] - bl_w, self.enc_batch, self.encoder)
+
+    @torch.no_grad()
+    def tiled_decode(self, z):
+        p = self.tiling_params()
+        st_h, st_w = int(p["lmin_h"] * (1 - p["of_h"])), int(p["lmin_w"] * (1 - p["of_w"]))
+        bl_h, bl_w = int(p["smin_h"] * p["of_h"]), int(p["smin_w"] * p["of_w"])
+        return self._tiled(z.to(self.dtype), p["lmin_h"], p["lmin_w"], st_h, st_w, bl_h, bl_w, p["smin_h"] - bl_h,
+                           p["smin_w"] - bl_w, self.dec_batch, self.decoder)
+
+    @torch.no_grad()
+    def encode(self, x, tiling=False):
         """[B,3,F,H,W] -> posterior parameters [B, 2*latent, T, H/8, W/8] (mean || logvar)."""
+        p = self.tiling_params()
+        if tiling and (x.shape[-1] > p["smin_w"] or x.shape[-2] > p["smin_h"]):
+            return self.tiled_encode(x)
         x = x.to(self.dtype)
         cache, outs = {}, []
         for s, e in frame_batches(x.shape[2], self.enc_batch):
@@ -172,8 +238,11 @@ class OracleVAE:
         return mean + torch.exp(0.5 * logvar) * noise.to(mean.dtype)
 
     @torch.no_grad()
-    def decode(self, z):
+    def decode(self, z, tiling=False):
         """[B,latent,T,h,w] (already divided by scaling_factor) -> [B,3,F,H,W]."""
+        p = self.tiling_params()
+        if tiling and (z.shape[-1] > p["lmin_w"] or z.shape[-2] > p["lmin_h"]):
+            return self.tiled_decode(z)
         z = z.to(self.dtype)
         cache, outs = {}, []
         for s, e in frame_batches(z.shape[2], self.dec_batch):

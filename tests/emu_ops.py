@@ -200,7 +200,19 @@ def gemv(W, bias, x, act_in=0):
     return y + bias.float() if bias is not None else y
 
 
-ALL = ["conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+def blend_edge(a, b, extent, axis):
+    af, bf = a.float(), b.float()
+    for e in range(extent):
+        wb = e / extent
+        if axis == 0:
+            bf[:, e] = af[:, a.shape[1] - extent + e] * (1 - wb) + bf[:, e] * wb
+        else:
+            bf[:, :, e] = af[:, :, a.shape[2] - extent + e] * (1 - wb) + bf[:, :, e] * wb
+    b.copy_(bf.to(BF))
+    return b
+
+
+ALL = ["blend_edge", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

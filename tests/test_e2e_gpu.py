@@ -95,3 +95,25 @@ def test_stage_parity(setup):
     rel = float((d - d_ref).abs().max() / d_ref.abs().max())
     print(f"[stage] decode rel-max-err {rel:.4f}")
     assert rel < 0.05
+
+
+def test_vae_tiling_gpu(golden_dir):
+    """--is_vae_st path (enable_tiling): HIP tiled encode/decode vs the oracle's restatement of diffusers' tiling."""
+    v, t, s = config.small_configs(num_layers=1)
+    v["sample_height"], v["sample_width"] = 96, 160            # tiles 48x80 px so a 9x120x192 clip needs 3x3 tiles
+    seed = 23
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=seed, device="cuda")
+    ov = OracleVAE(v, weights.random_state_dict(weights.vae_param_shapes(v), seed))
+    video = synth_clip(9, 120, 192, seed=5)
+    pipe.vae.enable_tiling()
+    p = pipe.vae.encode(video.cuda().to(torch.bfloat16)).latent_dist.parameters.float().cpu()
+    p_ref = ov.encode(video, tiling=True)
+    rel = float((p - p_ref).abs().max() / p_ref.abs().max())
+    print(f"[tiling] encode rel-max-err {rel:.4f}")
+    assert p.shape == p_ref.shape and rel < 0.05
+    z = torch.randn(1, 16, 3, 15, 24, generator=torch.Generator().manual_seed(2))
+    d = pipe.vae.decode(z.cuda().to(torch.bfloat16)).sample.float().cpu()
+    d_ref = ov.decode(z, tiling=True)
+    rel = float((d - d_ref).abs().max() / d_ref.abs().max())
+    print(f"[tiling] decode rel-max-err {rel:.4f}")
+    assert d.shape == d_ref.shape and rel < 0.05

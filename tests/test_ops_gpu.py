@@ -257,6 +257,16 @@ def test_layout_and_glue():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("ld,axis", [(32, 0), (32, 1), (4, 0), (4, 1)])
+def test_blend_edge(ld, axis):
+    a, b = rnd(3, 9, 11, ld, seed=30), rnd(3, 9, 11, ld, seed=31)
+    for extent in (0, 1, 5, 9):
+        ref = E.blend_edge(a.clone(), b.clone(), extent, axis)
+        got = ops.blend_edge(a.cuda(), b.clone().cuda(), extent, axis)
+        torch.cuda.synchronize()
+        close(f"blend_{ld}_{axis}_{extent}", got, ref)
+
+
 def test_invalid_arguments_raise():
     pc_c, pc_g = pack(64, 64, (3, 3, 3))
     with pytest.raises(RuntimeError, match="channels"):
