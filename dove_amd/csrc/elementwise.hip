@@ -263,3 +263,75 @@ extern "C" int dove_blend_edge_bf16(const void* a, void* b, int T, int Ha, int W
   DOVE_CHECK_LAUNCH("dove_blend_edge_bf16");
   return DOVE_OK;
 }
+
+// ---- script-level pre-processing (ref :192-235, :670-679): pad F to 8N+1 (repeat last frame), pad H,W to x16 with zeros
+//      (bottom/right), bilinear x`up` (align_corners=False, torch semantics), x/255*2-1, [F,H,W,3] u8 -> [3,F',H',W'] ----
+__global__ void preprocess_kernel(const uint8_t* __restrict__ src, int F0, int H0, int W0, int Fp, int Hp, int Wp, int up,
+                                  void* __restrict__ out, int odt) {
+  const int Ho = Hp * up, Wo = Wp * up;
+  const long long npix = (long long)Fp * Ho * Wo;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int ox = (int)(p % Wo);
+  const int oy = (int)((p / Wo) % Ho);
+  const int f = (int)(p / ((long long)Wo * Ho));
+  const int fs = f < F0 ? f : F0 - 1;
+  const float inv = 1.0f / (float)up;
+  float sy = ((float)oy + 0.5f) * inv - 0.5f, sx = ((float)ox + 0.5f) * inv - 0.5f;
+  sy = sy < 0.f ? 0.f : sy;
+  sx = sx < 0.f ? 0.f : sx;
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < Hp - 1 ? 1 : 0), x1 = x0 + (x0 < Wp - 1 ? 1 : 0);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const uint8_t* fr = src + (long long)fs * H0 * W0 * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto px = [&](int y, int x) -> float { return (y < H0 && x < W0) ? (float)fr[((long long)y * W0 + x) * 3 + c] : 0.f; };
+    const float top = px(y0, x0) * (1.f - lx) + px(y0, x1) * lx;
+    const float bot = px(y1, x0) * (1.f - lx) + px(y1, x1) * lx;
+    const float v = top * (1.f - ly) + bot * ly;
+    store_any(out, (long long)c * npix + p, odt, v / 255.0f * 2.0f - 1.0f);
+  }
+}
+
+extern "C" int dove_preprocess_u8(const void* frames, int F0, int H0, int W0, int pad_f, int pad_h, int pad_w, int upscale,
+                                   void* out, int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(frames && out, "preprocess: null pointer");
+  DOVE_CHECK_ARG(F0 > 0 && H0 > 0 && W0 > 0 && pad_f >= 0 && pad_h >= 0 && pad_w >= 0 && upscale >= 1, "preprocess: bad shape");
+  DOVE_CHECK_ARG(out_dtype == DOVE_F32 || out_dtype == DOVE_BF16, "preprocess: bad dtype %d", out_dtype);
+  const long long npix = (long long)(F0 + pad_f) * (H0 + pad_h) * upscale * (W0 + pad_w) * upscale;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)frames, F0, H0, W0, F0 + pad_f, H0 + pad_h, W0 + pad_w, upscale, out, out_dtype);
+  DOVE_CHECK_LAUNCH("dove_preprocess_u8");
+  return DOVE_OK;
+}
+
+// ---- post-processing (ref :238-246 crop, :124/143/168 uint8): [3,F,H,W] in [0,1] -> [Fo,Ho,Wo,3] u8 = trunc(clamp(x*255)) ----
+__global__ void postprocess_kernel(const void* __restrict__ vid, int dt, int F, int H, int W, int Fo, int Ho, int Wo,
+                                   uint8_t* __restrict__ out) {
+  const long long npix = (long long)Fo * Ho * Wo;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int x = (int)(p % Wo);
+  const int y = (int)((p / Wo) % Ho);
+  const int f = (int)(p / ((long long)Wo * Ho));
+  const long long plane = (long long)F * H * W;
+  const long long si = ((long long)f * H + y) * W + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = fminf(fmaxf(load_any(vid, c * plane + si, dt) * 255.0f, 0.f), 255.f);
+    out[p * 3 + c] = (uint8_t)v;
+  }
+}
+
+extern "C" int dove_postprocess_u8(const void* video, int dtype, int F, int H, int W, int Fo, int Ho, int Wo, void* out,
+                                    void* stream) {
+  DOVE_CHECK_ARG(video && out, "postprocess: null pointer");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "postprocess: bad dtype %d", dtype);
+  DOVE_CHECK_ARG(Fo > 0 && Ho > 0 && Wo > 0 && Fo <= F && Ho <= H && Wo <= W, "postprocess: crop must fit inside the video");
+  const long long npix = (long long)Fo * Ho * Wo;
+  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, video,
+                     dtype, F, H, W, Fo, Ho, Wo, (uint8_t*)out);
+  DOVE_CHECK_LAUNCH("dove_postprocess_u8");
+  return DOVE_OK;
+}

@@ -45,6 +45,8 @@ SIGNATURES = {
     "dove_unpatchify": [_VP, _LL, _I, _I, _I, _I, _I, _I, _VP, _I, _VP],
     "dove_gemv_bf16": [_VP, _VP, _VP, _I, _I, _I, _VP, _VP],
     "dove_blend_edge_bf16": [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP],
+    "dove_preprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _I, _VP],
+    "dove_postprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP],
 }
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)])}

@@ -278,3 +278,24 @@ def blend_edge(a: torch.Tensor, b: torch.Tensor, extent: int, axis: int) -> torc
     L.check(L.load().dove_blend_edge_bf16(L.ptr(a), L.ptr(b), b.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2],
                                           b.shape[3], extent, axis, L.stream_ptr()), "dove_blend_edge_bf16")
     return b
+
+
+def preprocess_u8(frames: torch.Tensor, pad_f: int, pad_h: int, pad_w: int, upscale: int, dtype) -> torch.Tensor:
+    """frames [F,H,W,3] uint8 -> [3, F+pad_f, (H+pad_h)*up, (W+pad_w)*up] dtype in [-1,1]."""
+    L.require_cuda(frames)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3
+    F0, H0, W0, _ = frames.shape
+    out = torch.empty(3, F0 + pad_f, (H0 + pad_h) * upscale, (W0 + pad_w) * upscale, dtype=dtype, device=frames.device)
+    L.check(L.load().dove_preprocess_u8(L.ptr(frames), F0, H0, W0, pad_f, pad_h, pad_w, upscale, L.ptr(out), L.dt_code(out),
+                                        L.stream_ptr()), "dove_preprocess_u8")
+    return out
+
+
+def postprocess_u8(video: torch.Tensor, Fo: int, Ho: int, Wo: int) -> torch.Tensor:
+    """video [3,F,H,W] in [0,1] -> [Fo,Ho,Wo,3] uint8 (crop + x255 + truncate)."""
+    L.require_cuda(video)
+    _, F, H, W = video.shape
+    out = torch.empty(Fo, Ho, Wo, 3, dtype=torch.uint8, device=video.device)
+    L.check(L.load().dove_postprocess_u8(L.ptr(video), L.dt_code(video), F, H, W, Fo, Ho, Wo, L.ptr(out), L.stream_ptr()),
+            "dove_postprocess_u8")
+    return out

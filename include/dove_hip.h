@@ -112,6 +112,14 @@ int dove_unpatchify(const void* tokens, long long ld, int T, int C, int H, int W
  * channels-last tiles [T,H,W,ld], ld multiple of 4. */
 int dove_blend_edge_bf16(const void* a, void* b, int T, int Ha, int Wa, int Hb, int Wb, int ld, int extent, int axis,
                          void* stream);
+/* Script-level pre/post-processing of /root/reference/inference_script.py on the GPU:
+ * preprocess: frames [F0,H0,W0,3] u8 -> [3, F0+pad_f, (H0+pad_h)*up, (W0+pad_w)*up] in [-1,1]: pad F by repeating the last frame,
+ *   pad H/W with zeros bottom/right (ref :220-232), bilinear x`up` with align_corners=False (ref :672), x/255*2-1 (ref :674).
+ * postprocess: video [3,F,H,W] in [0,1] -> frames [Fo,Ho,Wo,3] u8 = trunc(clamp(x*255,0,255)), cropping the padding
+ *   (ref :238-246, :124). */
+int dove_preprocess_u8(const void* frames, int F0, int H0, int W0, int pad_f, int pad_h, int pad_w, int upscale, void* out,
+                       int out_dtype, void* stream);
+int dove_postprocess_u8(const void* video, int dtype, int F, int H, int W, int Fo, int Ho, int Wo, void* out, void* stream);
 /* M = 1 linear with optional SiLU on the input (time_embedding MLP, norm*.linear modulation vectors) */
 int dove_gemv_bf16(const void* W, const float* bias, const float* x, int in_features, int out_features, int act_in,
                    float* y, void* stream);

@@ -212,7 +212,23 @@ def blend_edge(a, b, extent, axis):
     return b
 
 
-ALL = ["blend_edge", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+def preprocess_u8(frames, pad_f, pad_h, pad_w, upscale, dtype):
+    """The reference's own torch code path (ref :220-232, :672-679) restated."""
+    f = frames
+    if pad_f:
+        f = torch.cat([f, f[-1:].repeat(pad_f, 1, 1, 1)], dim=0)
+    f = F.pad(f, (0, 0, 0, pad_w, 0, pad_h))
+    v = f.float().permute(0, 3, 1, 2)
+    v = F.interpolate(v, size=(v.shape[2] * upscale, v.shape[3] * upscale), mode="bilinear", align_corners=False)
+    return (v / 255.0 * 2.0 - 1.0).permute(1, 0, 2, 3).contiguous().to(dtype)
+
+
+def postprocess_u8(video, Fo, Ho, Wo):
+    v = video[:, :Fo, :Ho, :Wo].permute(1, 2, 3, 0)
+    return (v.float() * 255).clamp(0, 255).to(torch.uint8).contiguous()
+
+
+ALL = ["blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

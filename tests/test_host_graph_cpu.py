@@ -156,3 +156,29 @@ def test_vae_tiling_vs_oracle(monkeypatch):
     # below the tile threshold the tiled flag is a no-op, like diffusers
     small = torch.randn(1, 3, 5, 48, 80).clamp(-1, 1)
     assert rel(pipe.vae.encode(small.to(torch.bfloat16)).latent_dist.parameters, ov.encode(small)) < 0.06
+
+
+def test_prepost_roundtrip_cpu(monkeypatch, tmp_path):
+    """preprocess_frames / postprocess_frames / frame I/O glue (emulated ops): shapes, pads, the reference's x4 crop quirk."""
+    emu_ops.install(monkeypatch)
+    from dove_amd import prepost
+    import numpy as np
+    g = torch.Generator().manual_seed(1)
+    frames = torch.randint(0, 256, (8, 45, 80, 3), generator=g, dtype=torch.uint8)
+    np.save(tmp_path / "clip.npy", frames.numpy())
+    loaded = prepost.load_frames(str(tmp_path / "clip.npy"))
+    assert torch.equal(loaded, frames)
+    video, pf, ph, pw, orig = prepost.preprocess_frames(loaded, upscale=4, dtype=torch.float32, device="cpu")
+    assert (pf, ph, pw) == (1, 3, 0) and orig == (8, 45, 80, 3)
+    assert video.shape == (1, 3, 9, 192, 320) and float(video.min()) >= -1 and float(video.max()) <= 1
+    out = prepost.postprocess_frames((video * 0.5 + 0.5), pf, ph, pw)
+    assert out.shape == (8, 180, 320, 3) and out.dtype == torch.uint8
+    # identity check at the LR sample positions is not exact (bilinear), but constant frames must survive exactly
+    const = torch.full((3, 16, 16, 3), 200, dtype=torch.uint8)
+    v, a, b, c, _ = prepost.preprocess_frames(const, upscale=2, dtype=torch.float32, device="cpu")
+    back = prepost.postprocess_frames(v * 0.5 + 0.5, a, b, c, crop_scale=2)
+    assert back.shape == (3, 32, 32, 3) and int(back.float().mean().round()) in (199, 200)
+    prepost.save_frames_as_png(back, str(tmp_path / "png"))
+    assert torch.equal(prepost.load_frames(str(tmp_path / "png")), back)
+    with pytest.raises(ValueError, match="H.264"):
+        prepost.load_frames("clip.mp4")

@@ -267,6 +267,26 @@ def test_blend_edge(ld, axis):
         close(f"blend_{ld}_{axis}_{extent}", got, ref)
 
 
+@pytest.mark.parametrize("F,H,W,up", [(8, 45, 80, 4), (9, 48, 64, 4), (3, 30, 50, 1), (5, 20, 24, 2)])
+def test_pre_post_processing(F, H, W, up):
+    from dove_amd import tiling
+    g = torch.Generator().manual_seed(40)
+    frames = torch.randint(0, 256, (F, H, W, 3), generator=g, dtype=torch.uint8)
+    pf, ph, pw = tiling.match_padding(F, H, W)
+    for dt in (torch.float32, BF):
+        ref = E.preprocess_u8(frames, pf, ph, pw, up, dt)
+        got = ops.preprocess_u8(frames.cuda(), pf, ph, pw, up, dt)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape == (3, F + pf, (H + ph) * up, (W + pw) * up)
+        tol = 2e-5 if dt == torch.float32 else 8e-3
+        assert float((got.float().cpu() - ref.float()).abs().max()) <= tol
+    vid = torch.rand(3, F + pf, (H + ph) * up, (W + pw) * up, generator=g) * 1.2 - 0.1
+    Fo, Ho, Wo = F, H * up, W * up
+    ref = E.postprocess_u8(vid, Fo, Ho, Wo)
+    got = ops.postprocess_u8(vid.cuda(), Fo, Ho, Wo).cpu()
+    assert torch.equal(got, ref)                       # uint8: bit-exact
+
+
 def test_invalid_arguments_raise():
     pc_c, pc_g = pack(64, 64, (3, 3, 3))
     with pytest.raises(RuntimeError, match="channels"):
