@@ -146,23 +146,30 @@ def main():
         macs = flops.clip_macs(v, t, args.frames, args.height, args.width)
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps * args.frames / elapsed
-        # dominant kernel: igemm conv/linear.  achieved = sum(algorithmic flops) / sum(launch durations) over the timed region
-        tot_fl = sum(r[1] for r in records)
-        tot_ms = sum(r[2].elapsed_time(r[3]) for r in records)
+        # dominant kernel = conv3x3_halo8_kernel (VAE 3x3x3 convs, ~52 % of the step).  achieved = sum(algorithmic FLOP)
+        # / sum(launch duration) over ITS launches inside the timed region (HIP events on the launch stream).
+        def agg(recs):
+            fl = sum(r[1] for r in recs)
+            ms = sum(r[2].elapsed_time(r[3]) for r in recs)
+            return fl, ms
+        dom = [r for r in records if r[4] == "conv3x3_halo8_kernel"]
+        dom_fl, dom_ms = agg(dom)
+        tot_fl, tot_ms = agg(records)
         by = {}
-        for key, fl, e0, e1 in records:
-            k = f"cin{key[0]}_cout{key[1]}_taps{key[2]}"
+        for key, fl, e0, e1, var in records:
+            k = f"{var}:cin{key[0]}_cout{key[1]}_taps{key[2]}"
             a = by.setdefault(k, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1)
             a[2] += 1
         top = sorted(by.items(), key=lambda kv: -kv[1][1])[:8]
-        achieved = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        all_igemm = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("igemm_hbm_bytes_per_launch")
+                traffic = json.load(f).get("halo8_hbm_bytes_per_launch")
         res = {
             "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -172,11 +179,13 @@ def main():
                        "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15},
             "frames_per_s_per_gpu": value / world,
             "whole_path_tflops_per_gpu": macs["flop"] * args.steps / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv3d/conv2d/linear, bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_halo8_kernel (LDS-halo implicit-GEMM 3x3x3 conv, bf16 MFMA 32x32x16)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": traffic, "launches": len(records), "avg_launch_ms": tot_ms / max(len(records), 1),
-                         "avg_launch_gflop": tot_fl / max(len(records), 1) / 1e9,
-                         "share_of_step_time": tot_ms / (elapsed * 1e3),
+                         "traffic": traffic, "launches": len(dom) // max(args.steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
+                         "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
+                         "share_of_step_time": dom_ms / (elapsed * 1e3),
+                         "all_igemm_kernels": {"achieved": all_igemm, "frac": all_igemm / MFMA_BF16_PEAK_TFLOPS,
+                                               "share_of_step_time": tot_ms / (elapsed * 1e3), "launches": len(records) // max(args.steps, 1)},
                          "top_classes": {k: {"ms": a[1] / args.steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // args.steps}
                                          for k, a in top}},
             "model_build_s": t_build,

@@ -62,6 +62,21 @@ def set_profiler(records: list | None):
     _profiler = records
 
 
+def kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, in_thw) -> str:
+    """Which kernel dove_conv_igemm_bf16 dispatches to (mirror of the host rule in csrc/igemm.hip; reporting only)."""
+    T, H, W = in_thw
+    m = t_out * hw_out[0] * hw_out[1]
+    if (pc.kt == pc.kh == pc.kw == 1 and stride == 1 and up == 0 and tmode == 0 and pc.cout_pad % 128 == 0 and m >= 4096
+            and (T, H, W) == (t_out, hw_out[0], hw_out[1])):
+        tiles = -(-m // 512) * (pc.cout_pad // 128)
+        if tiles >= 1024 or pc.cin_pad <= 4096:
+            return "gemm8_kernel"
+    if (pc.kh == 3 and pc.kw == 3 and stride == 1 and up == 0 and ph == 1 and pw == 1 and tmode == 0 and act == 0 and gate is None
+            and pc.cout_pad % 128 == 0 and hw_out == (H, W) and W >= 16):
+        return "conv3x3_halo8_kernel" if H >= 16 else "conv3x3_halo_kernel"
+    return "igemm_fast_kernel" if up == 0 else "igemm_kernel"
+
+
 def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
@@ -112,7 +127,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if _profiler is not None:
         e1.record()
         flops = 2.0 * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
-        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1))
+        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1,
+                          kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, (T, H, W))))
     return out
 
 
