@@ -731,8 +731,13 @@ constexpr int B_RING = 4;                                                       
 constexpr int LDS_BYTES = 2 * A_BYTES + B_RING * B_BYTES;                             // 131072
 }  // namespace halo8
 
-template <bool TIMING>
+// UP = true: the conv reads a nearest-x2 upsampled input (Upsample3D, kt == 1): the halo is the (16/2+2) x (32/2+2) INPUT
+// patch, output pixel (oh, ow) tap (dh, dw) reads input ((oh+dh-1)>>1, (ow+dw-1)>>1); per-lane column bases for the three
+// dw values + compile-time row immediates keep the fragment reads VALU-free; lanes 2k, 2k+1 read the same row (broadcast).
+template <bool kTiming, bool kUp>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a) {
+  constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;     // 18 x 10 input halo when kUp
+  constexpr int NROUNDS = kUp ? (UHW * UHH * 5 + 511) / 512 : halo8::A_ROUNDS;
   using namespace halo8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -760,14 +765,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   const int n0 = tn * BN;
   const int oh0 = thi * TH, ow0 = twi * TW;
 
-  unsigned voffA[A_ROUNDS];
+  unsigned voffA[halo8::A_ROUNDS];          // (kUp uses only the first NROUNDS entries)
 #pragma unroll
-  for (int r = 0; r < A_ROUNDS; ++r) {
+  for (int r = 0; r < halo8::A_ROUNDS; ++r) {
     const int s = r * 512 + tid;
     const int px = s / 5, c = s - px * 5;            // padded rows: 5 slots per pixel, slot 4 is padding
-    const int hh = px / HWID, hw = px - hh * HWID;
-    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
-    const bool ok = (px < HPIX) && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+    int ih, iw;
+    bool inb;
+    if (kUp) {
+      const int hh = px / UHW, hw = px - hh * UHW;
+      ih = (oh0 >> 1) - 1 + hh; iw = (ow0 >> 1) - 1 + hw;
+      inb = px < UHW * UHH;
+    } else {
+      const int hh = px / HWID, hw = px - hh * HWID;
+      ih = oh0 - 1 + hh; iw = ow0 - 1 + hw;
+      inb = px < HPIX;
+    }
+    const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
     voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
   }
   unsigned voffB;
@@ -791,7 +805,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
       if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
       return a.x;
     }
-    return a.x + (long long)t * frame_elems;
+    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
+    return a.x + (long long)tin * frame_elems;
   };
 
   int h_dt = 0, h_kc = 0;
@@ -844,11 +859,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   // ---- prologue: halo of group 0, weight tiles of steps 0 and 1 ----
   stage_halo_round(std::integral_constant<int, 0>{}, 0);
   stage_halo_round(std::integral_constant<int, 1>{}, 0);
-  stage_halo_round(std::integral_constant<int, 2>{}, 0);
-  stage_halo_round(std::integral_constant<int, 3>{}, 0);
-  stage_halo_round(std::integral_constant<int, 4>{}, 0);
-  stage_halo_round(std::integral_constant<int, 5>{}, 0);
-  static_assert(A_ROUNDS == 6, "prologue is written for 6 halo rounds");
+  if (!kUp) {   // plain `if`: a dependent `if constexpr` inside these nested generic lambdas makes hipcc silently drop the host stub
+    stage_halo_round(std::integral_constant<int, 2>{}, 0);
+    stage_halo_round(std::integral_constant<int, 3>{}, 0);
+    stage_halo_round(std::integral_constant<int, 4>{}, 0);
+    stage_halo_round(std::integral_constant<int, 5>{}, 0);
+  }
+  static_assert(halo8::A_ROUNDS == 6 && (!kUp || NROUNDS == 2), "prologue is written for 6 (2 when kUp) halo rounds");
   if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
   stage_b();
   if (nk > 1) stage_b();
@@ -859,18 +876,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   if ((a.debug & 32) && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger group
 
   const int abase0 = ((8 * grp + 4 * wm) * HWID + l31) * APITCH + hi * 16;   // byte address of (tile row 4wm, col l31), chunk hi
+  // kUp: input halo row of output row (8grp+4wm+p) tap dh = 4grp + 2wm + 1 + ((p+dh-1)>>1); the "-1" case is folded into
+  // the base (one row lower) so every immediate is >= 0.  Column of lane l31 tap dw = 1 + ((l31+dw-1)>>1).
+  int abaseU[3];
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw)
+    abaseU[dw] = ((4 * grp + 2 * wm) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
 
-  // TIMING build only: lane 0 of waves 0 and 4 of one workgroup logs s_memtime at 5 points of steps 18..53
+  // kTiming build only: lane 0 of waves 0 and 4 of one workgroup logs s_memtime at 5 points of steps 18..53
   unsigned long long* tlog = nullptr;
-  if (TIMING && blockIdx.x == 4001 && (wave & 3) == 0 && lane == 0) tlog = (unsigned long long*)a.gate + (wave >> 2) * 36 * 5;
+  if (kTiming && blockIdx.x == 4001 && (wave & 3) == 0 && lane == 0) tlog = (unsigned long long*)a.gate + (wave >> 2) * 36 * 5;
   int tstep = 0;
   int rd_slot = 0, issued_prev = 0;        // ring slot read by the current step; loads issued in the previous step
   auto stamp = [&](int k) {
-    if (TIMING && tlog && tstep >= 18 && tstep < 54) tlog[(tstep - 18) * 5 + k] = __builtin_readcyclecounter();
+    if (kTiming && tlog && tstep >= 18 && tstep < 54) tlog[(tstep - 18) * 5 + k] = __builtin_readcyclecounter();
   };
 
   auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
     constexpr int tap = decltype(tapc)::value;
+    const int gbuf = (g & 1) * A_BYTES;
     constexpr int dh = tap / 3, dw = tap % 3;
     stamp(0);
     // ---------------- phase 1: staging for step s+2, fragment reads for step s ----------------
@@ -878,14 +902,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
     // halo rounds of the next group at taps 0..4.
     int issued = 0;                                    // loads this wave issues in this phase (wave-uniform)
     if (tap < 6 || more_groups) { stage_b(); ++issued; }
-    if constexpr (tap < A_ROUNDS) {
+    if (tap < NROUNDS) {
       if (more_groups) { stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1); ++issued; }
     }
     bf16x8 xf[2][4], wf[2][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      xf[0][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH);        // immediate offsets only
-      xf[1][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH + 32);
+      if (kUp) {
+        const int rowimm = (((p + dh + 1) >> 1)) * UHW * APITCH;          // ((p+dh-1)>>1) + 1 rows above the folded base (immediate after unrolling)
+        xf[0][p] = *(const bf16x8*)(smem + abaseU[dw] + gbuf + rowimm);
+        xf[1][p] = *(const bf16x8*)(smem + abaseU[dw] + gbuf + rowimm + 32);
+      } else {
+        xf[0][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH);        // immediate offsets only
+        xf[1][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH + 32);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -1267,11 +1297,31 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     }
     static int halo8 = -1;
     if (halo8 < 0) { const char* e = getenv("DOVE_CONV_HALO8"); halo8 = (e && e[0] == '0') ? 0 : 1; }
+    const bool halo_up_ok = d->kt == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+                            d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in &&
+                            d->h_out >= 16 && d->w_out >= 32 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) && !no_halo &&
+                            !(a.debug & 7);
+    if (halo_up_ok && halo8) {
+      static bool attru = false;
+      if (!attru) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        attru = true;
+      }
+      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
+      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long gu = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(gu > 0 && gu < (1ll << 31), "conv_igemm: grid too large");
+      hipLaunchKernelGGL((conv3x3_halo8_kernel<false, true>), dim3((unsigned)gu), dim3(512), halo8::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8 up)");
+      return DOVE_OK;
+    }
     if (halo_ok && halo8 && d->h_out >= 16) {
       static bool attr8 = false;
       if (!attr8) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
         attr8 = true;
       }
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
@@ -1281,10 +1331,10 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
       if (d->debug_buf) {   // timing build: per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
         a.gate = (const float*)d->debug_buf;
-        hipLaunchKernelGGL(conv3x3_halo8_kernel<true>, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
         a.gate = nullptr;
       } else
-      hipLaunchKernelGGL(conv3x3_halo8_kernel<false>, dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      hipLaunchKernelGGL((conv3x3_halo8_kernel<false, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
       return DOVE_OK;
     }

@@ -70,6 +70,10 @@ CONV_CASES = [
     # 8-wave ping-pong halo kernel (H >= 16): 3 x 3 tiles of 16x32 with ragged edges, 2 cout tiles
     ("c3d_halo8_tiles", 64, 256, (3, 3, 3), 2, 40, 70, {"cache": True, "resid": True}),
     ("c3d_halo8_512", 512, 128, (3, 3, 3), 1, 16, 32, {}),
+    # upsample-fused conv on the ping-pong halo kernel (UP variant): ragged tiles, both temporal maps
+    ("c2d_up8", 128, 128, (3, 3), 2, 20, 40, {"up": 1, "pad": (1, 1)}),
+    ("c2d_up8_t2", 64, 256, (3, 3), 3, 9, 17, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
+    ("c2d_up8_t1", 256, 128, (3, 3), 2, 16, 16, {"up": 1, "pad": (1, 1), "tmode": 1, "t_out": 4}),
 ]
 
 
