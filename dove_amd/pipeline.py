@@ -79,10 +79,51 @@ class CogVideoXPipeline:
 
     enable_model_cpu_offload = enable_sequential_cpu_offload
 
-    def load_lora_weights(self, *a, **k):
-        raise NotImplementedError("LoRA fuse is a SURVEY 8(f) follow-up (DOVE's released checkpoint is full-SFT)")
+    def load_lora_weights(self, path, weight_name="pytorch_lora_weights.safetensors", adapter_name=None, **kw):
+        """Read a diffusers/peft LoRA file (ref :616-620): keys ``transformer.<module>.lora_A.weight`` [r, in] and
+        ``.lora_B.weight`` [out, r] on the attention projections (DOVE's targets: to_q, to_k, to_v, to_out.0;
+        /root/reference/finetune/schemas/args.py:71-73).  The adapter is kept on the host until ``fuse_lora``."""
+        import json as _json
 
-    fuse_lora = load_lora_weights
+        from safetensors import safe_open
+        fn = os.path.join(path, weight_name) if os.path.isdir(path) else path
+        sd, meta = {}, {}
+        with safe_open(fn, framework="pt") as f:
+            meta = f.metadata() or {}
+            for k in f.keys():
+                sd[k] = f.get_tensor(k)
+        alpha = rank = None
+        if "lora_adapter_metadata" in meta:      # newer diffusers store the peft config next to the tensors
+            cfg = _json.loads(meta["lora_adapter_metadata"])
+            cfg = cfg.get("transformer", cfg)
+            alpha, rank = cfg.get("lora_alpha"), cfg.get("r")
+        self._lora = dict(state=sd, alpha=alpha, rank=rank, name=adapter_name)
+
+    def fuse_lora(self, components=("transformer",), lora_scale: float = 1.0, **kw):
+        """W += lora_scale * (alpha / r) * B @ A on every adapted Linear of the transformer (ref :621), then drop the
+        adapter.  Without stored alpha the peft default alpha == r (scale 1) is assumed, like diffusers."""
+        if getattr(self, "_lora", None) is None:
+            raise RuntimeError("fuse_lora() called before load_lora_weights()")
+        if "transformer" not in components:
+            return
+        lo = self._lora
+        pairs = {}
+        for k, v in lo["state"].items():
+            k2 = k[len("transformer."):] if k.startswith("transformer.") else k
+            for tag in (".lora_A.weight", ".lora_B.weight", ".lora.down.weight", ".lora.up.weight"):
+                if k2.endswith(tag):
+                    which = "A" if ("lora_A" in tag or "down" in tag) else "B"
+                    pairs.setdefault(k2[: -len(tag)], {})[which] = v
+        if not pairs:
+            raise RuntimeError("no lora_A / lora_B tensors found in the adapter file")
+        for mod, ab in pairs.items():
+            if "A" not in ab or "B" not in ab:
+                raise RuntimeError(f"incomplete LoRA pair for {mod}")
+            r = ab["A"].shape[0]
+            scale = lora_scale * ((lo["alpha"] / (lo["rank"] or r)) if lo["alpha"] is not None else 1.0)
+            self.transformer.add_weight_delta(mod, ab["B"].float() @ ab["A"].float(), scale)
+        self.transformer._mod_cache = {}
+        self._lora = None
 
     @torch.no_grad()
     def decode_latents(self, latents: torch.Tensor, _range01: bool = False) -> torch.Tensor:

@@ -83,6 +83,24 @@ class CogVideoXTransformer3DModel:
         self.norm_out = (f32("norm_out.norm.weight"), f32("norm_out.norm.bias"))
         self.proj_out = lin("proj_out")
 
+    def add_weight_delta(self, module: str, delta: torch.Tensor, scale: float):
+        """In-place ``W += scale * delta`` on a packed Linear (LoRA fuse).  ``module`` is the diffusers module path, e.g.
+        ``transformer_blocks.3.attn1.to_q``; q/k/v live in the fused QKV weight."""
+        import re
+        m = re.fullmatch(r"transformer_blocks\.(\d+)\.attn1\.(to_q|to_k|to_v|to_out\.0)", module)
+        if not m:
+            raise NotImplementedError(f"LoRA on {module} is not supported (DOVE adapts to_q/to_k/to_v/to_out.0 only)")
+        blk = self.blocks[int(m.group(1))]
+        D = self.D
+        if m.group(2) == "to_out.0":
+            pc, row0 = blk["out"], 0
+        else:
+            pc, row0 = blk["qkv"], {"to_q": 0, "to_k": D, "to_v": 2 * D}[m.group(2)]
+        if tuple(delta.shape) != (D, D):
+            raise RuntimeError(f"LoRA delta for {module} has shape {tuple(delta.shape)}, expected {(D, D)}")
+        w = pc.w[0, row0:row0 + D, :D]
+        w.copy_((w.float() + scale * delta.to(w.device, torch.float32)).to(torch.bfloat16))
+
     # ---- timestep-dependent constants ----------------------------------------------------------------
     def _modulation(self, t: int):
         """emb = time_embedding(sinusoid(t)); per block the six AdaLN-Zero chunks (shift, scale, gate, enc_shift,

@@ -182,3 +182,78 @@ def test_prepost_roundtrip_cpu(monkeypatch, tmp_path):
     assert torch.equal(prepost.load_frames(str(tmp_path / "png")), back)
     with pytest.raises(ValueError, match="H.264"):
         prepost.load_frames("clip.mp4")
+
+
+def _write_checkpoint(root, v, t, s, wv, wt):
+    """A CogVideoX1.5/DOVE-style directory (finetune/scripts/prepare_sft_ckpt.py layout): vae single file, transformer
+    sharded with an index json (fp32 shards), scheduler config."""
+    import json
+    from safetensors.torch import save_file
+    for d in ("vae", "transformer", "scheduler"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    json.dump(v, open(os.path.join(root, "vae", "config.json"), "w"))
+    json.dump(t, open(os.path.join(root, "transformer", "config.json"), "w"))
+    json.dump(dict(s, _class_name="CogVideoXDPMScheduler"), open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    save_file({k: x.contiguous() for k, x in wv.items()}, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    keys = list(wt)
+    half = len(keys) // 2
+    shards = {"diffusion_pytorch_model-00001-of-00002.safetensors": keys[:half],
+              "diffusion_pytorch_model-00002-of-00002.safetensors": keys[half:]}
+    wmap = {}
+    for fn, ks in shards.items():
+        save_file({k: wt[k].contiguous() for k in ks}, os.path.join(root, "transformer", fn))
+        wmap.update({k: fn for k in ks})
+    json.dump({"metadata": {}, "weight_map": wmap}, open(os.path.join(root, "transformer", "diffusion_pytorch_model.safetensors.index.json"), "w"))
+
+
+def test_from_pretrained_and_lora_fuse(monkeypatch, tmp_path):
+    """Checkpoint loader (key/shape strict) + LoRA load/fuse (ref :613-621) on a synthetic checkpoint directory."""
+    emu_ops.install(monkeypatch)
+    from safetensors.torch import save_file
+    v, t, s = config.tiny_configs()
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), 31)
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), 31)
+    _write_checkpoint(str(tmp_path / "ckpt"), v, t, s, wv, wt)
+    pipe = CogVideoXPipeline.from_pretrained(str(tmp_path / "ckpt"), torch_dtype=torch.bfloat16, device="cpu")
+    ref = CogVideoXPipeline.from_config(v, t, s, seed=31, device="cpu")
+    assert torch.equal(pipe.transformer.blocks[1]["qkv"].w, ref.transformer.blocks[1]["qkv"].w)
+    assert torch.equal(pipe.vae.pc["decoder.conv_in"].w, ref.vae.pc["decoder.conv_in"].w)
+    assert abs(float(pipe.scheduler.alphas_cumprod[399]) - 0.3935440575) < 1e-6
+    # strictness: a checkpoint with a missing tensor or a wrong shape must fail loudly
+    import json
+    wt_bad = {k: x for k, x in wt.items() if k != "proj_out.bias"}
+    _write_checkpoint(str(tmp_path / "bad1"), v, t, s, wv, wt_bad)
+    with pytest.raises(RuntimeError, match="mismatch"):
+        weights.load_component(str(tmp_path / "bad1" / "transformer"), weights.dit_param_shapes)
+    wt_bad2 = dict(wt)
+    wt_bad2["proj_out.bias"] = torch.zeros(7)
+    _write_checkpoint(str(tmp_path / "bad2"), v, t, s, wv, wt_bad2)
+    with pytest.raises(RuntimeError, match="shape"):
+        weights.load_component(str(tmp_path / "bad2" / "transformer"), weights.dit_param_shapes)
+    # LoRA: rank-4 adapter on block 0 to_q and block 1 to_out.0, alpha/r = 0.5 stored in the metadata
+    D = t["num_attention_heads"] * t["attention_head_dim"]
+    g = torch.Generator().manual_seed(5)
+    lora = {}
+    for mod in ("transformer_blocks.0.attn1.to_q", "transformer_blocks.1.attn1.to_out.0"):
+        lora[f"transformer.{mod}.lora_A.weight"] = torch.randn(4, D, generator=g) * 0.1
+        lora[f"transformer.{mod}.lora_B.weight"] = torch.randn(D, 4, generator=g) * 0.1
+    os.makedirs(tmp_path / "lora")
+    save_file(lora, str(tmp_path / "lora" / "pytorch_lora_weights.safetensors"),
+              metadata={"lora_adapter_metadata": json.dumps({"r": 4, "lora_alpha": 2})})
+    pipe.load_lora_weights(str(tmp_path / "lora"), weight_name="pytorch_lora_weights.safetensors", adapter_name="test_1")
+    pipe.fuse_lora(components=["transformer"], lora_scale=1.0)
+    wt2 = dict(wt)
+    for mod in ("transformer_blocks.0.attn1.to_q", "transformer_blocks.1.attn1.to_out.0"):
+        wt2[mod + ".weight"] = wt[mod + ".weight"] + 0.5 * lora[f"transformer.{mod}.lora_B.weight"] @ lora[f"transformer.{mod}.lora_A.weight"]
+    torch.manual_seed(1)
+    hidden = torch.randn(1, 4, 16, 8, 12)
+    text = torch.randn(1, 226, t["text_embed_dim"])
+    rope = odit.rope_3d(64, 2, 4, 6)
+    ts = torch.tensor([399])
+    want = odit.OracleDiT(t, wt2).forward(hidden, text, ts, rope)
+    base = odit.OracleDiT(t, wt).forward(hidden, text, ts, rope)
+    got = pipe.transformer(hidden_states=hidden.to(torch.bfloat16), encoder_hidden_states=text.to(torch.bfloat16), timestep=ts,
+                           image_rotary_emb=rope, return_dict=False)[0]
+    assert rel(got, want) < 0.05 and rel(base, want) > 2 * rel(got, want)     # the adapter really changed the output
+    with pytest.raises(RuntimeError, match="before load_lora_weights"):
+        pipe.fuse_lora()
