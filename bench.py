@@ -91,9 +91,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run: one rank per GPU over RCCL
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
@@ -119,7 +121,7 @@ def main():
         return process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -135,7 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_profiler(None)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,7 +205,7 @@ def main():
             mse = ((got - sref) ** 2).flatten(3).mean(-1)
             res["psnr_vs_oracle_db"] = float((10 * torch.log10(1.0 / (mse + 1e-8))).mean())
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
