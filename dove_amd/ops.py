@@ -149,7 +149,8 @@ _gn_ws: dict = {}
 
 
 def _ws(device):
-    key = str(device)
+    # one scratch buffer per (device, stream): the two-stream VAE mode runs GroupNorm statistics concurrently
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
     if key not in _gn_ws:
         _gn_ws[key] = torch.empty(2048 * 64, dtype=torch.float32, device=device)
     return _gn_ws[key]

@@ -117,3 +117,17 @@ def test_vae_tiling_gpu(golden_dir):
     rel = float((d - d_ref).abs().max() / d_ref.abs().max())
     print(f"[tiling] decode rel-max-err {rel:.4f}")
     assert d.shape == d_ref.shape and rel < 0.05
+
+
+def test_two_stream_vae_is_bit_identical(setup):
+    """Alternate frame-batches on two HIP streams (per-conv events) must not change a single bit."""
+    pipe, (v, t, s), wv, wt, text = setup
+    video = synth_clip(17, 48, 80, seed=11).cuda().to(torch.bfloat16)
+    z = torch.randn(1, 16, 5, 6, 10, generator=torch.Generator().manual_seed(4)).cuda().to(torch.bfloat16)
+    outs = {}
+    for n in (1, 2):
+        pipe.vae.n_streams = n
+        outs[n] = (pipe.vae.encode(video).latent_dist.parameters.clone(), pipe.vae.decode(z).sample.clone())
+        torch.cuda.synchronize()
+    pipe.vae.n_streams = 2
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
