@@ -1011,6 +1011,349 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
 }
 
 
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3_halo4x: the same 16 x 32 pixel x 128 channel workgroup tile and LDS image as conv3x3_halo8, but ONE wave per
+// SIMD owning the whole 512-entry register file (4 waves, 1 workgroup per CU).  The phase log of halo8 showed that the
+// memory phase of a wave is slowed ~2x whenever its SIMD partner streams MFMAs, and the partner's MFMA phase stretches
+// from 512 to ~680 cycles: two waves per SIMD fight for issue slots.  Here each wave computes 128 pixels x 128 channels
+// (16 accumulator tiles = 256 registers, 8 fragment reads per 16 MFMAs = 0.5 KB of LDS traffic per MFMA) and software-
+// pipelines its own fragments through registers: while the 16 MFMAs of k-half 0 run, the fragments of k-half 1 are read,
+// and while those run, k-half 0 of the NEXT step is read -- legal across the step barrier because the counted vmcnt drain
+// keeps every staged tile two steps ahead of its first reader.  One barrier per 32 MFMAs, no MFMA ever waits on LDS.
+// ------------------------------------------------------------------------------------------------
+template <int BR_, int BAHEAD_, int HPS_, int DS0_, bool TIMING_ = false>
+struct Halo4xCfg {
+  static constexpr bool TIMING = TIMING_;
+  static constexpr int BR = BR_, BAHEAD = BAHEAD_;
+  static constexpr int HPS = HPS_;                              // halo rounds staged per step
+  static constexpr int DS0 = DS0_;                              // first MFMA gap that carries a k-half-1 fragment read
+  static constexpr int LDS_BYTES = 2 * halo8::A_BYTES + BR * halo8::B_BYTES;
+  static constexpr int nh(int tap, int nr) { return (HPS * tap + HPS <= nr) ? HPS : ((HPS * tap < nr) ? nr - HPS * tap : 0); }
+  static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
+  static constexpr int inflight(int tap, int nr) {              // loads issued in the BAHEAD-2 steps before step `tap`
+    int n = 0;
+    for (int d = 1; d <= BAHEAD - 2; ++d) n += issued((tap + 9 - d) % 9, nr);
+    return n;
+  }
+};
+
+template <bool kUp, class CFG>
+__global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
+  using namespace halo8;
+  constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
+  constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
+  // weight ring: BR slots, staged BAHEAD steps ahead; loads of the last BAHEAD-2 steps may still be in flight at a step
+  // barrier (LDS-DMA issue -> landed is ~1.1 us under load, a step is ~0.5 us)
+  constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, HPS = CFG::HPS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const unsigned long long t_entry = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
+  const int t = rest % a.T_out; rest /= a.T_out;
+  const int twi = rest % a.tiles_w;
+  const int thi = rest / a.tiles_w;
+  const int n0 = tn * BN;
+  const int oh0 = thi * TH, ow0 = twi * TW;
+
+  unsigned voffA[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const int s = r * 256 + tid;
+    const int px = s / 5, c = s - px * 5;
+    int ih, iw;
+    bool inb;
+    if (kUp) {
+      const int hh = px / UHW, hw = px - hh * UHW;
+      ih = (oh0 >> 1) - 1 + hh; iw = (ow0 >> 1) - 1 + hw;
+      inb = px < UHW * UHH;
+    } else {
+      const int hh = px / HWID, hw = px - hh * HWID;
+      ih = oh0 - 1 + hh; iw = ow0 - 1 + hw;
+      inb = px < HPIX;
+    }
+    const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
+  }
+  unsigned voffB[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = j * 64 + (tid >> 2);
+    const int c = (tid & 3) ^ ((row >> 2) & 3);
+    voffB[j] = (unsigned)((row * a.Cin + c * 8) * 2);
+  }
+  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
+  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
+  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
+  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
+  const int kcn = a.Cin / BK;
+  const int ngroups = a.kt * kcn;
+
+  // branch-free (scalar selects): the whole post-barrier part of a step must stay ONE basic block so that the scheduler can
+  // interleave staging / fragment reads with the MFMAs
+  const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
+  auto frame_ptr0 = [&](int dt) -> const bf16_t* {
+    const int fv = t + dt - (a.kt - 1);
+    const bf16_t* causal = fv >= 0 ? a.x + fv * frame_elems : (a.cache ? a.cache + (a.kt - 1 + fv) * frame_elems : a.x);
+    return a.kt > 1 ? causal : a.x + (long long)tin * frame_elems;
+  };
+  // the (at most three) source frames of this tile, resolved once; per-round selection is two scalar selects
+  const bf16_t* const fp0 = frame_ptr0(0);
+  const bf16_t* const fp1 = a.kt > 1 ? frame_ptr0(1) : fp0;
+  const bf16_t* const fp2 = a.kt > 2 ? frame_ptr0(2) : fp0;
+  auto frame_ptr = [&](int dt) -> const bf16_t* { return dt == 0 ? fp0 : (dt == 1 ? fp1 : fp2); };
+
+  int h_dt = 0, h_kc = 0;
+  const bf16_t* h_fp = fp0;                 // frame of the group whose halo is being staged (updated once per group)
+  auto stage_halo_round = [&](auto rc, int buf, bool on) {     // `on` false: zero-length descriptor -> the load is a no-op write of zeros
+    constexpr int r = decltype(rc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)h_fp, (short)0, on ? (int)frame_bytes : 0, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
+                                             h_kc * ROWB, 0, 0);
+  };
+  int b_tap = 0, b_kc = 0, b_slot = 0;
+  const bf16_t* b_wp = a.w + (long long)n0 * a.Cin;            // running pointer to tap (dt*9 + tap) of this cout tile
+  const long long w_fwd = wtap_stride, w_back = -8 * (long long)wtap_stride;
+  auto stage_b = [&](bool on) {
+    const int buf = b_slot;
+    b_slot = (b_slot + 1 == BR) ? 0 : b_slot + 1;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, on ? (int)wtap_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
+                                               voffB[j], b_kc * ROWB, 0, 0);
+    const int nt = b_tap + 1;
+    const bool wrap = nt == 9;
+    b_tap = wrap ? 0 : nt;
+    const int nkc = b_kc + (wrap ? 1 : 0);
+    const bool wrap2 = nkc == kcn;
+    b_kc = wrap2 ? 0 : nkc;
+    // tap index dt*9+tap: +1 normally and when both wrap (next dt), -8 when only the tap wraps (same dt, next k chunk);
+    // never advanced past the tensor: after the last real tap the descriptor length is 0 anyway but keep the base mapped
+    b_wp += on ? ((wrap && !wrap2) ? w_back : w_fwd) : 0;
+  };
+
+  // weight fragment offsets: 4 cout tiles x 2 k-halves (slot 0), XOR-swizzled 64-B rows
+  int boff[4][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 32 + l31;
+      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
+    }
+  // activation fragment bases (padded 80-B halo rows -> base + immediate for every tap)
+  const int abase0 = ((4 * wave) * HWID + l31) * APITCH + hi * 16;
+  int abaseU[3];
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw) abaseU[dw] = ((2 * wave) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+  // epilogue-side lane role (16 lanes x 8 channels cover one pixel row): its bias is fetched now, under the halo prologue
+  const int e_px = lane >> 4, e_ch = lane & 15;
+  const int cb = n0 + e_ch * 8;
+  f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) { bias_lo = *(const f32x4*)(a.bias + cb); bias_hi = *(const f32x4*)(a.bias + cb + 4); }
+
+  // ---- prologue: whole first halo + weight tiles of steps 0, 1, 2 ----
+  {
+    stage_halo_round(std::integral_constant<int, 0>{}, 0, true); stage_halo_round(std::integral_constant<int, 1>{}, 0, true);
+    stage_halo_round(std::integral_constant<int, 2>{}, 0, true); stage_halo_round(std::integral_constant<int, 3>{}, 0, true);
+    if (!kUp) {
+      stage_halo_round(std::integral_constant<int, 4>{}, 0, true); stage_halo_round(std::integral_constant<int, 5>{}, 0, true);
+      stage_halo_round(std::integral_constant<int, 6>{}, 0, true); stage_halo_round(std::integral_constant<int, 7>{}, 0, true);
+      stage_halo_round(std::integral_constant<int, 8>{}, 0, true); stage_halo_round(std::integral_constant<int, 9>{}, 0, true);
+      stage_halo_round(std::integral_constant<int, 10>{}, 0, true); stage_halo_round(std::integral_constant<int, 11>{}, 0, true);
+    }
+  }
+  if (++h_kc == kcn) { h_kc = 0; ++h_dt; h_fp = frame_ptr(h_dt); }
+#pragma unroll
+  for (int i = 0; i < BAHEAD; ++i) stage_b(true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // fragment loaders (tap is a compile-time constant -> every address is base VGPR + immediate)
+  auto load_a = [&](auto tapc, auto kkc, int gb, bf16x8 (&xf)[4]) {
+    constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+    constexpr int dh = tap / 3, dw = tap % 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (kUp) {
+        const int rowimm = ((p + dh + 1) >> 1) * UHW * APITCH;
+        xf[p] = *(const bf16x8*)(smem + abaseU[dw] + gb + rowimm + kk * 32);
+      } else {
+        xf[p] = *(const bf16x8*)(smem + abase0 + gb + ((p + dh) * HWID + dw) * APITCH + kk * 32);
+      }
+    }
+  };
+  auto load_b = [&](auto kkc, int slot, bf16x8 (&wf)[4]) {
+    constexpr int kk = decltype(kkc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(smem + slot * B_BYTES + boff[i][kk]);
+  };
+  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+
+  int rd_slot = 0;
+  unsigned long long t_wait = 0, t_bar = 0;
+  const unsigned long long t_begin = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
+  bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
+  load_a(std::integral_constant<int, 0>{}, K0{}, 0, xa);
+  load_b(K0{}, 0, wa);
+
+  // one K-step = one spatial tap of one (frame tap, channel chunk) group; fragments of k-half 0 are already in xa/wa
+  auto step = [&](auto tapc, int g, int gb, bool more_groups, bool last_step) {
+    constexpr int tap = decltype(tapc)::value;
+    // drain loads issued two or more steps ago, then the step barrier (LDS hand-off point)
+    constexpr int NH = CFG::nh(tap, NR);                       // halo rounds staged in this step
+    constexpr int PEND = CFG::inflight(tap, NR);               // (issue counts are tap-periodic: loads are unconditional)
+    unsigned long long tq0 = 0, tq1 = 0;
+    if (CFG::TIMING) { tq0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
+    if (CFG::TIMING) { tq1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    __builtin_amdgcn_s_barrier();
+    if (CFG::TIMING) {
+      const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+      t_wait += tq1 - tq0;
+      t_bar += tq2 - tq1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- from here to the end of the step: ONE basic block (every load is issued unconditionally; a zero-length
+    //      descriptor turns the ones past the end of the K walk into harmless zero fills of unused slots) ----
+    const bool sb = (tap < 9 - BAHEAD) || more_groups;
+    stage_b(sb);
+    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, (g + 1) & 1, more_groups);
+    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, (g + 1) & 1, more_groups);
+    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? HPS * tap + 2 : 0)>{}, (g + 1) & 1, more_groups);
+    load_a(tapc, K1{}, gb, xb);
+    load_b(K1{}, rd_slot, wb);
+    mma(wa, xa);
+    const int nslot = (rd_slot + 1 == BR) ? 0 : rd_slot + 1;
+    constexpr int ntap = (tap + 1) % 9;
+    const int ngb = (tap == 8) ? (((g + 1) & 1) * A_BYTES) : gb;
+    load_a(std::integral_constant<int, ntap>{}, K0{}, ngb, xa);         // (after the last step this reads LDS nobody uses)
+    load_b(K0{}, nslot, wa);
+    mma(wb, xb);
+    rd_slot = nslot;
+    // pinned interleave: every MFMA gap carries a slice of the scalar staging work and (first half) one fragment read
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);                // 6 SALU
+      if (i < 2 + NH) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA)
+      if (i >= CFG::DS0 && i < CFG::DS0 + 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read (k-half 1 fragments)
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                // 1 VALU
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
+      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int g = 0; g < ngroups; ++g) {
+    const int gb = (g & 1) * A_BYTES;
+    const bool more = g + 1 < ngroups;
+    step(std::integral_constant<int, 0>{}, g, gb, more, false);
+    step(std::integral_constant<int, 1>{}, g, gb, more, false);
+    step(std::integral_constant<int, 2>{}, g, gb, more, false);
+    step(std::integral_constant<int, 3>{}, g, gb, more, false);
+    step(std::integral_constant<int, 4>{}, g, gb, more, false);
+    step(std::integral_constant<int, 5>{}, g, gb, more, false);
+    step(std::integral_constant<int, 6>{}, g, gb, more, false);
+    step(std::integral_constant<int, 7>{}, g, gb, more, false);
+    step(std::integral_constant<int, 8>{}, g, gb, more, !more);
+    if (++h_kc == kcn) { h_kc = 0; ++h_dt; h_fp = frame_ptr(h_dt); }
+  }
+
+  if (CFG::TIMING && a.gate && blockIdx.x == 4001 && lane == 0) {     // TIMING build: `gate` is the host's debug buffer
+    unsigned long long* o = (unsigned long long*)a.gate + wave * 4;
+    o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_wait; o[2] = t_bar; o[3] = (unsigned long long)ngroups * 9;
+    o[16 + wave] = t_begin - t_entry;                                    // prologue
+  }
+  const unsigned long long t_epi = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
+  // ---- epilogue: wave w owns tile rows 4w..4w+3 (128 pixels), all 128 channels.  The MFMA result layout (lane = pixel,
+  // 4 consecutive channels per register quad) would give 8-B stores scattered over 32 rows per instruction; instead each
+  // wave transposes its tile through its own slice of the (now idle) LDS, two tile rows at a time, and writes 16 B per
+  // lane with 16 lanes covering one pixel's 256 B: every store instruction is four full 256-B rows. ----
+  __builtin_amdgcn_s_barrier();                              // every wave is done reading the K-walk's LDS image
+  {
+    // staged in fp32 so bias and residual are added before the single bf16 rounding, as in the unfused reference ops
+    constexpr int EROW = 528;                                // 512 B per pixel + 16 pad
+    char* const eslice = smem + wave * (32 * EROW);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int oh = oh0 + 4 * wave + p;
+      uint4 rr[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {                       // residual rows first: their latency hides under the LDS pass
+        const int owp = ow0 + it * 4 + e_px;
+        rr[it] = make_uint4(0, 0, 0, 0);
+        if (a.resid && oh < a.H_out && owp < a.W_out && cb < a.Cout_st) {
+          const bf16_t* rp = a.resid + (((long long)t * a.H_out + oh) * a.W_out + owp) * a.ldr + cb;
+          if (cb + 8 <= a.Cout_st) rr[it] = *(const uint4*)rp;
+          else { const uint2 r2 = *(const uint2*)rp; rr[it].x = r2.x; rr[it].y = r2.y; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = acc[i][p][gq * 4 + e];
+          *(f32x4*)(eslice + l31 * EROW + (i * 32 + 8 * gq + 4 * hi) * 4) = o;
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private slice: no barrier needed
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int px = it * 4 + e_px;
+        const int owp = ow0 + px;
+        const f32x4 lo = *(const f32x4*)(eslice + px * EROW + e_ch * 32) + bias_lo;
+        const f32x4 hi4 = *(const f32x4*)(eslice + px * EROW + e_ch * 32 + 16) + bias_hi;
+        const uint4 r = rr[it];
+        uint4 v;
+        v.x = pack_bf2(lo[0] + __uint_as_float(r.x << 16), lo[1] + __uint_as_float(r.x & 0xffff0000u));
+        v.y = pack_bf2(lo[2] + __uint_as_float(r.y << 16), lo[3] + __uint_as_float(r.y & 0xffff0000u));
+        v.z = pack_bf2(hi4[0] + __uint_as_float(r.z << 16), hi4[1] + __uint_as_float(r.z & 0xffff0000u));
+        v.w = pack_bf2(hi4[2] + __uint_as_float(r.w << 16), hi4[3] + __uint_as_float(r.w & 0xffff0000u));
+        if (oh < a.H_out && owp < a.W_out && cb < a.Cout_st) {
+          bf16_t* dst = a.out + (((long long)t * a.H_out + oh) * a.W_out + owp) * a.ldo + cb;
+          if (cb + 8 <= a.Cout_st) *(uint4*)dst = v;
+          else *(uint2*)dst = make_uint2(v.x, v.y);          // Cout_st is a multiple of 4
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  if (CFG::TIMING && a.gate && blockIdx.x == 4001 && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ((unsigned long long*)a.gate)[20 + wave] = __builtin_amdgcn_s_memtime() - t_epi;   // epilogue incl. store drain
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // gemm8: the ping-pong structure of conv3x3_halo8 for plain GEMMs (every Linear of the DiT, 1x1x1 convs):
 // 512 rows x 128 output channels per 8-wave workgroup, K-step 32, 3-deep LDS rings for both operands
@@ -1301,6 +1644,43 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
                             d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in &&
                             d->h_out >= 16 && d->w_out >= 32 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) && !no_halo &&
                             !(a.debug & 7);
+    static int halo4x = -1, h4cfg = 0;
+    if (halo4x < 0) {
+      const char* e = getenv("DOVE_CONV_HALO4X");
+      halo4x = (e && e[0] == '1') ? 1 : 0;
+      const char* c = getenv("DOVE_HALO4X_CFG");
+      h4cfg = c ? atoi(c) : 0;
+    }
+    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16))) {
+      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
+      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
+      int cfg_now = h4cfg;
+      if (cfg_now == 9 && d->debug_buf) a.gate = (const float*)d->debug_buf;
+      else if (cfg_now == 9) cfg_now = 0;
+      auto launch4x = [&](auto cfg) {
+        using C = decltype(cfg);
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+          (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+          attr = true;
+        }
+        if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, C>), dim3((unsigned)g4), dim3(256), C::LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, C>), dim3((unsigned)g4), dim3(256), C::LDS_BYTES, s, a);
+      };
+      switch (cfg_now) {
+        case 1: launch4x(Halo4xCfg<6, 5, 3, 0>{}); break;   // deep ring, 3 halo rounds / step
+        case 2: launch4x(Halo4xCfg<6, 4, 2, 4>{}); break;   // one more step of load latency budget only
+        case 3: launch4x(Halo4xCfg<4, 3, 2, 0>{}); break;   // shallow ring, early k-half-1 reads
+        case 9: launch4x(Halo4xCfg<4, 3, 2, 4, true>{}); break;   // TIMING build of the default
+        default: launch4x(Halo4xCfg<4, 3, 2, 4>{}); break;
+      }
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
+      return DOVE_OK;
+    }
     if (halo_up_ok && halo8) {
       static bool attru = false;
       if (!attru) {
