@@ -8,6 +8,7 @@ typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (8 bf16 = 4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define DOVE_OK 0
 #define DOVE_EINVAL (-1)

@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
   constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
   // weight ring: BR slots, staged BAHEAD steps ahead; loads of the last BAHEAD-2 steps may still be in flight at a step
-  // barrier (LDS-DMA issue -> landed is ~1.1 us under load, a step is ~0.5 us)
+  // barrier
   constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, HPS = CFG::HPS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1052,34 +1052,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   __builtin_assume(wave >= 0 && wave < 4);
   const int hi = lane >> 5, l31 = lane & 31;
 
-  const unsigned long long t_entry = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
-  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
-  const int t = rest % a.T_out; rest /= a.T_out;
-  const int twi = rest % a.tiles_w;
-  const int thi = rest / a.tiles_w;
-  const int n0 = tn * BN;
-  const int oh0 = thi * TH, ow0 = twi * TW;
+  // PERSISTENT workgroups: block b walks tiles b, b + G, b + 2G, ... as ONE continuous K walk.  Three cursors run over
+  // the tile sequence: the halo stream (one group ahead of the MFMAs), the weight stream (BAHEAD steps ahead) and the
+  // compute stream; the first two cross into the next tile while the current one is still accumulating, so a tile
+  // boundary costs the epilogue only - no prologue bubble, no workgroup launch, and the stores drain under the next walk.
+  const int ntiles = a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+  const int G = (int)gridDim.x;
+  struct Tile { int n0, t, oh0, ow0; };
+  auto decode = [&](int id) -> Tile {
+    unsigned rest = xcd_remap((unsigned)(id < ntiles ? id : ntiles - 1), (unsigned)ntiles);
+    Tile q;
+    q.n0 = (int)(rest % a.tiles_n) * BN; rest /= a.tiles_n;
+    q.t = (int)(rest % a.T_out); rest /= a.T_out;
+    q.ow0 = (int)(rest % a.tiles_w) * TW;
+    q.oh0 = (int)(rest / a.tiles_w) * TH;
+    return q;
+  };
 
-  unsigned voffA[12];
-#pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    const int s = r * 256 + tid;
-    const int px = s / 5, c = s - px * 5;
-    int ih, iw;
-    bool inb;
-    if (kUp) {
-      const int hh = px / UHW, hw = px - hh * UHW;
-      ih = (oh0 >> 1) - 1 + hh; iw = (ow0 >> 1) - 1 + hw;
-      inb = px < UHW * UHH;
-    } else {
-      const int hh = px / HWID, hw = px - hh * HWID;
-      ih = oh0 - 1 + hh; iw = ow0 - 1 + hw;
-      inb = px < HPIX;
-    }
-    const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
-    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
-  }
   unsigned voffB[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1094,35 +1083,73 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   const int kcn = a.Cin / BK;
   const int ngroups = a.kt * kcn;
 
-  // branch-free (scalar selects): the whole post-barrier part of a step must stay ONE basic block so that the scheduler can
-  // interleave staging / fragment reads with the MFMAs
-  const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-  auto frame_ptr0 = [&](int dt) -> const bf16_t* {
-    const int fv = t + dt - (a.kt - 1);
-    const bf16_t* causal = fv >= 0 ? a.x + fv * frame_elems : (a.cache ? a.cache + (a.kt - 1 + fv) * frame_elems : a.x);
-    return a.kt > 1 ? causal : a.x + (long long)tin * frame_elems;
+  // ---- halo stream ----
+  unsigned voffA[12];
+  const bf16_t *hfp0 = a.x, *hfp1 = a.x, *hfp2 = a.x;        // the (at most three) source frames of the stream's tile
+  const bf16_t* h_fp = a.x;                                   // frame of the group being staged
+  int h_dt = 0, h_kc = 0, h_tile = 0, h_oh0 = -1, h_ow0 = -1;
+  bool h_on = false;
+  auto halo_open = [&](int id) {                              // uniform; the lane offsets are redone only on a new spatial tile
+    h_tile = id;
+    h_on = id < ntiles;
+    const Tile q = decode(id);
+    if (q.oh0 != h_oh0 || q.ow0 != h_ow0) {
+      h_oh0 = q.oh0; h_ow0 = q.ow0;
+#pragma unroll
+      for (int r = 0; r < 12; ++r) {
+        const int s = r * 256 + tid;
+        const int px = s / 5, c = s - px * 5;
+        int ih, iw;
+        bool inb;
+        if (kUp) {
+          const int hh = px / UHW, hw = px - hh * UHW;
+          ih = (q.oh0 >> 1) - 1 + hh; iw = (q.ow0 >> 1) - 1 + hw;
+          inb = px < UHW * UHH;
+        } else {
+          const int hh = px / HWID, hw = px - hh * HWID;
+          ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
+          inb = px < HPIX;
+        }
+        const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+        voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
+      }
+    }
+    const int t = q.t;
+    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
+    auto frame = [&](int dt) -> const bf16_t* {
+      const int fv = t + dt - (a.kt - 1);
+      const bf16_t* causal = fv >= 0 ? a.x + fv * frame_elems : (a.cache ? a.cache + (a.kt - 1 + fv) * frame_elems : a.x);
+      return a.kt > 1 ? causal : a.x + (long long)tin * frame_elems;
+    };
+    hfp0 = frame(0);
+    hfp1 = a.kt > 1 ? frame(1) : hfp0;
+    hfp2 = a.kt > 2 ? frame(2) : hfp0;
+    h_dt = 0; h_kc = 0; h_fp = hfp0;
   };
-  // the (at most three) source frames of this tile, resolved once; per-round selection is two scalar selects
-  const bf16_t* const fp0 = frame_ptr0(0);
-  const bf16_t* const fp1 = a.kt > 1 ? frame_ptr0(1) : fp0;
-  const bf16_t* const fp2 = a.kt > 2 ? frame_ptr0(2) : fp0;
-  auto frame_ptr = [&](int dt) -> const bf16_t* { return dt == 0 ? fp0 : (dt == 1 ? fp1 : fp2); };
-
-  int h_dt = 0, h_kc = 0;
-  const bf16_t* h_fp = fp0;                 // frame of the group whose halo is being staged (updated once per group)
-  auto stage_halo_round = [&](auto rc, int buf, bool on) {     // `on` false: zero-length descriptor -> the load is a no-op write of zeros
+  auto halo_advance = [&]() {                                 // cursor -> next (frame tap, channel chunk) group, maybe next tile
+    if (++h_kc == kcn) {
+      h_kc = 0;
+      if (++h_dt == a.kt) halo_open(h_tile + G);
+      else h_fp = h_dt == 1 ? hfp1 : hfp2;
+    }
+  };
+  auto stage_halo_round = [&](auto rc, int buf) {            // stream off: zero-length descriptor -> harmless zero fill
     constexpr int r = decltype(rc)::value;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)h_fp, (short)0, on ? (int)frame_bytes : 0, 0x00020000);
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)h_fp, (short)0, h_on ? (int)frame_bytes : 0, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
                                              h_kc * ROWB, 0, 0);
   };
-  int b_tap = 0, b_kc = 0, b_slot = 0;
-  const bf16_t* b_wp = a.w + (long long)n0 * a.Cin;            // running pointer to tap (dt*9 + tap) of this cout tile
+
+  // ---- weight stream ----
+  int b_tap = 0, b_kc = 0, b_dt = 0, b_slot = 0;
+  const bf16_t* b_wp = a.w;                                   // running pointer to tap (dt*9 + tap) of the stream's cout tile
+  const bf16_t* b_next_base = a.w;                            // same for the tile after the compute stream's (set per tile)
+  bool b_on = true, b_next_on = false;
   const long long w_fwd = wtap_stride, w_back = -8 * (long long)wtap_stride;
-  auto stage_b = [&](bool on) {
+  auto stage_b = [&]() {                                      // branch-free: part of the step's single basic block
     const int buf = b_slot;
     b_slot = (b_slot + 1 == BR) ? 0 : b_slot + 1;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, on ? (int)wtap_bytes : 0, 0x00020000);
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, b_on ? (int)wtap_bytes : 0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
@@ -1133,9 +1160,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     const int nkc = b_kc + (wrap ? 1 : 0);
     const bool wrap2 = nkc == kcn;
     b_kc = wrap2 ? 0 : nkc;
-    // tap index dt*9+tap: +1 normally and when both wrap (next dt), -8 when only the tap wraps (same dt, next k chunk);
-    // never advanced past the tensor: after the last real tap the descriptor length is 0 anyway but keep the base mapped
-    b_wp += on ? ((wrap && !wrap2) ? w_back : w_fwd) : 0;
+    const int ndt = b_dt + (wrap2 ? 1 : 0);
+    const bool tile_end = ndt == a.kt;
+    b_dt = tile_end ? 0 : ndt;
+    // tap index dt*9+tap: +1 normally and when tap and chunk both wrap (next dt), -8 when only the tap wraps
+    const bf16_t* stepped = b_wp + ((wrap && !wrap2) ? w_back : w_fwd);
+    b_wp = tile_end ? b_next_base : (b_on ? stepped : b_wp);
+    b_on = tile_end ? b_next_on : b_on;
   };
 
   // weight fragment offsets: 4 cout tiles x 2 k-halves (slot 0), XOR-swizzled 64-B rows
@@ -1153,33 +1184,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
   for (int dw = 0; dw < 3; ++dw) abaseU[dw] = ((2 * wave) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
 
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-  // epilogue-side lane role (16 lanes x 8 channels cover one pixel row): its bias is fetched now, under the halo prologue
-  const int e_px = lane >> 4, e_ch = lane & 15;
-  const int cb = n0 + e_ch * 8;
-  f32x4 bias_lo = {0.f, 0.f, 0.f, 0.f}, bias_hi = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) { bias_lo = *(const f32x4*)(a.bias + cb); bias_hi = *(const f32x4*)(a.bias + cb + 4); }
-
-  // ---- prologue: whole first halo + weight tiles of steps 0, 1, 2 ----
+  if (a.debug & 128) {   // experiment: de-phase the CUs of an XCD so that tile epilogues / halo bursts do not coincide
+    const int idx = (int)(blockIdx.x >> 3) & 31;
+    for (int i = 0; i < idx; ++i) __builtin_amdgcn_s_sleep(80);
+  }
+  // ---- prologue (once per workgroup): whole first halo + weight tiles of the first BAHEAD steps ----
+  halo_open((int)blockIdx.x);
   {
-    stage_halo_round(std::integral_constant<int, 0>{}, 0, true); stage_halo_round(std::integral_constant<int, 1>{}, 0, true);
-    stage_halo_round(std::integral_constant<int, 2>{}, 0, true); stage_halo_round(std::integral_constant<int, 3>{}, 0, true);
+    stage_halo_round(std::integral_constant<int, 0>{}, 0); stage_halo_round(std::integral_constant<int, 1>{}, 0);
+    stage_halo_round(std::integral_constant<int, 2>{}, 0); stage_halo_round(std::integral_constant<int, 3>{}, 0);
     if (!kUp) {
-      stage_halo_round(std::integral_constant<int, 4>{}, 0, true); stage_halo_round(std::integral_constant<int, 5>{}, 0, true);
-      stage_halo_round(std::integral_constant<int, 6>{}, 0, true); stage_halo_round(std::integral_constant<int, 7>{}, 0, true);
-      stage_halo_round(std::integral_constant<int, 8>{}, 0, true); stage_halo_round(std::integral_constant<int, 9>{}, 0, true);
-      stage_halo_round(std::integral_constant<int, 10>{}, 0, true); stage_halo_round(std::integral_constant<int, 11>{}, 0, true);
+      stage_halo_round(std::integral_constant<int, 4>{}, 0); stage_halo_round(std::integral_constant<int, 5>{}, 0);
+      stage_halo_round(std::integral_constant<int, 6>{}, 0); stage_halo_round(std::integral_constant<int, 7>{}, 0);
+      stage_halo_round(std::integral_constant<int, 8>{}, 0); stage_halo_round(std::integral_constant<int, 9>{}, 0);
+      stage_halo_round(std::integral_constant<int, 10>{}, 0); stage_halo_round(std::integral_constant<int, 11>{}, 0);
     }
   }
-  if (++h_kc == kcn) { h_kc = 0; ++h_dt; h_fp = frame_ptr(h_dt); }
+  halo_advance();
+  b_wp = a.w + (long long)decode((int)blockIdx.x).n0 * a.Cin;
 #pragma unroll
-  for (int i = 0; i < BAHEAD; ++i) stage_b(true);
+  for (int i = 0; i < BAHEAD; ++i) stage_b();                // (a tile has >= 18 steps: no tile switch in here)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1203,6 +1227,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(smem + slot * B_BYTES + boff[i][kk]);
   };
+  f32x16 acc[4][4];
   auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1214,47 +1239,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   using K1 = std::integral_constant<int, 1>;
 
   int rd_slot = 0;
-  unsigned long long t_wait = 0, t_bar = 0;
-  const unsigned long long t_begin = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
   bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
   load_a(std::integral_constant<int, 0>{}, K0{}, 0, xa);
   load_b(K0{}, 0, wa);
 
-  // one K-step = one spatial tap of one (frame tap, channel chunk) group; fragments of k-half 0 are already in xa/wa
-  auto step = [&](auto tapc, int g, int gb, bool more_groups, bool last_step) {
+  // one K-step = one spatial tap of one (frame tap, channel chunk) group; fragments of k-half 0 are already in xa/wa.
+  // gg = running group count of this workgroup (its parity picks the halo buffer), across tiles.
+  auto step = [&](auto tapc, int gg, int gb) {
     constexpr int tap = decltype(tapc)::value;
-    // drain loads issued two or more steps ago, then the step barrier (LDS hand-off point)
     constexpr int NH = CFG::nh(tap, NR);                       // halo rounds staged in this step
     constexpr int PEND = CFG::inflight(tap, NR);               // (issue counts are tap-periodic: loads are unconditional)
-    unsigned long long tq0 = 0, tq1 = 0;
-    if (CFG::TIMING) { tq0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");
-    if (CFG::TIMING) { tq1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    __builtin_amdgcn_s_barrier();
-    if (CFG::TIMING) {
-      const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
-      t_wait += tq1 - tq0;
-      t_bar += tq2 - tq1;
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");   // drain all but the last BAHEAD-2 steps' loads,
+    __builtin_amdgcn_s_barrier();                                  // then the step barrier (LDS hand-off point)
     __builtin_amdgcn_sched_barrier(0);
     // ---- from here to the end of the step: ONE basic block (every load is issued unconditionally; a zero-length
-    //      descriptor turns the ones past the end of the K walk into harmless zero fills of unused slots) ----
-    const bool sb = (tap < 9 - BAHEAD) || more_groups;
-    stage_b(sb);
-    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, (g + 1) & 1, more_groups);
-    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, (g + 1) & 1, more_groups);
-    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? HPS * tap + 2 : 0)>{}, (g + 1) & 1, more_groups);
+    //      descriptor turns the ones past the end of the tile sequence into harmless zero fills of unused slots) ----
+    stage_b();
+    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, (gg + 1) & 1);
+    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, (gg + 1) & 1);
+    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? HPS * tap + 2 : 0)>{}, (gg + 1) & 1);
     load_a(tapc, K1{}, gb, xb);
     load_b(K1{}, rd_slot, wb);
     mma(wa, xa);
     const int nslot = (rd_slot + 1 == BR) ? 0 : rd_slot + 1;
     constexpr int ntap = (tap + 1) % 9;
-    const int ngb = (tap == 8) ? (((g + 1) & 1) * A_BYTES) : gb;
-    load_a(std::integral_constant<int, ntap>{}, K0{}, ngb, xa);         // (after the last step this reads LDS nobody uses)
+    const int ngb = (tap == 8) ? (((gg + 1) & 1) * A_BYTES) : gb;
+    load_a(std::integral_constant<int, ntap>{}, K0{}, ngb, xa);         // (tap 8 of a tile's last group: the NEXT tile's first)
     load_b(K0{}, nslot, wa);
     mma(wb, xb);
     rd_slot = nslot;
-    // pinned interleave: every MFMA gap carries a slice of the scalar staging work and (first half) one fragment read
+    // pinned interleave: every MFMA gap carries a slice of the scalar staging work and one fragment read
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
@@ -1272,87 +1286,138 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  for (int g = 0; g < ngroups; ++g) {
-    const int gb = (g & 1) * A_BYTES;
-    const bool more = g + 1 < ngroups;
-    step(std::integral_constant<int, 0>{}, g, gb, more, false);
-    step(std::integral_constant<int, 1>{}, g, gb, more, false);
-    step(std::integral_constant<int, 2>{}, g, gb, more, false);
-    step(std::integral_constant<int, 3>{}, g, gb, more, false);
-    step(std::integral_constant<int, 4>{}, g, gb, more, false);
-    step(std::integral_constant<int, 5>{}, g, gb, more, false);
-    step(std::integral_constant<int, 6>{}, g, gb, more, false);
-    step(std::integral_constant<int, 7>{}, g, gb, more, false);
-    step(std::integral_constant<int, 8>{}, g, gb, more, !more);
-    if (++h_kc == kcn) { h_kc = 0; ++h_dt; h_fp = frame_ptr(h_dt); }
-  }
+  // epilogue-side lane role: 8 lanes x 8 channels cover 64 channels (128 B) of one pixel
+  const int e_px = lane >> 3, e_ch = lane & 7;
+  int gg = 0;
+  unsigned long long tm_walk = 0, tm_bar = 0, tm_body = 0, tm_drain = 0, tm_n = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
+  const unsigned long long tm_start = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
+  for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
+    if (CFG::TIMING) tm0 = __builtin_amdgcn_s_memtime();
+    const Tile c = decode(tile);
+    {
+      const int nxt = tile + G;
+      b_next_on = nxt < ntiles;
+      b_next_base = a.w + (long long)decode(nxt).n0 * a.Cin;
+    }
+    f32x4 bias_r[2][2];                                       // this lane's 8 channels in each 64-channel half
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cbh = c.n0 + h * 64 + e_ch * 8;
+      bias_r[h][0] = bias_r[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) { bias_r[h][0] = *(const f32x4*)(a.bias + cbh); bias_r[h][1] = *(const f32x4*)(a.bias + cbh + 4); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
 
-  if (CFG::TIMING && a.gate && blockIdx.x == 4001 && lane == 0) {     // TIMING build: `gate` is the host's debug buffer
-    unsigned long long* o = (unsigned long long*)a.gate + wave * 4;
-    o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_wait; o[2] = t_bar; o[3] = (unsigned long long)ngroups * 9;
-    o[16 + wave] = t_begin - t_entry;                                    // prologue
-  }
-  const unsigned long long t_epi = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
-  // ---- epilogue: wave w owns tile rows 4w..4w+3 (128 pixels), all 128 channels.  The MFMA result layout (lane = pixel,
-  // 4 consecutive channels per register quad) would give 8-B stores scattered over 32 rows per instruction; instead each
-  // wave transposes its tile through its own slice of the (now idle) LDS, two tile rows at a time, and writes 16 B per
-  // lane with 16 lanes covering one pixel's 256 B: every store instruction is four full 256-B rows. ----
-  __builtin_amdgcn_s_barrier();                              // every wave is done reading the K-walk's LDS image
-  {
-    // staged in fp32 so bias and residual are added before the single bf16 rounding, as in the unfused reference ops
-    constexpr int EROW = 528;                                // 512 B per pixel + 16 pad
-    char* const eslice = smem + wave * (32 * EROW);
+    for (int g = 0; g < ngroups; ++g, ++gg) {
+      const int gb = (gg & 1) * A_BYTES;
+      step(std::integral_constant<int, 0>{}, gg, gb);
+      step(std::integral_constant<int, 1>{}, gg, gb);
+      step(std::integral_constant<int, 2>{}, gg, gb);
+      step(std::integral_constant<int, 3>{}, gg, gb);
+      step(std::integral_constant<int, 4>{}, gg, gb);
+      step(std::integral_constant<int, 5>{}, gg, gb);
+      step(std::integral_constant<int, 6>{}, gg, gb);
+      step(std::integral_constant<int, 7>{}, gg, gb);
+      step(std::integral_constant<int, 8>{}, gg, gb);
+      halo_advance();
+    }
+
+    // ---- epilogue: wave w owns tile rows 4w..4w+3 (128 pixels), all 128 channels.  The MFMA result layout (lane = pixel,
+    // 4 consecutive channels per register quad) would give 8-B stores scattered over 32 rows per instruction; instead the
+    // wave transposes through its own 12 KB slice of the halo buffer the last group just finished with (the other one
+    // already holds the next tile's first halo), one tile row x 64 channels at a time in fp32 (bias and residual are
+    // added before the single bf16 rounding), and stores 16 B per lane with 8 lanes covering a full 128-B line. ----
+    if (CFG::TIMING) tm1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();                            // every wave is done reading that buffer
+    if (CFG::TIMING) tm2 = __builtin_amdgcn_s_memtime();
+    {
+      constexpr int EROW = 272;                              // 64 fp32 per pixel + 16 pad
+      char* const eslice = smem + ((gg - 1) & 1) * A_BYTES + wave * 12288;
+      // lane byte offsets inside one output row segment (32 pixels from ow0, channels from n0): buffer addressing, so a
+      // column past the image edge is an out-of-range offset (dropped by the hardware) and a row past it a zero-length
+      // descriptor - the epilogue has no divergent control flow and no per-store 64-bit address arithmetic
+      unsigned o_off[4], r_off[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int oh = oh0 + 4 * wave + p;
-      uint4 rr[8];
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {                       // residual rows first: their latency hides under the LDS pass
-        const int owp = ow0 + it * 4 + e_px;
-        rr[it] = make_uint4(0, 0, 0, 0);
-        if (a.resid && oh < a.H_out && owp < a.W_out && cb < a.Cout_st) {
-          const bf16_t* rp = a.resid + (((long long)t * a.H_out + oh) * a.W_out + owp) * a.ldr + cb;
-          if (cb + 8 <= a.Cout_st) rr[it] = *(const uint4*)rp;
-          else { const uint2 r2 = *(const uint2*)rp; rr[it].x = r2.x; rr[it].y = r2.y; }
-        }
+      for (int it = 0; it < 4; ++it) {
+        const int px = it * 8 + e_px;
+        const bool okw = c.ow0 + px < a.W_out;
+        o_off[it] = okw ? (unsigned)((px * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
+        r_off[it] = okw ? (unsigned)((px * (int)a.ldr + e_ch * 8) * 2) : 0x80000000u;
       }
+      auto emit = [&](auto has_resid) {
+        constexpr bool kRes = decltype(has_resid)::value;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int p = 0; p < 4; ++p) {
+          const int oh = c.oh0 + 4 * wave + p;
+          const long long pix0 = ((long long)c.t * a.H_out + oh) * a.W_out + c.ow0;
+          const bool okh = oh < a.H_out;
+          const auto srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + pix0 * a.ldo + c.n0), (short)0,
+                                                               okh ? (int)(TW * a.ldo * 2) : 0, 0x00020000);
+          const auto srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.resid + pix0 * a.ldr + c.n0 : a.out), (short)0,
+                                                               (kRes && okh) ? (int)(TW * a.ldr * 2) : 0, 0x00020000);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          f32x4 o;
+          for (int h = 0; h < 2; ++h) {
+            u32x4 rr[4];
+            if (kRes) {                                      // residual first: its latency hides under the LDS pass
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = acc[i][p][gq * 4 + e];
-          *(f32x4*)(eslice + l31 * EROW + (i * 32 + 8 * gq + 4 * hi) * 4) = o;
+              for (int it = 0; it < 4; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 128, 0);
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[h * 2 + i2][p][gq * 4 + e];
+                *(f32x4*)(eslice + l31 * EROW + (i2 * 32 + 8 * gq + 4 * hi) * 4) = o;
+              }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
+            f32x4 lo[4], hi4[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              lo[it] = *(const f32x4*)(eslice + (it * 8 + e_px) * EROW + e_ch * 32);
+              hi4[it] = *(const f32x4*)(eslice + (it * 8 + e_px) * EROW + e_ch * 32 + 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
+              if (kRes) {
+                const u32x4 r = rr[it];
+                x0 += f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                            __uint_as_float(r[1] & 0xffff0000u)};
+                x1 += f32x4{__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16),
+                            __uint_as_float(r[3] & 0xffff0000u)};
+              }
+              const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 128, 0);
+            }
+          }
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private slice: no barrier needed
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int px = it * 4 + e_px;
-        const int owp = ow0 + px;
-        const f32x4 lo = *(const f32x4*)(eslice + px * EROW + e_ch * 32) + bias_lo;
-        const f32x4 hi4 = *(const f32x4*)(eslice + px * EROW + e_ch * 32 + 16) + bias_hi;
-        const uint4 r = rr[it];
-        uint4 v;
-        v.x = pack_bf2(lo[0] + __uint_as_float(r.x << 16), lo[1] + __uint_as_float(r.x & 0xffff0000u));
-        v.y = pack_bf2(lo[2] + __uint_as_float(r.y << 16), lo[3] + __uint_as_float(r.y & 0xffff0000u));
-        v.z = pack_bf2(hi4[0] + __uint_as_float(r.z << 16), hi4[1] + __uint_as_float(r.z & 0xffff0000u));
-        v.w = pack_bf2(hi4[2] + __uint_as_float(r.w << 16), hi4[3] + __uint_as_float(r.w & 0xffff0000u));
-        if (oh < a.H_out && owp < a.W_out && cb < a.Cout_st) {
-          bf16_t* dst = a.out + (((long long)t * a.H_out + oh) * a.W_out + owp) * a.ldo + cb;
-          if (cb + 8 <= a.Cout_st) *(uint4*)dst = v;
-          else *(uint2*)dst = make_uint2(v.x, v.y);          // Cout_st is a multiple of 4
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      if (a.resid) emit(std::true_type{});
+      else emit(std::false_type{});
+    }
+    // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9; the loads of
+    // the next tile's first steps were issued before them and have long landed)
+    if (CFG::TIMING) tm3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CFG::TIMING) {
+      const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
+      tm_walk += tm1 - tm0; tm_bar += tm2 - tm1; tm_body += tm3 - tm2; tm_drain += tm4 - tm3; ++tm_n;
     }
   }
-  if (CFG::TIMING && a.gate && blockIdx.x == 4001 && lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ((unsigned long long*)a.gate)[20 + wave] = __builtin_amdgcn_s_memtime() - t_epi;   // epilogue incl. store drain
+  if (CFG::TIMING && a.gate && blockIdx.x == 100 && lane == 0) {       // TIMING build: `gate` is the host's debug buffer
+    unsigned long long* o = (unsigned long long*)a.gate + wave * 8;
+    o[0] = tm_walk; o[1] = tm_bar; o[2] = tm_body; o[3] = tm_drain; o[4] = tm_n; o[5] = (unsigned long long)ngroups * 9;
+    o[6] = __builtin_amdgcn_s_memtime() - tm_start;
   }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // gemm8: the ping-pong structure of conv3x3_halo8 for plain GEMMs (every Linear of the DiT, 1x1x1 convs):
@@ -1651,7 +1716,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       const char* c = getenv("DOVE_HALO4X_CFG");
       h4cfg = c ? atoi(c) : 0;
     }
-    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16))) {
+    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16)) && a.Cout_st % 128 == 0 && a.ldo < (1 << 20) && a.ldr < (1 << 20)) {
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
       a.tiles_n = d->cout_pad / 128;
@@ -1668,8 +1733,18 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
           (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
           attr = true;
         }
-        if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, C>), dim3((unsigned)g4), dim3(256), C::LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, C>), dim3((unsigned)g4), dim3(256), C::LDS_BYTES, s, a);
+        // persistent: one workgroup per CU walks its share of the tiles (DOVE_HALO4X_GRID=0: one workgroup per tile)
+        static int pgrid = -1;
+        if (pgrid < 0) {
+          int dev = 0, cus = 256;
+          (void)hipGetDevice(&dev);
+          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          const char* ge = getenv("DOVE_HALO4X_GRID");
+          pgrid = ge ? atoi(ge) : cus;
+        }
+        const unsigned grid = (pgrid > 0 && g4 > pgrid) ? (unsigned)pgrid : (unsigned)g4;
+        if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, C>), dim3(grid), dim3(256), C::LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, C>), dim3(grid), dim3(256), C::LDS_BYTES, s, a);
       };
       switch (cfg_now) {
         case 1: launch4x(Halo4xCfg<6, 5, 3, 0>{}); break;   // deep ring, 3 halo rounds / step

@@ -1,5 +1,5 @@
-"""Cycle accounting of one conv3x3_halo4x workgroup (TIMING build, DOVE_CONV_HALO4X=1 DOVE_HALO4X_CFG=9): per wave the
-total s_memtime ticks of the K walk, the part spent in the counted vmcnt wait and the part in the step barrier."""
+"""Cycle accounting of one persistent conv3x3_halo4x workgroup (TIMING build: DOVE_CONV_HALO4X=1 DOVE_HALO4X_CFG=9):
+per wave, s_memtime ticks per tile spent in the K walk, the pre-epilogue barrier, the epilogue body and the store drain."""
 import os
 import sys
 
@@ -18,10 +18,9 @@ torch.cuda.synchronize()
 for _ in range(3):
     ops.conv(x, pc, out=y, debug_buf=buf)
 torch.cuda.synchronize()
-full = buf.cpu()
-t = full[:16].view(4, 4)
+t = buf.cpu().view(4, 8)
 for wv in range(4):
-    tot, wait, bar, n = (int(v) for v in t[wv])
-    print(f"wave {wv}: steps {n}  total {tot} ticks = {tot / max(n, 1):.1f}/step   vmcnt-wait {wait / max(n, 1):.1f}/step   "
-          f"barrier {bar / max(n, 1):.1f}/step   body {(tot - wait - bar) / max(n, 1):.1f}/step")
-print("prologue ticks per wave:", full[16:20].tolist(), " epilogue (incl. store drain):", full[20:24].tolist())
+    walk, bar, body, drain, n, steps, total = (int(v) for v in t[wv][:7])
+    n = max(n, 1)
+    print(f"wave {wv}: tiles {n} steps/tile {steps}  per tile: K-walk {walk / n:.0f} ({walk / n / max(steps, 1):.1f}/step)  "
+          f"barrier {bar / n:.0f}  epilogue body {body / n:.0f}  store drain {drain / n:.0f}   whole kernel {total} ticks")
