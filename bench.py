@@ -148,13 +148,17 @@ def main():
         macs = flops.clip_macs(v, t, args.frames, args.height, args.width)
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps * args.frames / elapsed
-        # dominant kernel = conv3x3_halo8_kernel (VAE 3x3x3 convs, ~52 % of the step).  achieved = sum(algorithmic FLOP)
+        # dominant kernel = conv3x3_halo4x_kernel (VAE 3x3x3 / up-sampling 3x3 convs, ~half of the step).  achieved = sum(algorithmic FLOP)
         # / sum(launch duration) over ITS launches inside the timed region (HIP events on the launch stream).
         def agg(recs):
             fl = sum(r[1] for r in recs)
             ms = sum(r[2].elapsed_time(r[3]) for r in recs)
             return fl, ms
-        dom = [r for r in records if r[4] == "conv3x3_halo8_kernel"]
+        DOM = "conv3x3_halo4x_kernel"
+        dom = [r for r in records if r[4] == DOM]
+        if not dom:                                   # DOVE_CONV_HALO4X=0 fallback build of the same path
+            DOM = "conv3x3_halo8_kernel"
+            dom = [r for r in records if r[4] == DOM]
         dom_fl, dom_ms = agg(dom)
         tot_fl, tot_ms = agg(records)
         by = {}
@@ -171,7 +175,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("halo8_hbm_bytes_per_launch")
+                traffic = json.load(f).get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -181,7 +185,7 @@ def main():
                        "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15},
             "frames_per_s_per_gpu": value / world,
             "whole_path_tflops_per_gpu": macs["flop"] * args.steps / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_halo8_kernel (LDS-halo implicit-GEMM 3x3x3 conv, bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": DOM + " (persistent LDS-halo implicit-GEMM 3x3(x3) conv, bf16 MFMA 32x32x16)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "launches": len(dom) // max(args.steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,

@@ -1022,13 +1022,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
 // and while those run, k-half 0 of the NEXT step is read -- legal across the step barrier because the counted vmcnt drain
 // keeps every staged tile two steps ahead of its first reader.  One barrier per 32 MFMAs, no MFMA ever waits on LDS.
 // ------------------------------------------------------------------------------------------------
-template <int BR_, int BAHEAD_, int HPS_, int DS0_, bool TIMING_ = false>
 struct Halo4xCfg {
-  static constexpr bool TIMING = TIMING_;
-  static constexpr int BR = BR_, BAHEAD = BAHEAD_;
-  static constexpr int HPS = HPS_;                              // halo rounds staged per step
-  static constexpr int DS0 = DS0_;                              // first MFMA gap that carries a k-half-1 fragment read
-  static constexpr int LDS_BYTES = 2 * halo8::A_BYTES + BR * halo8::B_BYTES;
+  static constexpr int BR = 6;                                  // weight ring slots; 9 taps x 2 group parities = 3 turns:
+                                                                //   slot(tap, parity) = (tap + 3 parity) % 6 is compile-time
+  static constexpr int BAHEAD = 3;                              // weights are staged 3 steps ahead
+  static constexpr int HPS = 2;                                 // halo rounds staged per step (steps 0..5 of a group)
+  static constexpr int DS0 = 4;                                 // first MFMA gap that carries a k-half-1 fragment read
+  static constexpr int LDS_BYTES = 2 * halo8::A_BYTES + BR * halo8::B_BYTES;   // 147456
   static constexpr int nh(int tap, int nr) { return (HPS * tap + HPS <= nr) ? HPS : ((HPS * tap < nr) ? nr - HPS * tap : 0); }
   static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
   static constexpr int inflight(int tap, int nr) {              // loads issued in the BAHEAD-2 steps before step `tap`
@@ -1038,36 +1038,129 @@ struct Halo4xCfg {
   }
 };
 
-template <bool kUp, class CFG>
-__global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
+// Staging-side state of the persistent halo4x walk.  Plain structs + force-inlined functions (not by-reference lambda
+// closures nested three deep: those left the counters in scratch memory, where the compiler treats them as per-lane
+// values and builds every buffer descriptor through a waterfall loop).
+struct H4Tile { int n0, t, oh0, ow0; };
+struct H4Const {
+  int ntiles, G, kcn, frame_bytes, wtap_bytes, tid;
+  long long frame_elems, wtap_stride;
+};
+struct H4State {
+  unsigned voffA[12];                                         // lane offsets of the 12 halo rounds (spatial tile of nxt)
+  int n_tile, n_dt, n_kc, n_oh0, n_ow0;                       // group `nxt`: tile, frame tap, channel chunk
+  bool n_on;                                                  // nxt's tile exists (else: zero-length descriptors)
+  int t;                                                      // output frame of nxt's tile
+  const bf16_t* wt_base;                                      // weights of nxt's cout tile
+  const bf16_t* h_base;                                       // nxt's halo source: frame + channel chunk
+  const bf16_t* wg_nxt;                                       // nxt's weights: tap 0 of (frame tap, chunk)
+  int h_nrec, nrec_b_cur, nrec_b_nxt;
+};
+// a 64-bit select is lowered to v_cndmask and runtime integer division runs on the VALU: pin such results back to SGPRs
+__device__ __forceinline__ const bf16_t* h4_pin64(const bf16_t* p) {
+  const unsigned long long v = (unsigned long long)p;
+  return (const bf16_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+}
+__device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k, int id) {
+  unsigned rest = xcd_remap((unsigned)(id < k.ntiles ? id : k.ntiles - 1), (unsigned)k.ntiles);
+  H4Tile q;
+  q.n0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_n) * halo8::BN); rest /= a.tiles_n;
+  q.t = __builtin_amdgcn_readfirstlane((int)(rest % a.T_out)); rest /= a.T_out;
+  q.ow0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_w) * halo8::TW);
+  q.oh0 = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_w) * halo8::TH);
+  return q;
+}
+template <bool kUp>
+__device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, const H4Const& k, int id) {
   using namespace halo8;
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
+  s.n_tile = id;
+  s.n_on = id < k.ntiles;
+  const H4Tile q = h4_decode(a, k, id);
+  if (q.oh0 != s.n_oh0 || q.ow0 != s.n_ow0) {                // lane offsets are redone only on a new spatial tile
+    s.n_oh0 = q.oh0; s.n_ow0 = q.ow0;
+#pragma unroll
+    for (int r = 0; r < 12; ++r) {
+      const int sl = r * 256 + k.tid;
+      const int px = sl / 5, c = sl - px * 5;
+      int ih, iw;
+      bool inb;
+      if (kUp) {
+        const int hh = px / UHW, hw = px - hh * UHW;
+        ih = (q.oh0 >> 1) - 1 + hh; iw = (q.ow0 >> 1) - 1 + hw;
+        inb = px < UHW * UHH;
+      } else {
+        const int hh = px / HWID, hw = px - hh * HWID;
+        ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
+        inb = px < HPIX;
+      }
+      const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
+      s.voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
+    }
+  }
+  s.t = q.t;
+  s.wt_base = a.w + (long long)q.n0 * a.Cin;
+  s.n_dt = 0; s.n_kc = 0;
+}
+__device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const H4Const& k) {   // descriptors of group nxt
+  using namespace halo8;
+  // source frame of (tile frame t, frame tap n_dt): causal taps before the first frame come from the conv cache (or
+  // replicate frame 0); plain index arithmetic - no table of per-tap pointers, whose select would turn into an indexed
+  // load from the struct and keep all of it in scratch memory
+  const int t = s.t;
+  const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
+  const int fv = t + s.n_dt - (a.kt - 1);
+  const bool from_cache = a.kt > 1 && fv < 0 && a.cache != nullptr;
+  const int fidx = a.kt > 1 ? (fv >= 0 ? fv : (from_cache ? a.kt - 1 + fv : 0)) : tin;
+  const bf16_t* f = h4_pin64((from_cache ? a.cache : a.x) + (long long)fidx * k.frame_elems);
+  s.h_base = f + s.n_kc * BK;
+  s.h_nrec = s.n_on ? k.frame_bytes - s.n_kc * ROWB : 0;      // off stream: zero-length descriptor -> harmless zero fill
+  s.wg_nxt = s.wt_base + (long long)(s.n_dt * 9) * k.wtap_stride + s.n_kc * BK;
+  s.nrec_b_nxt = s.n_on ? k.wtap_bytes - s.n_kc * ROWB : 0;
+}
+template <bool kUp>
+__device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const H4Const& k) {   // cur <- nxt, nxt <- successor
+  s.nrec_b_cur = s.nrec_b_nxt;
+  if (++s.n_kc == k.kcn) {
+    s.n_kc = 0;
+    if (++s.n_dt == a.kt) h4_open_tile<kUp>(s, a, k, s.n_tile + k.G);
+  }
+  h4_set_nxt(s, a, k);
+}
+
+template <bool kUp, bool kTiming>
+__global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
+  using namespace halo8;
+  using CFG = Halo4xCfg;
+  constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
   constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
-  // weight ring: BR slots, staged BAHEAD steps ahead; loads of the last BAHEAD-2 steps may still be in flight at a step
-  // barrier
   constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, HPS = CFG::HPS;
+  constexpr int B0 = 2 * A_BYTES;                               // LDS: halo buffer 0 | halo buffer 1 | weight ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 4);
   const int hi = lane >> 5, l31 = lane & 31;
 
-  // PERSISTENT workgroups: block b walks tiles b, b + G, b + 2G, ... as ONE continuous K walk.  Three cursors run over
-  // the tile sequence: the halo stream (one group ahead of the MFMAs), the weight stream (BAHEAD steps ahead) and the
-  // compute stream; the first two cross into the next tile while the current one is still accumulating, so a tile
-  // boundary costs the epilogue only - no prologue bubble, no workgroup launch, and the stores drain under the next walk.
-  const int ntiles = a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-  const int G = (int)gridDim.x;
-  struct Tile { int n0, t, oh0, ow0; };
-  auto decode = [&](int id) -> Tile {
-    unsigned rest = xcd_remap((unsigned)(id < ntiles ? id : ntiles - 1), (unsigned)ntiles);
-    Tile q;
-    q.n0 = (int)(rest % a.tiles_n) * BN; rest /= a.tiles_n;
-    q.t = (int)(rest % a.T_out); rest /= a.T_out;
-    q.ow0 = (int)(rest % a.tiles_w) * TW;
-    q.oh0 = (int)(rest / a.tiles_w) * TH;
-    return q;
-  };
+  // PERSISTENT workgroups: block b walks tiles b, b + G, b + 2G, ... as ONE continuous K walk of (frame tap, channel
+  // chunk) GROUPS of 9 spatial taps.  While group `cur` is multiplied, the halo of group `nxt` (the next group of this
+  // tile or the first of the next tile) and the weights 3 steps ahead are in flight, so a tile boundary costs the
+  // epilogue only - no prologue bubble, no workgroup launch, and the stores drain under the next tile's walk.
+  // Everything a step needs from the staging side is per-group scalar state prepared at the group boundary; LDS slots
+  // and buffers are compile-time functions of (tap, group parity), so a step carries ~10 scalar instructions.
+  H4Const kc;
+  kc.ntiles = a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+  kc.G = (int)gridDim.x;
+  kc.kcn = a.Cin / BK;
+  kc.frame_elems = (long long)a.H_in * a.W_in * a.Cin;
+  kc.frame_bytes = (int)(kc.frame_elems * 2);
+  kc.wtap_bytes = (int)((long long)BN * a.Cin * 2);
+  kc.wtap_stride = (long long)a.Cout_pad * a.Cin;
+  kc.tid = tid;
+  const int ntiles = kc.ntiles, G = kc.G;
+  const int ngroups = a.kt * kc.kcn;
+  const long long wtap_stride = kc.wtap_stride;
 
   unsigned voffB[2];
 #pragma unroll
@@ -1076,97 +1169,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     const int c = (tid & 3) ^ ((row >> 2) & 3);
     voffB[j] = (unsigned)((row * a.Cin + c * 8) * 2);
   }
-  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
-  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
-  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
-  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
-  const int kcn = a.Cin / BK;
-  const int ngroups = a.kt * kcn;
 
-  // ---- halo stream ----
+  // `st` is touched only by the h4_* functions; what the steps consume is copied into plain locals after every advance
+  // (a struct captured by the step lambdas' closures is not promoted to registers)
+  H4State st;
+  st.n_oh0 = -1; st.n_ow0 = -1;
   unsigned voffA[12];
-  const bf16_t *hfp0 = a.x, *hfp1 = a.x, *hfp2 = a.x;        // the (at most three) source frames of the stream's tile
-  const bf16_t* h_fp = a.x;                                   // frame of the group being staged
-  int h_dt = 0, h_kc = 0, h_tile = 0, h_oh0 = -1, h_ow0 = -1;
-  bool h_on = false;
-  auto halo_open = [&](int id) {                              // uniform; the lane offsets are redone only on a new spatial tile
-    h_tile = id;
-    h_on = id < ntiles;
-    const Tile q = decode(id);
-    if (q.oh0 != h_oh0 || q.ow0 != h_ow0) {
-      h_oh0 = q.oh0; h_ow0 = q.ow0;
+  const bf16_t *h_base = a.x, *wg_nxt = a.w;
+  int h_nrec = 0, nrec_b_cur = 0, nrec_b_nxt = 0;
+  auto publish = [&](const H4State& q) {
 #pragma unroll
-      for (int r = 0; r < 12; ++r) {
-        const int s = r * 256 + tid;
-        const int px = s / 5, c = s - px * 5;
-        int ih, iw;
-        bool inb;
-        if (kUp) {
-          const int hh = px / UHW, hw = px - hh * UHW;
-          ih = (q.oh0 >> 1) - 1 + hh; iw = (q.ow0 >> 1) - 1 + hw;
-          inb = px < UHW * UHH;
-        } else {
-          const int hh = px / HWID, hw = px - hh * HWID;
-          ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
-          inb = px < HPIX;
-        }
-        const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
-        voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
-      }
-    }
-    const int t = q.t;
-    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-    auto frame = [&](int dt) -> const bf16_t* {
-      const int fv = t + dt - (a.kt - 1);
-      const bf16_t* causal = fv >= 0 ? a.x + fv * frame_elems : (a.cache ? a.cache + (a.kt - 1 + fv) * frame_elems : a.x);
-      return a.kt > 1 ? causal : a.x + (long long)tin * frame_elems;
-    };
-    hfp0 = frame(0);
-    hfp1 = a.kt > 1 ? frame(1) : hfp0;
-    hfp2 = a.kt > 2 ? frame(2) : hfp0;
-    h_dt = 0; h_kc = 0; h_fp = hfp0;
+    for (int r = 0; r < 12; ++r) voffA[r] = q.voffA[r];
+    h_base = q.h_base; wg_nxt = q.wg_nxt; h_nrec = q.h_nrec; nrec_b_cur = q.nrec_b_cur; nrec_b_nxt = q.nrec_b_nxt;
   };
-  auto halo_advance = [&]() {                                 // cursor -> next (frame tap, channel chunk) group, maybe next tile
-    if (++h_kc == kcn) {
-      h_kc = 0;
-      if (++h_dt == a.kt) halo_open(h_tile + G);
-      else h_fp = h_dt == 1 ? hfp1 : hfp2;
-    }
-  };
-  auto stage_halo_round = [&](auto rc, int buf) {            // stream off: zero-length descriptor -> harmless zero fill
-    constexpr int r = decltype(rc)::value;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)h_fp, (short)0, h_on ? (int)frame_bytes : 0, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
-                                             h_kc * ROWB, 0, 0);
-  };
+  const bf16_t* b_wp = a.w;                                   // running pointer of the weight stream
 
-  // ---- weight stream ----
-  int b_tap = 0, b_kc = 0, b_dt = 0, b_slot = 0;
-  const bf16_t* b_wp = a.w;                                   // running pointer to tap (dt*9 + tap) of the stream's cout tile
-  const bf16_t* b_next_base = a.w;                            // same for the tile after the compute stream's (set per tile)
-  bool b_on = true, b_next_on = false;
-  const long long w_fwd = wtap_stride, w_back = -8 * (long long)wtap_stride;
-  auto stage_b = [&]() {                                      // branch-free: part of the step's single basic block
-    const int buf = b_slot;
-    b_slot = (b_slot + 1 == BR) ? 0 : b_slot + 1;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, b_on ? (int)wtap_bytes : 0, 0x00020000);
+  auto stage_halo_round = [&](auto rc, auto bufc) {
+    constexpr int r = decltype(rc)::value, buf = decltype(bufc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)h_base, (short)0, h_nrec, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + r * 4096 + wave * 1024), 16, voffA[r], 0, 0, 0);
+  };
+  auto stage_b = [&](auto slotc, int nrec) {                  // one weight tap -> ring slot; the stream pointer moves on
+    constexpr int slot = decltype(slotc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, nrec, 0x00020000);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
-                                               voffB[j], b_kc * ROWB, 0, 0);
-    const int nt = b_tap + 1;
-    const bool wrap = nt == 9;
-    b_tap = wrap ? 0 : nt;
-    const int nkc = b_kc + (wrap ? 1 : 0);
-    const bool wrap2 = nkc == kcn;
-    b_kc = wrap2 ? 0 : nkc;
-    const int ndt = b_dt + (wrap2 ? 1 : 0);
-    const bool tile_end = ndt == a.kt;
-    b_dt = tile_end ? 0 : ndt;
-    // tap index dt*9+tap: +1 normally and when tap and chunk both wrap (next dt), -8 when only the tap wraps
-    const bf16_t* stepped = b_wp + ((wrap && !wrap2) ? w_back : w_fwd);
-    b_wp = tile_end ? b_next_base : (b_on ? stepped : b_wp);
-    b_on = tile_end ? b_next_on : b_on;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + B0 + slot * B_BYTES + j * 4096 + wave * 1024), 16, voffB[j],
+                                               0, 0, 0);
+    b_wp += wtap_stride;
   };
 
   // weight fragment offsets: 4 cout tiles x 2 k-halves (slot 0), XOR-swizzled 64-B rows
@@ -1176,9 +1206,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = i * 32 + l31;
-      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
+      boff[i][kk] = B0 + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
     }
-  // activation fragment bases (padded 80-B halo rows -> base + immediate for every tap)
+  // activation fragment bases (padded 80-B halo rows -> base + immediate for every tap and either buffer)
   const int abase0 = ((4 * wave) * HWID + l31) * APITCH + hi * 16;
   int abaseU[3];
 #pragma unroll
@@ -1188,29 +1218,35 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     const int idx = (int)(blockIdx.x >> 3) & 31;
     for (int i = 0; i < idx; ++i) __builtin_amdgcn_s_sleep(80);
   }
-  // ---- prologue (once per workgroup): whole first halo + weight tiles of the first BAHEAD steps ----
-  halo_open((int)blockIdx.x);
+  // ---- prologue (once per workgroup): whole first halo + the first BAHEAD weight taps ----
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  h4_open_tile<kUp>(st, a, kc, (int)blockIdx.x);
+  h4_set_nxt(st, a, kc);
+  publish(st);
   {
-    stage_halo_round(std::integral_constant<int, 0>{}, 0); stage_halo_round(std::integral_constant<int, 1>{}, 0);
-    stage_halo_round(std::integral_constant<int, 2>{}, 0); stage_halo_round(std::integral_constant<int, 3>{}, 0);
+    stage_halo_round(std::integral_constant<int, 0>{}, I0{}); stage_halo_round(std::integral_constant<int, 1>{}, I0{});
+    stage_halo_round(std::integral_constant<int, 2>{}, I0{}); stage_halo_round(std::integral_constant<int, 3>{}, I0{});
     if (!kUp) {
-      stage_halo_round(std::integral_constant<int, 4>{}, 0); stage_halo_round(std::integral_constant<int, 5>{}, 0);
-      stage_halo_round(std::integral_constant<int, 6>{}, 0); stage_halo_round(std::integral_constant<int, 7>{}, 0);
-      stage_halo_round(std::integral_constant<int, 8>{}, 0); stage_halo_round(std::integral_constant<int, 9>{}, 0);
-      stage_halo_round(std::integral_constant<int, 10>{}, 0); stage_halo_round(std::integral_constant<int, 11>{}, 0);
+      stage_halo_round(std::integral_constant<int, 4>{}, I0{}); stage_halo_round(std::integral_constant<int, 5>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 6>{}, I0{}); stage_halo_round(std::integral_constant<int, 7>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 8>{}, I0{}); stage_halo_round(std::integral_constant<int, 9>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 10>{}, I0{}); stage_halo_round(std::integral_constant<int, 11>{}, I0{});
     }
   }
-  halo_advance();
-  b_wp = a.w + (long long)decode((int)blockIdx.x).n0 * a.Cin;
-#pragma unroll
-  for (int i = 0; i < BAHEAD; ++i) stage_b();                // (a tile has >= 18 steps: no tile switch in here)
+  b_wp = wg_nxt;
+  stage_b(std::integral_constant<int, 0>{}, nrec_b_nxt);
+  stage_b(std::integral_constant<int, 1>{}, nrec_b_nxt);
+  stage_b(std::integral_constant<int, 2>{}, nrec_b_nxt);
+  h4_advance<kUp>(st, a, kc);
+  publish(st);                                                  // cur = group 0 of the first tile, nxt = its successor
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  // fragment loaders (tap is a compile-time constant -> every address is base VGPR + immediate)
-  auto load_a = [&](auto tapc, auto kkc, int gb, bf16x8 (&xf)[4]) {
-    constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value;
+  // fragment loaders: every address is a base VGPR + an immediate
+  auto load_a = [&](auto tapc, auto kkc, auto bufc, bf16x8 (&xf)[4]) {
+    constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value, gb = decltype(bufc)::value * A_BYTES;
     constexpr int dh = tap / 3, dw = tap % 3;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -1222,10 +1258,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       }
     }
   };
-  auto load_b = [&](auto kkc, int slot, bf16x8 (&wf)[4]) {
-    constexpr int kk = decltype(kkc)::value;
+  auto load_b = [&](auto kkc, auto slotc, bf16x8 (&wf)[4]) {
+    constexpr int kk = decltype(kkc)::value, slot = decltype(slotc)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(smem + slot * B_BYTES + boff[i][kk]);
+    for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(smem + boff[i][kk] + slot * B_BYTES);
   };
   f32x16 acc[4][4];
   auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4]) {
@@ -1235,70 +1271,67 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       for (int p = 0; p < 4; ++p)
         acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
   };
-  using K0 = std::integral_constant<int, 0>;
-  using K1 = std::integral_constant<int, 1>;
 
-  int rd_slot = 0;
   bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
-  load_a(std::integral_constant<int, 0>{}, K0{}, 0, xa);
-  load_b(K0{}, 0, wa);
+  load_a(I0{}, I0{}, I0{}, xa);
+  load_b(I0{}, I0{}, wa);
 
-  // one K-step = one spatial tap of one (frame tap, channel chunk) group; fragments of k-half 0 are already in xa/wa.
-  // gg = running group count of this workgroup (its parity picks the halo buffer), across tiles.
-  auto step = [&](auto tapc, int gg, int gb) {
-    constexpr int tap = decltype(tapc)::value;
+  // one K-step = one spatial tap of group cur (parity par); fragments of k-half 0 are already in xa/wa
+  auto step = [&](auto tapc, auto parc) {
+    constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
     constexpr int NH = CFG::nh(tap, NR);                       // halo rounds staged in this step
     constexpr int PEND = CFG::inflight(tap, NR);               // (issue counts are tap-periodic: loads are unconditional)
+    constexpr int stap = tap + BAHEAD;                         // the weight tap staged now (>= 9: of group nxt)
+    using Par = std::integral_constant<int, par>;
+    using NPar = std::integral_constant<int, 1 - par>;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");   // drain all but the last BAHEAD-2 steps' loads,
     __builtin_amdgcn_s_barrier();                                  // then the step barrier (LDS hand-off point)
     __builtin_amdgcn_sched_barrier(0);
-    // ---- from here to the end of the step: ONE basic block (every load is issued unconditionally; a zero-length
-    //      descriptor turns the ones past the end of the tile sequence into harmless zero fills of unused slots) ----
-    stage_b();
-    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, (gg + 1) & 1);
-    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, (gg + 1) & 1);
-    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? HPS * tap + 2 : 0)>{}, (gg + 1) & 1);
-    load_a(tapc, K1{}, gb, xb);
-    load_b(K1{}, rd_slot, wb);
+    // ---- from here to the end of the step: ONE basic block ----
+    if (stap == 9) b_wp = wg_nxt;
+    stage_b(std::integral_constant<int, (stap + 3 * par) % 6>{}, stap < 9 ? nrec_b_cur : nrec_b_nxt);
+    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, NPar{});
+    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, NPar{});
+    load_a(tapc, I1{}, Par{}, xb);
+    load_b(I1{}, std::integral_constant<int, (tap + 3 * par) % 6>{}, wb);
     mma(wa, xa);
-    const int nslot = (rd_slot + 1 == BR) ? 0 : rd_slot + 1;
-    constexpr int ntap = (tap + 1) % 9;
-    const int ngb = (tap == 8) ? (((gg + 1) & 1) * A_BYTES) : gb;
-    load_a(std::integral_constant<int, ntap>{}, K0{}, ngb, xa);         // (tap 8 of a tile's last group: the NEXT tile's first)
-    load_b(K0{}, nslot, wa);
+    // next step's k-half 0 (tap 8: tap 0 of group nxt - after a tile's last group that is the NEXT tile's first)
+    if (tap < 8) load_a(std::integral_constant<int, (tap + 1) % 9>{}, I0{}, Par{}, xa);
+    else load_a(I0{}, I0{}, NPar{}, xa);
+    load_b(I0{}, std::integral_constant<int, (tap + 1 + 3 * par) % 6>{}, wa);
     mma(wb, xb);
-    rd_slot = nslot;
-    // pinned interleave: every MFMA gap carries a slice of the scalar staging work and one fragment read
+    // pinned interleave: the staging work and one fragment read per MFMA gap
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x004, 6, 0);                // 6 SALU
-      if (i < 2 + NH) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (LDS-DMA)
-      if (i >= CFG::DS0 && i < CFG::DS0 + 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read (k-half 1 fragments)
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                // 1 VALU
+      if (i < 2 + NH) {
+        __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);              // <= 4 SALU (descriptor, m0)
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
+      }
+      if (i >= CFG::DS0 && i < CFG::DS0 + 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 ds_read (k-half 1)
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
-      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  auto group = [&](auto parc) {
+    step(std::integral_constant<int, 0>{}, parc); step(std::integral_constant<int, 1>{}, parc);
+    step(std::integral_constant<int, 2>{}, parc); step(std::integral_constant<int, 3>{}, parc);
+    step(std::integral_constant<int, 4>{}, parc); step(std::integral_constant<int, 5>{}, parc);
+    step(std::integral_constant<int, 6>{}, parc); step(std::integral_constant<int, 7>{}, parc);
+    step(std::integral_constant<int, 8>{}, parc);
   };
 
   // epilogue-side lane role: 8 lanes x 8 channels cover 64 channels (128 B) of one pixel
   const int e_px = lane >> 3, e_ch = lane & 7;
-  int gg = 0;
   unsigned long long tm_walk = 0, tm_bar = 0, tm_body = 0, tm_drain = 0, tm_n = 0, tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0;
-  const unsigned long long tm_start = CFG::TIMING ? __builtin_amdgcn_s_memtime() : 0;
+  const unsigned long long tm_start = kTiming ? __builtin_amdgcn_s_memtime() : 0;
   for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
-    if (CFG::TIMING) tm0 = __builtin_amdgcn_s_memtime();
-    const Tile c = decode(tile);
-    {
-      const int nxt = tile + G;
-      b_next_on = nxt < ntiles;
-      b_next_base = a.w + (long long)decode(nxt).n0 * a.Cin;
-    }
+    if (kTiming) tm0 = __builtin_amdgcn_s_memtime();
+    const H4Tile c = h4_decode(a, kc, tile);
     f32x4 bias_r[2][2];                                       // this lane's 8 channels in each 64-channel half
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -1313,18 +1346,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
 
-    for (int g = 0; g < ngroups; ++g, ++gg) {
-      const int gb = (gg & 1) * A_BYTES;
-      step(std::integral_constant<int, 0>{}, gg, gb);
-      step(std::integral_constant<int, 1>{}, gg, gb);
-      step(std::integral_constant<int, 2>{}, gg, gb);
-      step(std::integral_constant<int, 3>{}, gg, gb);
-      step(std::integral_constant<int, 4>{}, gg, gb);
-      step(std::integral_constant<int, 5>{}, gg, gb);
-      step(std::integral_constant<int, 6>{}, gg, gb);
-      step(std::integral_constant<int, 7>{}, gg, gb);
-      step(std::integral_constant<int, 8>{}, gg, gb);
-      halo_advance();
+    // a tile has an even number of groups (Cin % 64 == 0): two per trip, one of each halo-buffer parity - straight-line,
+    // so there is no control-flow merge at which the register allocator would have to reconcile two step bodies
+    for (int g = 0; g < ngroups; g += 2) {
+      group(I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      h4_advance<kUp>(st, a, kc);
+      publish(st);
+      __builtin_amdgcn_sched_barrier(0);
+      group(I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      h4_advance<kUp>(st, a, kc);
+      publish(st);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: wave w owns tile rows 4w..4w+3 (128 pixels), all 128 channels.  The MFMA result layout (lane = pixel,
@@ -1332,12 +1366,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     // wave transposes through its own 12 KB slice of the halo buffer the last group just finished with (the other one
     // already holds the next tile's first halo), one tile row x 64 channels at a time in fp32 (bias and residual are
     // added before the single bf16 rounding), and stores 16 B per lane with 8 lanes covering a full 128-B line. ----
-    if (CFG::TIMING) tm1 = __builtin_amdgcn_s_memtime();
+    if (kTiming) tm1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();                            // every wave is done reading that buffer
-    if (CFG::TIMING) tm2 = __builtin_amdgcn_s_memtime();
+    if (kTiming) tm2 = __builtin_amdgcn_s_memtime();
     {
       constexpr int EROW = 272;                              // 64 fp32 per pixel + 16 pad
-      char* const eslice = smem + ((gg - 1) & 1) * A_BYTES + wave * 12288;
+      char* const eslice = smem + A_BYTES + wave * 12288;      // (a tile's last group has parity 1)
       // lane byte offsets inside one output row segment (32 pixels from ow0, channels from n0): buffer addressing, so a
       // column past the image edge is an out-of-range offset (dropped by the hardware) and a row past it a zero-length
       // descriptor - the epilogue has no divergent control flow and no per-store 64-bit address arithmetic
@@ -1405,14 +1439,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     }
     // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9; the loads of
     // the next tile's first steps were issued before them and have long landed)
-    if (CFG::TIMING) tm3 = __builtin_amdgcn_s_memtime();
+    if (kTiming) tm3 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (CFG::TIMING) {
+    if (kTiming) {
       const unsigned long long tm4 = __builtin_amdgcn_s_memtime();
       tm_walk += tm1 - tm0; tm_bar += tm2 - tm1; tm_body += tm3 - tm2; tm_drain += tm4 - tm3; ++tm_n;
     }
   }
-  if (CFG::TIMING && a.gate && blockIdx.x == 100 && lane == 0) {       // TIMING build: `gate` is the host's debug buffer
+  if (kTiming && a.gate && blockIdx.x == 100 && lane == 0) {       // TIMING build: `gate` is the host's debug buffer
     unsigned long long* o = (unsigned long long*)a.gate + wave * 8;
     o[0] = tm_walk; o[1] = tm_bar; o[2] = tm_body; o[3] = tm_drain; o[4] = tm_n; o[5] = (unsigned long long)ngroups * 9;
     o[6] = __builtin_amdgcn_s_memtime() - tm_start;
@@ -1712,47 +1746,38 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     static int halo4x = -1, h4cfg = 0;
     if (halo4x < 0) {
       const char* e = getenv("DOVE_CONV_HALO4X");
-      halo4x = (e && e[0] == '1') ? 1 : 0;
+      halo4x = (e && e[0] == '0') ? 0 : 1;   // default on; DOVE_CONV_HALO4X=0 falls back to conv3x3_halo8
       const char* c = getenv("DOVE_HALO4X_CFG");
       h4cfg = c ? atoi(c) : 0;
     }
-    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16)) && a.Cout_st % 128 == 0 && a.ldo < (1 << 20) && a.ldr < (1 << 20)) {
+    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16)) && a.Cout_st % 128 == 0 && a.Cin % 64 == 0 && a.ldo < (1 << 20) && a.ldr < (1 << 20)) {
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
       a.tiles_n = d->cout_pad / 128;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
-      int cfg_now = h4cfg;
-      if (cfg_now == 9 && d->debug_buf) a.gate = (const float*)d->debug_buf;
-      else if (cfg_now == 9) cfg_now = 0;
-      auto launch4x = [&](auto cfg) {
-        using C = decltype(cfg);
-        static bool attr = false;
-        if (!attr) {
-          (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-          (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-          attr = true;
-        }
-        // persistent: one workgroup per CU walks its share of the tiles (DOVE_HALO4X_GRID=0: one workgroup per tile)
-        static int pgrid = -1;
-        if (pgrid < 0) {
-          int dev = 0, cus = 256;
-          (void)hipGetDevice(&dev);
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-          const char* ge = getenv("DOVE_HALO4X_GRID");
-          pgrid = ge ? atoi(ge) : cus;
-        }
-        const unsigned grid = (pgrid > 0 && g4 > pgrid) ? (unsigned)pgrid : (unsigned)g4;
-        if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, C>), dim3(grid), dim3(256), C::LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, C>), dim3(grid), dim3(256), C::LDS_BYTES, s, a);
-      };
-      switch (cfg_now) {
-        case 1: launch4x(Halo4xCfg<6, 5, 3, 0>{}); break;   // deep ring, 3 halo rounds / step
-        case 2: launch4x(Halo4xCfg<6, 4, 2, 4>{}); break;   // one more step of load latency budget only
-        case 3: launch4x(Halo4xCfg<4, 3, 2, 0>{}); break;   // shallow ring, early k-half-1 reads
-        case 9: launch4x(Halo4xCfg<4, 3, 2, 4, true>{}); break;   // TIMING build of the default
-        default: launch4x(Halo4xCfg<4, 3, 2, 4>{}); break;
+      const bool timing = h4cfg == 9 && d->debug_buf;
+      if (timing) a.gate = (const float*)d->debug_buf;
+      static bool attr4 = false;
+      if (!attr4) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        attr4 = true;
       }
+      // persistent: one workgroup per CU walks its share of the tiles (DOVE_HALO4X_GRID=0: one workgroup per tile)
+      static int pgrid = -1;
+      if (pgrid < 0) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* ge = getenv("DOVE_HALO4X_GRID");
+        pgrid = ge ? atoi(ge) : cus;
+      }
+      const unsigned grid = (pgrid > 0 && g4 > pgrid) ? (unsigned)pgrid : (unsigned)g4;
+      if (timing && !d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
       return DOVE_OK;
     }

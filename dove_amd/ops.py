@@ -6,6 +6,8 @@ import ctypes as C
 import math
 from dataclasses import dataclass
 
+import os
+
 import torch
 
 from . import lib as L
@@ -71,12 +73,15 @@ def kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, in_t
         tiles = -(-m // 512) * (pc.cout_pad // 128)
         if tiles >= 1024 or pc.cin_pad <= 4096:
             return "gemm8_kernel"
+    big = "conv3x3_halo8_kernel"
+    if os.environ.get("DOVE_CONV_HALO4X", "1") != "0" and pc.cout_store % 128 == 0 and pc.cin_pad % 64 == 0:
+        big = "conv3x3_halo4x_kernel"
     if (pc.kh == 3 and pc.kw == 3 and stride == 1 and up == 0 and ph == 1 and pw == 1 and tmode == 0 and act == 0 and gate is None
             and pc.cout_pad % 128 == 0 and hw_out == (H, W) and W >= 16):
-        return "conv3x3_halo8_kernel" if H >= 16 else "conv3x3_halo_kernel"
+        return big if H >= 16 else "conv3x3_halo_kernel"
     if (pc.kt == 1 and pc.kh == 3 and pc.kw == 3 and stride == 1 and up == 1 and ph == 1 and pw == 1 and act == 0 and gate is None
             and pc.cout_pad % 128 == 0 and hw_out == (2 * H, 2 * W) and hw_out[0] >= 16 and hw_out[1] >= 32):
-        return "conv3x3_halo8_kernel"
+        return big
     return "igemm_fast_kernel" if up == 0 else "igemm_kernel"
 
 

@@ -27,8 +27,11 @@ for k, v in acc.items():
         res[k] = {"launches": n, "fetch_bytes_per_launch_x2corr": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
 top = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "fetch_correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected", "per_kernel": res}
-if "conv3x3_halo8_kernel" in res:
-    top["halo8_hbm_bytes_per_launch"] = res["conv3x3_halo8_kernel"]["hbm_bytes_per_launch"]
+for dk in ("conv3x3_halo4x_kernel", "conv3x3_halo8_kernel"):
+    if dk in res:
+        top["dominant_kernel"] = dk
+        top["dominant_hbm_bytes_per_launch"] = res[dk]["hbm_bytes_per_launch"]
+        break
 json.dump(top, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]:
     print(f"{k:40s} launches {v['launches']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e9:8.3f} GB")
