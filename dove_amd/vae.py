@@ -99,7 +99,10 @@ class AutoencoderKLCogVideoX:
         if c.get("norm_num_groups", 32) != 32:
             raise NotImplementedError("HIP GroupNorm kernels are built for 32 groups")
         import os as _os
-        self.n_streams = int(_os.environ.get("DOVE_VAE_STREAMS", "2"))   # measured +2 % on the 33x720x1280 clip vs 1
+        # 2 = alternate frame-batches on two HIP streams.  Worth +2 % with the 8-wave conv kernel, +1.4 % with the persistent
+        # conv3x3_halo4x (whose workgroups own a whole CU each, so two convs mostly serialise) - and it makes per-kernel
+        # durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
+        self.n_streams = int(_os.environ.get("DOVE_VAE_STREAMS", "1"))
         self._streams = None
         self._pack(state_dict)
 

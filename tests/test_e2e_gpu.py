@@ -125,9 +125,10 @@ def test_two_stream_vae_is_bit_identical(setup):
     video = synth_clip(17, 48, 80, seed=11).cuda().to(torch.bfloat16)
     z = torch.randn(1, 16, 5, 6, 10, generator=torch.Generator().manual_seed(4)).cuda().to(torch.bfloat16)
     outs = {}
+    default = pipe.vae.n_streams
     for n in (1, 2):
         pipe.vae.n_streams = n
         outs[n] = (pipe.vae.encode(video).latent_dist.parameters.clone(), pipe.vae.decode(z).sample.clone())
         torch.cuda.synchronize()
-    pipe.vae.n_streams = 2
+    pipe.vae.n_streams = default
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
