@@ -70,6 +70,9 @@ def kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, in_t
     m = t_out * hw_out[0] * hw_out[1]
     if (pc.kt == pc.kh == pc.kw == 1 and stride == 1 and up == 0 and tmode == 0 and pc.cout_pad % 128 == 0 and m >= 4096
             and (T, H, W) == (t_out, hw_out[0], hw_out[1])):
+        if (os.environ.get("DOVE_GEMM4X", "1") != "0" and pc.cout_pad % 256 == 0 and pc.cout_store % 256 == 0
+                and pc.cin_pad % 128 == 0 and pc.cin_pad >= 256 and act in (0, 1)):
+            return "gemm4x_kernel"
         tiles = -(-m // 512) * (pc.cout_pad // 128)
         if tiles >= 1024 or pc.cin_pad <= 4096:
             return "gemm8_kernel"

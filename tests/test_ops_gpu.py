@@ -116,6 +116,13 @@ LIN_CASES = [
     ("lin8_k64", 4100, 64, 256, {}),
     ("lin8_k96", 4200, 96, 128, {}),
     ("lin8_k128", 4608, 128, 3072, {}),
+    # gemm4x persistent 256x256 kernel (M >= 4096, cout % 256 == 0, cin % 128 == 0): ragged M tail, one and many K chunks,
+    # more tiles than CUs (tile switch inside a workgroup), GELU / gated in-place residual epilogues
+    ("lin4x_ragged", 4099, 256, 256, {}),
+    ("lin4x_many_tiles", 20011, 256, 1024, {}),
+    ("lin4x_many_tiles_gate", 20011, 384, 768, {"gate": True, "inplace": True}),
+    ("lin4x_gelu_deep", 4500, 1536, 512, {"act": 1}),
+    ("lin4x_resid", 4300, 512, 256, {"resid_only": True}),
 ]
 
 
@@ -127,6 +134,8 @@ def test_linear(case):
     kw = dict(kw)
     gate = resid = None
     inplace = kw.pop("inplace", False)
+    if kw.pop("resid_only", False):
+        resid = rnd(N, cout, seed=7)
     if kw.pop("gate", False):
         g = torch.Generator().manual_seed(6)
         gate = torch.randn(2, pc_c.cout_pad, generator=g)
