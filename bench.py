@@ -172,10 +172,13 @@ def main():
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         all_igemm = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic = None
+        pmc_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
+                pj = json.load(f)
+                traffic = pj.get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
+                pmc_busy = {"whole_step": pj.get("whole_step_mfma_busy_frac"), "per_kernel": pj.get("mfma_busy_frac_per_kernel")}
         res = {
             "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -190,6 +193,9 @@ def main():
                          "traffic": traffic, "launches": len(dom) // max(args.steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
                          "share_of_step_time": dom_ms / (elapsed * 1e3),
+                         # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) from profiles/pmc_traffic.json
+                         # (separate rocprofv3 --pmc pass over this command, tools/gpu_pmc_bench.sh)
+                         "mfma_pipe_busy_frac_pmc": pmc_busy,
                          "all_igemm_kernels": {"achieved": all_igemm, "frac": all_igemm / MFMA_BF16_PEAK_TFLOPS,
                                                "share_of_step_time": tot_ms / (elapsed * 1e3), "launches": len(records) // max(args.steps, 1)},
                          "top_classes": {k: {"ms": a[1] / args.steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // args.steps}

@@ -14,7 +14,7 @@ for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(f):
             k = re.sub(r"[<(].*", "", row.get("Kernel_Name", "")).replace("void ", "")[:40]
             c = row.get("Counter_Name")
-            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
                 a = acc[k][c]
                 a[0] += float(row.get("Counter_Value", 0) or 0)
                 a[1] += 1
@@ -25,7 +25,14 @@ for k, v in acc.items():
         fetch = v["FETCH_SIZE"][0] / n * 1024 * 2
         write = v["WRITE_SIZE"][0] / v["WRITE_SIZE"][1] * 1024
         res[k] = {"launches": n, "fetch_bytes_per_launch_x2corr": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
-top = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+# whole-step MFMA-pipe utilisation: busy cycles summed over the 1024 SIMDs / (active cycles per XCD x 1024), over every kernel
+mb = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"][0] for v in acc.values() if "SQ_VALU_MFMA_BUSY_CYCLES" in v)
+ga = sum(v["GRBM_GUI_ACTIVE"][0] for v in acc.values() if "GRBM_GUI_ACTIVE" in v)
+mfma_busy = {k: v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (v["GRBM_GUI_ACTIVE"][0] / 8 * 1024)
+             for k, v in acc.items() if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", [0])[0] > 0}
+top = {"whole_step_mfma_busy_frac": (mb / (ga / 8 * 1024)) if ga else None,
+       "mfma_busy_frac_per_kernel": {k: round(x, 4) for k, x in sorted(mfma_busy.items(), key=lambda kv: -kv[1])[:12]},
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
        "fetch_correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected", "per_kernel": res}
 for dk in ("conv3x3_halo4x_kernel", "conv3x3_halo8_kernel"):
     if dk in res:
@@ -33,5 +40,7 @@ for dk in ("conv3x3_halo4x_kernel", "conv3x3_halo8_kernel"):
         top["dominant_hbm_bytes_per_launch"] = res[dk]["hbm_bytes_per_launch"]
         break
 json.dump(top, open(out, "w"), indent=1)
+print("whole-step MFMA-pipe busy fraction:", top["whole_step_mfma_busy_frac"])
+print({k: v for k, v in list(top["mfma_busy_frac_per_kernel"].items())[:6]})
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:10]:
     print(f"{k:40s} launches {v['launches']:5d}  HBM/launch {v['hbm_bytes_per_launch']/1e9:8.3f} GB")
