@@ -132,3 +132,34 @@ def test_two_stream_vae_is_bit_identical(setup):
         torch.cuda.synchronize()
     pipe.vae.n_streams = default
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+
+
+def test_fullsize_vae_causal_prefix_and_determinism(setup):
+    """BASELINE configs[1] size (33x720x1280), through properties that do not need an oracle run at that size:
+    (i) causal prefix - the VAE is causal in time and normalises per frame-batch, so a clip cut at a frame-batch boundary
+        must reproduce the uncut result BIT-exactly: encode(clip[:17]) == encode(clip)[:5], decode(z[:3]) == decode(z)[:9]
+        (same kernels, same shapes per batch; a conv cache or persistent-tile bug that leaks later frames breaks it);
+    (ii) determinism - the same call twice gives identical bits (no atomics, no run-to-run scheduling dependence);
+    (iii) outputs finite and the right shape."""
+    pipe = setup[0]
+    lr = synth_clip(33, 180, 320, seed=5)[0].cuda()                                   # [3,33,180,320] in [-1,1]
+    clip = torch.nn.functional.interpolate(lr.permute(1, 0, 2, 3), size=(720, 1280), mode="bilinear",
+                                           align_corners=False).permute(1, 0, 2, 3)[None].to(torch.bfloat16).contiguous()
+    full = pipe.vae.encode(clip).latent_dist.parameters.clone()
+    again = pipe.vae.encode(clip).latent_dist.parameters.clone()
+    pre = pipe.vae.encode(clip[:, :, :17].contiguous()).latent_dist.parameters.clone()
+    torch.cuda.synchronize()
+    assert full.shape == (1, 32, 9, 90, 160) and pre.shape == (1, 32, 5, 90, 160)
+    assert bool(torch.isfinite(full.float()).all())
+    assert torch.equal(full, again), "encode is not deterministic"
+    assert torch.equal(pre, full[:, :, :5]), "encoder output of a frame-batch-aligned prefix changed with later frames"
+    z = (full[:, :16].float() * 0.7).to(torch.bfloat16).contiguous()
+    dec = pipe.vae.decode(z).sample.clone()
+    dec2 = pipe.vae.decode(z).sample.clone()
+    dpre = pipe.vae.decode(z[:, :, :3].contiguous()).sample.clone()
+    torch.cuda.synchronize()
+    assert dec.shape == (1, 3, 33, 720, 1280) and dpre.shape == (1, 3, 9, 720, 1280)
+    assert bool(torch.isfinite(dec.float()).all())
+    assert torch.equal(dec, dec2), "decode is not deterministic"
+    assert torch.equal(dpre, dec[:, :, :9]), "decoder output of a frame-batch-aligned prefix changed with later latents"
+
