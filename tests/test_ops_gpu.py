@@ -238,6 +238,60 @@ def test_attention_spiked_rows():
     close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
 
 
+def test_conv_and_linear_fullsize_properties():
+    """Headline shapes (128->128 3x3x3 conv on 8x720x1280; 18 226 x 3072 -> 9216 linear): determinism, exact
+    power-of-two homogeneity (op(2x) == 2 op(x) without bias: every product and partial sum scales exactly), temporal
+    causality of the conv (frames 0..3 of the output do not change when frames 4..7 of the input do)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    pc = ops.pack_conv(torch.randn(128, 128, 3, 3, 3) * (128 * 27) ** -0.5, None, "cuda")
+    x = torch.randn(8, 720, 1280, 128, device="cuda", generator=g).to(BF)
+    y = ops.conv(x, pc)
+    assert torch.equal(y, ops.conv(x, pc)), "conv is not deterministic"
+    assert torch.equal(ops.conv((x.float() * 2).to(BF), pc), (y.float() * 2).to(BF))
+    x2 = x.clone()
+    x2[4:] = torch.randn(4, 720, 1280, 128, device="cuda", generator=g).to(BF)
+    assert torch.equal(ops.conv(x2, pc)[:4], y[:4]), "causal conv: early frames depend on later ones"
+    del x2, y
+    pl = ops.pack_conv(torch.randn(9216, 3072) * 3072 ** -0.5, None, "cuda")
+    t = torch.randn(18226, 3072, device="cuda", generator=g).to(BF)
+    z = ops.linear(t, pl)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(z.float()).all())
+    assert torch.equal(z, ops.linear(t, pl)), "linear is not deterministic"
+    assert torch.equal(ops.linear((t.float() * 2).to(BF), pl), (z.float() * 2).to(BF))
+    torch.cuda.synchronize()
+
+
+def test_attention_fullsize_properties():
+    """N = 18 226 tokens x 48 heads (the headline clip): properties that need no reference at that size.
+    (i) rows of softmax sum to one: V = 1 must give 1 (P is rounded to bf16 before PV while the normaliser is fp32: 2^-7);
+    (ii) exact linearity in V for power-of-two scales: attention(Q, K, 2V) == 2 * attention(Q, K, V) bit for bit;
+    (iii) keys in the zero-padded tail (columns N..Npad) never contribute: poisoning them changes nothing."""
+    N, heads = 18226, 48
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Qh = torch.zeros(heads, npad, 64, dtype=BF, device="cuda")
+    Kh = torch.zeros(heads, npad, 64, dtype=BF, device="cuda")
+    Vt = torch.zeros(heads, 64, npad, dtype=BF, device="cuda")
+    Qh[:, :N] = (torch.randn(heads, N, 64, device="cuda", generator=g) * 0.5).to(BF)
+    Kh[:, :N] = torch.randn(heads, N, 64, device="cuda", generator=g).to(BF)
+    Vt[:, :, :N] = torch.randn(heads, 64, N, device="cuda", generator=g).to(BF)
+    out = lambda: torch.zeros(N, heads * 64, dtype=BF, device="cuda")   # noqa: E731
+    ones = torch.zeros_like(Vt)
+    ones[:, :, :N] = 1.0
+    o1 = ops.attention(Qh, Kh, ones, N, npad, heads, out())
+    assert float((o1.float() - 1.0).abs().max()) <= 2 ** -7
+    a = ops.attention(Qh, Kh, Vt, N, npad, heads, out())
+    b = ops.attention(Qh, Kh, (Vt.float() * 2).to(BF), N, npad, heads, out())
+    assert torch.equal((a.float() * 2).to(BF), b)
+    Kp, Vp = Kh.clone(), Vt.clone()
+    Kp[:, N:] = 7.0
+    Vp[:, :, N:] = 1e4
+    c = ops.attention(Qh, Kp, Vp, N, npad, heads, out())
+    torch.cuda.synchronize()
+    assert torch.equal(a, c)
+
+
 def test_layout_and_glue():
     x = torch.randn(3, 4, 10, 12, generator=torch.Generator().manual_seed(18))
     for xx in (x, x.to(BF)):
