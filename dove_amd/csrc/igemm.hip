@@ -42,6 +42,8 @@ struct IgemmArgs {
   long long gate_split;
   int tw_log2, tiles_w, tiles_h, tiles_n;
   int debug;  // timing ablations only (DOVE_IGEMM_ABLATE): 1 skip A loads, 2 skip B loads, 4 skip MFMA
+  float* gn_partial;   // conv3x3_halo4x only: fused GroupNorm(32) partial sums of the stored output, [rows][32][2]
+  int cpg_log;         // log2(channels per group) = log2(Cout / 32)
 };
 
 template <int BN, int BK>
@@ -1383,8 +1385,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         o_off[it] = okw ? (unsigned)((px * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
         r_off[it] = okw ? (unsigned)((px * (int)a.ldr + e_ch * 8) * 2) : 0x80000000u;
       }
-      auto emit = [&](auto has_resid) {
+      auto emit = [&](auto has_resid, auto has_gn) {
         constexpr bool kRes = decltype(has_resid)::value;
+        constexpr bool kGn = decltype(has_gn)::value;
+        // fused GroupNorm statistics: this lane's 8 channels per 64-channel half = two 4-channel quads; (sum, sum of
+        // squares) of the bf16-ROUNDED stored values kept pairwise (even / odd channel) until the end of the tile
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
+        f32x2 gs[2][2], gq[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) { gs[h][q2] = f32x2{0.f, 0.f}; gq[h][q2] = f32x2{0.f, 0.f}; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int oh = c.oh0 + 4 * wave + p;
@@ -1429,6 +1440,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
                             __uint_as_float(r[3] & 0xffff0000u)};
               }
               const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
+              if (kGn) {
+                const bool valid = okh && o_off[it] != 0x80000000u;     // pixels past the image edge are not part of the tensor
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const uint32_t w = valid ? v[e] : 0u;
+                  const f32x2 f = {__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+                  gs[h][e >> 1] += f;
+                  gq[h][e >> 1] += f * f;
+                }
+              }
               __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 128, 0);
               // store-data hazard (found on MI355X): the 16-B store reads its data VGPRs for the last lanes a few cycles after
               // issue; the next iteration's first VALU writes re-used them and its fp32 intermediates were stored instead
@@ -1438,9 +1459,43 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
             }
           }
         }
+        if (kGn) {
+          // lane totals -> totals over the wave's 128 pixels (lanes that differ in e_px), then one (sum, sumsq) per group
+          const int cpg_log = a.cpg_log;                       // 2, 3 or 4 channels-per-group bits (Cout 128 / 256 / 512)
+          const long long row = ((((long long)c.t * a.tiles_h + (c.oh0 >> 4)) * a.tiles_w + (c.ow0 >> 5)) << 2) + wave;
+          float* dst = a.gn_partial + row * 64;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float sv[2], qv[2];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              sv[q2] = gs[h][q2][0] + gs[h][q2][1];
+              qv[q2] = gq[h][q2][0] + gq[h][q2][1];
+#pragma unroll
+              for (int m = 8; m < 64; m <<= 1) { sv[q2] += __shfl_xor(sv[q2], m); qv[q2] += __shfl_xor(qv[q2], m); }
+            }
+            const int ch0 = c.n0 + h * 64 + e_ch * 8;          // first of this lane's 8 channels
+            if (cpg_log == 2) {                                // 4 channels per group: each quad is a group
+              if (e_px == 0) {
+                dst[(ch0 >> 2) * 2] = sv[0]; dst[(ch0 >> 2) * 2 + 1] = qv[0];
+                dst[((ch0 >> 2) + 1) * 2] = sv[1]; dst[((ch0 >> 2) + 1) * 2 + 1] = qv[1];
+              }
+            } else {
+              float s8 = sv[0] + sv[1], q8 = qv[0] + qv[1];    // 8 channels per group: the lane's two quads
+              if (cpg_log == 4) { s8 += __shfl_xor(s8, 1); q8 += __shfl_xor(q8, 1); }   // 16: two neighbouring lanes
+              const bool writer = e_px == 0 && (cpg_log == 3 || (e_ch & 1) == 0);
+              if (writer) { dst[(ch0 >> cpg_log) * 2] = s8; dst[(ch0 >> cpg_log) * 2 + 1] = q8; }
+            }
+          }
+        }
       };
-      if (a.resid) emit(std::true_type{});
-      else emit(std::false_type{});
+      if (a.gn_partial) {
+        if (a.resid) emit(std::true_type{}, std::true_type{});
+        else emit(std::false_type{}, std::true_type{});
+      } else {
+        if (a.resid) emit(std::true_type{}, std::false_type{});
+        else emit(std::false_type{}, std::false_type{});
+      }
     }
     // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9; the loads of
     // the next tile's first steps were issued before them and have long landed)
@@ -2002,6 +2057,35 @@ static int launch_igemm(const IgemmArgs& a, unsigned grid, hipStream_t s) {
   return DOVE_OK;
 }
 
+// does this call dispatch to conv3x3_halo4x?  (one rule for the launch and for dove_conv_gn_partial_rows)
+static bool halo4x_applies(const dove_conv_desc* d) {
+  static int enabled = -1, no_halo = -1, ablate = 0;
+  if (enabled < 0) {
+    const char* e = getenv("DOVE_CONV_HALO4X");
+    enabled = (e && e[0] == '0') ? 0 : 1;                      // default on; 0 falls back to conv3x3_halo8
+    const char* n = getenv("DOVE_IGEMM_NOHALO");
+    no_halo = (n && n[0] == '1') ? 1 : 0;
+    const char* ab = getenv("DOVE_IGEMM_ABLATE");
+    ablate = ab ? atoi(ab) : 0;
+  }
+  if (!enabled || no_halo) return false;
+  const bool common = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
+                      d->cout_pad % 128 == 0 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
+                      d->cout_store % 128 == 0 && d->cin % 64 == 0 && d->ldo < (1 << 20) && (!d->resid || d->ldr < (1 << 20));
+  if (!common) return false;
+  if (d->up == 0)
+    return d->tmode == 0 && d->h_out == d->h_in && d->w_out == d->w_in && d->w_out >= 16 && d->h_out >= 16;
+  return d->kt == 1 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in && d->h_out >= 16 && d->w_out >= 32 && !(ablate & 7);
+}
+
+extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
+  if (!d || !halo4x_applies(d)) return 0;
+  if (d->cout_store != 128 && d->cout_store != 256 && d->cout_store != 512) return 0;   // 4 / 8 / 16 channels per group
+  if (d->cout_store != d->cout_pad) return 0;
+  const long long th = (d->h_out + halo8::TH - 1) / halo8::TH, tw = (d->w_out + halo8::TW - 1) / halo8::TW;
+  return (long long)d->t_out * th * tw * 4;
+}
+
 extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d && d->x && d->w && d->out, "conv_igemm: null pointer");
   DOVE_CHECK_ARG(d->cin % 32 == 0 && d->cin > 0, "conv_igemm: Cin (%d) must be a positive multiple of 32 (pad on pack)", d->cin);
@@ -2025,6 +2109,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   a.Cin = d->cin; a.Cout_pad = d->cout_pad; a.Cout_st = d->cout_store;
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
+  a.gn_partial = nullptr; a.cpg_log = 0;
   {
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("DOVE_IGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
@@ -2133,7 +2218,12 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       const char* c = getenv("DOVE_HALO4X_CFG");
       h4cfg = c ? atoi(c) : 0;
     }
-    if (halo4x && ((halo_up_ok) || (halo_ok && d->h_out >= 16)) && a.Cout_st % 128 == 0 && a.Cin % 64 == 0 && a.ldo < (1 << 20) && a.ldr < (1 << 20)) {
+    DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
+                   "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
+    (void)halo4x;
+    if (halo4x_applies(d)) {
+      a.gn_partial = d->gn_partial;
+      a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
       a.tiles_n = d->cout_pad / 128;

@@ -74,6 +74,34 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// partial rows written by a conv epilogue (one per tile x wave) -> 256 rows for gn_finalize_kernel; fp64, fixed order
+__global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ partial, long long rows,
+                                                             float* __restrict__ out) {
+  const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
+  double acc = 0.0;
+  for (long long r = (long long)blockIdx.x * 4 + part; r < rows; r += (long long)gridDim.x * 4) acc += (double)partial[r * 64 + j];
+  __shared__ double sh[256];
+  sh[tid] = acc;
+  __syncthreads();
+  if (tid < 64) out[blockIdx.x * 64 + tid] = (float)((sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]));
+}
+
+extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws,
+                                                float* stats, void* stream) {
+  DOVE_CHECK_ARG(partial && ws && stats, "groupnorm_finalize_partials: null pointer");
+  DOVE_CHECK_ARG(rows > 0 && count > 0, "groupnorm_finalize_partials: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  if (rows <= 1024) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, partial, (int)rows, count, eps, stats);
+  } else {
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (float*)ws);
+    DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials(reduce)");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, 256, count, eps, stats);
+  }
+  DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials");
+  return DOVE_OK;
+}
+
 extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws,
                                           int ws_blocks, float* stats, void* stream) {
   DOVE_CHECK_ARG(x && partial_ws && stats, "groupnorm_stats: null pointer");

@@ -23,6 +23,7 @@ class ConvDesc(C.Structure):
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
         ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong), ("debug_buf", C.c_void_p),
+        ("gn_partial", C.c_void_p),
     ]
 
 
@@ -32,6 +33,7 @@ _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     "dove_conv_igemm_bf16": [C.POINTER(ConvDesc), _VP],
     "dove_groupnorm_stats_bf16": [_VP, _LL, _I, _F, _VP, _I, _VP, _VP],
+    "dove_groupnorm_finalize_partials": [_VP, _LL, C.c_double, _F, _VP, _VP, _VP],
     "dove_groupnorm_apply_bf16": [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, C.POINTER(C.c_int), _VP],
     "dove_layernorm_modulate_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP, _VP, _LL, _VP],
     "dove_qkv_post_bf16": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP],
@@ -49,6 +51,7 @@ SIGNATURES = {
     "dove_postprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP],
 }
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
+         "dove_conv_gn_partial_rows": (C.c_longlong, [C.POINTER(ConvDesc)]),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)])}
 
 

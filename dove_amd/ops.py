@@ -91,8 +91,14 @@ def kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, in_t
 def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
-         out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None) -> torch.Tensor:
-    """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo]."""
+         out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None,
+         gn_eps: float | None = None) -> torch.Tensor:
+    """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo].
+
+    ``gn_eps``: the output feeds an nn.GroupNorm(32, C, eps) (resnet norm1/norm2, SpatialNorm's norm_layer).  When the
+    dispatched kernel can fuse the statistics into its epilogue (``dove_conv_gn_partial_rows`` > 0), they are computed
+    there and attached to the returned tensor as ``out.gn_stats`` ([32,2] mean / rstd, fp32) - `groupnorm_stats_of`
+    then skips the separate pass over the tensor; otherwise nothing is attached and the caller's path is unchanged."""
     L.require_cuda(x, cache, resid, gate, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 4, (x.dtype, x.shape)
     T, H, W, Cx = x.shape
@@ -131,6 +137,12 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
     if gate is not None:
         assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
+    partial = None
+    if gn_eps is not None and ldo == pc.cout_store:
+        rows = int(L.load().dove_conv_gn_partial_rows(C.byref(d)))
+        if rows > 0:
+            partial = torch.empty(rows, 64, dtype=torch.float32, device=x.device)
+            d.gn_partial = partial.data_ptr()
     if _profiler is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -140,7 +152,25 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         flops = 2.0 * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
         _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1,
                           kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, (T, H, W))))
+    if partial is None:
+        if getattr(out, "gn_stats", None) is not None:      # a re-used `out` tensor must not keep statistics of old contents
+            out.gn_stats = None
+    else:
+        stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
+        count = float(t_out * hw_out[0] * hw_out[1]) * (pc.cout_store // 32)
+        L.check(L.load().dove_groupnorm_finalize_partials(partial.data_ptr(), partial.shape[0], count, gn_eps, L.ptr(_ws(x.device)),
+                                                          L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials")
+        out.gn_stats = (stats, gn_eps)
     return out
+
+
+def groupnorm_stats_of(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """GroupNorm(32) statistics of x: the ones its producing conv already computed (``conv(..., gn_eps=eps)``), else a
+    pass over x."""
+    have = getattr(x, "gn_stats", None)
+    if have is not None and have[1] == eps:
+        return have[0]
+    return groupnorm_stats(x, eps)
 
 
 def linear(x: torch.Tensor, pc: PackedConv, **kw) -> torch.Tensor:

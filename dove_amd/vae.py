@@ -174,7 +174,7 @@ class AutoencoderKLCogVideoX:
         return ops.conv(x, pc, cache=prev, **kw)
 
     def _norm_silu(self, x, name, zq=None):
-        stats = ops.groupnorm_stats(x, self.eps)
+        stats = ops.groupnorm_stats_of(x, self.eps)       # fused into the producing conv's epilogue when it could be
         g, b = self.aff[name]
         if zq is None:
             return ops.groupnorm_apply(x, stats, g, b, silu=True)
@@ -186,11 +186,11 @@ class AutoencoderKLCogVideoX:
 
     def _resnet(self, x, name, cache, zq=None):
         h = self._norm_silu(x, name + ".norm1", zq)
-        h = self._cconv(h, name + ".conv1", cache)
+        h = self._cconv(h, name + ".conv1", cache, gn_eps=self.eps)         # feeds norm2
         h = self._norm_silu(h, name + ".norm2", zq)
         if name + ".conv_shortcut" in self.pc:
             x = ops.conv(x, self.pc[name + ".conv_shortcut"])
-        return self._cconv(h, name + ".conv2", cache, resid=x)
+        return self._cconv(h, name + ".conv2", cache, resid=x, gn_eps=self.eps)   # feeds the next block's norm1 / norm_out
 
     def _downsample(self, x, name, compress_time):
         if compress_time:
@@ -203,7 +203,7 @@ class AutoencoderKLCogVideoX:
             tmode, t_out = (2, 2 * T - 1) if T % 2 == 1 else (1, 2 * T)
         else:
             tmode, t_out = 0, T
-        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1))
+        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps)
 
     def _encoder(self, x, cache):
         h = self._cconv(x, "encoder.conv_in", cache)

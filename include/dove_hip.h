@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 1
+#define DOVE_ABI_VERSION 2
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -58,8 +58,20 @@ typedef struct dove_conv_desc {
   int kt, kh, kw, stride, pad_h, pad_w, up, tmode, act;
   long long ldo, ldr, gate_split;
   void* debug_buf; /* NULL in production; tools/halo8_timing.py passes a device buffer for the phase-timing build */
+  /* optional fused GroupNorm(32) statistics of `out` (the nn.GroupNorm that consumes this conv's output in
+   * CogVideoXResnetBlock3D / CogVideoXSpatialNorm3D): fp32 [dove_conv_gn_partial_rows(d)][32][2] partial (sum, sum of
+   * squares) per group over the bf16-rounded stored values; reduce with dove_groupnorm_finalize_partials.  Only the
+   * kernels for which dove_conv_gn_partial_rows() > 0 produce them; anything else with gn_partial != NULL is an error. */
+  float* gn_partial;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
+/* rows of gn_partial this call would write, 0 if its kernel does not fuse the statistics (caller then runs
+ * dove_groupnorm_stats_bf16 on the output as before) */
+long long dove_conv_gn_partial_rows(const dove_conv_desc* d);
+/* stats [32][2] (mean, rstd) from partial [rows][32][2] (deterministic two-level fp64 combine).  count = elements per
+ * group = npix * C/32; ws >= 256*64 floats of scratch. */
+int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws, float* stats,
+                                     void* stream);
 
 /* nn.GroupNorm(32, C, eps) statistics over one frame-batch [npix, C] (diffusers CogVideoXResnetBlock3D norm1/norm2,
  * encoder.norm_out, and the norm_layer inside CogVideoXSpatialNorm3D).  stats = [32][2] (mean, rstd) fp32.

@@ -22,7 +22,7 @@ def _frame_index(t, tmode):
 
 
 def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, resid=None,
-         gate=None, gate_split=0, act=0, ldo=None, out=None):
+         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None):
     T, H, W, Cx = x.shape
     assert Cx == pc.cin_pad
     ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
@@ -83,6 +83,10 @@ def groupnorm_stats(x, eps):
     mean = xf.mean(dim=(0, 2))
     var = (xf * xf).mean(dim=(0, 2)) - mean * mean
     return torch.stack([mean, 1.0 / torch.sqrt(var.clamp_min(0) + eps)], dim=1).float()
+
+
+def groupnorm_stats_of(x, eps):
+    return groupnorm_stats(x, eps)
 
 
 def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
@@ -228,7 +232,7 @@ def postprocess_u8(video, Fo, Ho, Wo):
     return (v.float() * 255).clamp(0, 255).to(torch.uint8).contiguous()
 
 
-ALL = ["blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+ALL = ["groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

@@ -238,6 +238,37 @@ def test_attention_spiked_rows():
     close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
 
 
+@pytest.mark.parametrize("cin,cout,k,T,H,W,up,resid", [
+    (128, 128, (3, 3, 3), 3, 37, 70, 0, False),      # 4 channels / group, ragged edge tiles
+    (64, 256, (3, 3, 3), 2, 40, 64, 0, True),        # 8 channels / group, two cout tiles, residual epilogue
+    (128, 512, (3, 3, 3), 1, 16, 33, 0, False),      # 16 channels / group, four cout tiles
+    (256, 256, (3, 3), 2, 9, 20, 1, False),          # upsample-fused conv (output 18 x 40)
+    (128, 128, (3, 3, 3), 9, 48, 96, 0, True),       # more tiles than one per workgroup row
+])
+def test_conv_fused_gn_stats(cin, cout, k, T, H, W, up, resid):
+    """GroupNorm(32) statistics fused into the conv3x3_halo4x epilogue == a separate statistics pass over its bf16 output
+    (same tolerance as test_groupnorm_stats_apply: fp32 partials, fp64 combine on both sides)."""
+    pc_c, pc_g = pack(cout, cin, k)
+    x = rnd(T, H, W, cin, seed=2)
+    kw = {}
+    if len(k) == 3:
+        kw["cache"] = rnd(2, H, W, cin, seed=3).cuda()
+    if up:
+        kw.update(up=1, pad=(1, 1))
+    if resid:
+        kw["resid"] = rnd(T, H << up, W << up, cout, seed=4).cuda()
+    y = ops.conv(x.cuda(), pc_g, gn_eps=1e-6, **kw)
+    fused = getattr(y, "gn_stats", None)
+    assert fused is not None, "this shape should dispatch to conv3x3_halo4x and fuse the statistics"
+    ref = ops.groupnorm_stats(y, 1e-6)
+    plain = ops.conv(x.cuda(), pc_g, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, y), "requesting the statistics must not change the conv output"
+    assert torch.allclose(fused[0].cpu(), ref.cpu(), rtol=2e-4, atol=2e-5), (fused[0].cpu() - ref.cpu()).abs().max()
+    assert torch.equal(ops.groupnorm_stats_of(y, 1e-6), fused[0])
+    assert getattr(ops.conv(x.cuda(), pc_g, out=y, **kw), "gn_stats", None) is None    # re-used output drops stale stats
+
+
 def test_conv_and_linear_fullsize_properties():
     """Headline shapes (128->128 3x3x3 conv on 8x720x1280; 18 226 x 3072 -> 9216 linear): determinism, exact
     power-of-two homogeneity (op(2x) == 2 op(x) without bias: every product and partial sum scales exactly), temporal
