@@ -55,6 +55,7 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
 
 
 _profiler = None
+_GN_FUSE = os.environ.get("DOVE_CONV_GN_FUSE", "1") != "0"     # 0: always run the separate GroupNorm statistics pass
 
 
 def set_profiler(records: list | None):
@@ -138,7 +139,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if gate is not None:
         assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
     partial = None
-    if gn_eps is not None and ldo == pc.cout_store:
+    if gn_eps is not None and ldo == pc.cout_store and _GN_FUSE:
         rows = int(L.load().dove_conv_gn_partial_rows(C.byref(d)))
         if rows > 0:
             partial = torch.empty(rows, 64, dtype=torch.float32, device=x.device)
