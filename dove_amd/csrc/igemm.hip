@@ -1216,10 +1216,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
   for (int dw = 0; dw < 3; ++dw) abaseU[dw] = ((2 * wave) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
 
-  if (a.debug & 128) {   // experiment: de-phase the CUs of an XCD so that tile epilogues / halo bursts do not coincide
-    const int idx = (int)(blockIdx.x >> 3) & 31;
-    for (int i = 0; i < idx; ++i) __builtin_amdgcn_s_sleep(80);
-  }
   // ---- prologue (once per workgroup): whole first halo + the first BAHEAD weight taps ----
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
