@@ -13,8 +13,16 @@ xGMI on the GPU box, "gloo" in CPU tests).  SURVEY.md 8(e).
     the last local batch sends its own to rank+1 -- neighbour traffic on ONE xGMI link, in layer order, so ranks
     run as a wavefront skewed by one layer.  GroupNorm statistics are per frame-batch, batches are never split
     across ranks, hence no reduction is needed and results are bit-identical to the single-GPU path.
-    The DiT attends over all tokens of the clip (not frame-separable): moments are all-gathered and the DiT runs
-    replicated; only the VAE (71 % of the FLOPs) is sharded.
+    The DiT attends over all tokens of the clip (not frame-separable): moments are all-gathered and the DiT runs either
+    replicated or (C) sequence/head-parallel.
+
+(C) Ulysses-style DiT for the single-clip mode: the [N, 3072] residual stream is sharded by ROWS (tokens; text rows
+    first) for everything that is row-local - LayerNormZero, the QKV / out / FFN linears with their gated residuals,
+    QK-LayerNorm + RoPE - and by HEADS for attention (48 heads / R ranks): one all_to_all moves Q', K', V^T from
+    "my rows, all heads" to "all rows, my heads" before the flash-attention kernel and one moves its output back, per
+    layer (4 x N x 3072 x 2 B / R per rank and layer over xGMI).  Every row and every head sees exactly the arithmetic of
+    the single-GPU path, so the result is bit-identical (gloo test with 2 and 3 ranks); `process_video_sharded` chains
+    (B) encode -> (C) DiT -> (B) decode.
 """
 from __future__ import annotations
 
@@ -166,3 +174,155 @@ def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0):
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
     vae.last_halo_bytes = cache.bytes_sent
     return ops.ncthw_from_cl(full, vae.config["out_channels"], vae.dtype, **post)[None]
+
+
+# ---- (C) sequence / head parallel DiT -------------------------------------------------------------------
+def _row_bounds(n, world):
+    return [(i * n) // world for i in range(world + 1)]
+
+
+def _a2a(out_splits, inp, in_splits, group):
+    """all_to_all_single on a flat bf16 tensor (moved as bytes: gloo has no bf16 wire type)."""
+    out = torch.empty(sum(out_splits), dtype=inp.dtype, device=inp.device)
+    dist.all_to_all_single(out.view(torch.uint8), inp.contiguous().view(torch.uint8), [2 * v for v in out_splits],
+                           [2 * v for v in in_splits], group=group)
+    return out
+
+
+@torch.no_grad()
+def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
+    """One sample of CogVideoXTransformer3DModel.forward (same arguments as ``tr._forward_one``) with rows sharded over the
+    ranks of ``group`` and attention head-parallel.  Every rank returns the full [T,C,H,W] prediction."""
+    import math
+
+    from . import ops
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    D, heads = tr.D, tr.heads
+    if heads % world:
+        raise ValueError(f"{heads} attention heads do not split over {world} ranks")
+    hloc = heads // world
+    dev = tr.device
+    T, Cc, H, W = hidden.shape
+    p, pt = tr.p, tr.pt
+    hidden = hidden.to(dev).contiguous()
+    text = text.to(dev, torch.bfloat16).contiguous()
+    cos, sin = (r.to(dev, torch.float32).contiguous() for r in rope)
+    Lt = text.shape[0]
+    nv = (T // pt) * (H // p) * (W // p)
+    N = Lt + nv
+    npad = (N + 127) // 128 * 128
+    bounds = _row_bounds(N, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    counts = [bounds[i + 1] - bounds[i] for i in range(world)]
+    nloc = r1 - r0
+    assert nloc > 0, "more ranks than tokens"
+    lt_loc = max(0, min(r1, Lt) - r0)                          # local rows that are text rows (they come first)
+    v0, v1 = max(r0, Lt) - Lt, max(r1, Lt) - Lt                # local video rows [v0, v1)
+    blocks_mod, final_mod = tr._modulation(t)
+
+    hs = torch.empty(nloc, D, dtype=torch.bfloat16, device=dev)
+    if lt_loc:
+        ops.linear(text[r0:r0 + lt_loc].contiguous(), tr.pe_text, out=hs[:lt_loc])
+    if v1 > v0:
+        tok = ops.patchify(hidden, pt, p, tr.pe_proj.cin_pad)
+        ops.linear(tok[v0:v1].contiguous(), tr.pe_proj, out=hs[lt_loc:])
+    cos_l, sin_l = cos[v0:v1].contiguous(), sin[v0:v1].contiguous()
+    if v1 == v0:                                               # a text-only shard still hands a valid table to the kernel
+        cos_l, sin_l = cos[:1].contiguous(), sin[:1].contiguous()
+    nlpad = (nloc + 127) // 128 * 128
+    z = lambda *shp: torch.zeros(*shp, dtype=torch.bfloat16, device=dev)   # noqa: E731
+    Ql, Kl, Vl = z(heads, nlpad, 64), z(heads, nlpad, 64), z(heads, 64, nlpad)
+    Qh, Kh, Vt = z(hloc, npad, 64), z(hloc, npad, 64), z(hloc, 64, npad)
+    qscale = (tr.hd ** -0.5) * math.log2(math.e)
+    blk_in = [c * hloc * 64 for c in counts]                    # elements I receive from each source rank
+
+    def rows_to_heads(loc, transposed):
+        # loc: [heads, nloc, 64] (or [heads, 64, nloc]); destination j gets my rows of ITS heads
+        src = (loc[:, :, :nloc] if transposed else loc[:, :nloc]).contiguous()
+        got = _a2a(blk_in, src.view(-1), [nloc * hloc * 64] * world, group)
+        parts, off = [], 0
+        for c in counts:
+            blk = got[off:off + c * hloc * 64]
+            parts.append(blk.view(hloc, 64, c) if transposed else blk.view(hloc, c, 64))
+            off += c * hloc * 64
+        return torch.cat(parts, dim=2 if transposed else 1)
+
+    for blk, md in zip(tr.blocks, blocks_mod):
+        n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], tr.eps, md["m1"], lt_loc)
+        qkv = ops.linear(n1, blk["qkv"])
+        ops.qkv_post(qkv, nloc, nlpad, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
+                     qscale, 1e-6, Ql, Kl, Vl)
+        Qh[:, :N] = rows_to_heads(Ql, False)
+        Kh[:, :N] = rows_to_heads(Kl, False)
+        Vt[:, :, :N] = rows_to_heads(Vl, True)
+        att = torch.empty(N, hloc * 64, dtype=torch.bfloat16, device=dev)
+        ops.attention(Qh, Kh, Vt, N, npad, hloc, att)
+        # heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
+        back = _a2a([nloc * hloc * 64] * world, att.view(-1), blk_in, group)
+        att_loc = torch.cat([back[i * nloc * hloc * 64:(i + 1) * nloc * hloc * 64].view(nloc, hloc * 64) for i in range(world)],
+                            dim=1).contiguous()
+        ops.linear(att_loc, blk["out"], resid=hs, gate=md["gate1"], gate_split=lt_loc, out=hs)
+        n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], tr.eps, md["m2"], lt_loc, out=n1)
+        f1 = ops.linear(n2, blk["ff1"], act=1)
+        ops.linear(f1, blk["ff2"], resid=hs, gate=md["gate2"], gate_split=lt_loc, out=hs)
+
+    width = tr.proj_out.cout_store
+    o_loc = torch.zeros(0, width, dtype=torch.bfloat16, device=dev)
+    if v1 > v0:
+        xv = hs[lt_loc:].contiguous()
+        xv = ops.layernorm_modulate(xv, tr.norm_final[0], tr.norm_final[1], tr.eps)
+        xv = ops.layernorm_modulate(xv, tr.norm_out[0], tr.norm_out[1], tr.eps, final_mod, 0)
+        o_loc = ops.linear(xv, tr.proj_out)
+    vcounts = [max(bounds[i + 1], Lt) - max(bounds[i], Lt) for i in range(world)]
+    vmax = max(vcounts)
+    pad = torch.zeros(vmax, width, dtype=torch.bfloat16, device=dev)
+    pad[: o_loc.shape[0]] = o_loc
+    bufs = [torch.empty(vmax, width * 2, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, pad.view(torch.uint8), group=group)
+    o = torch.cat([b[:c] for b, c in zip(bufs, vcounts)], dim=0).view(torch.bfloat16)
+    return ops.unpatchify(o.contiguous(), T, Cc, H, W, pt, p, tr.dtype)
+
+
+class _ShardedVAE:
+    def __init__(self, vae, group):
+        self._vae, self._group = vae, group
+        self.device, self.dtype, self.config = vae.device, vae.dtype, vae.config
+
+    def encode(self, x):
+        class _O:
+            latent_dist = encode_sharded(self._vae, x, self._group)
+        return _O()
+
+
+class _ShardedTransformer:
+    def __init__(self, tr, group):
+        self._tr, self._group, self.config = tr, group, tr.config
+
+    def __call__(self, hidden_states, encoder_hidden_states, timestep, image_rotary_emb=None, return_dict=False, **_):
+        ts = [int(v) for v in timestep.reshape(-1).tolist()]
+        outs = [dit_forward_ulysses(self._tr, hidden_states[b], encoder_hidden_states[b], ts[b if len(ts) > 1 else 0],
+                                    image_rotary_emb, self._group) for b in range(hidden_states.shape[0])]
+        return (torch.stack(outs),)
+
+
+class _ShardedPipe:
+    """Duck-typed ``pipe`` whose VAE and transformer run sharded over ``group`` (what process_video touches, nothing more)."""
+
+    def __init__(self, pipe, group):
+        self._pipe, self._group = pipe, group
+        self.vae = _ShardedVAE(pipe.vae, group)
+        self.transformer = _ShardedTransformer(pipe.transformer, group)
+        self.scheduler, self.tokenizer, self.text_encoder = pipe.scheduler, pipe.tokenizer, pipe.text_encoder
+
+    def decode_latents(self, latents, _range01=False):
+        z = latents.permute(0, 2, 1, 3, 4).contiguous()
+        return decode_sharded(self._pipe.vae, z, self._group, _range01=_range01,
+                              _prescale=1.0 / float(self._pipe.vae.config["scaling_factor"]))
+
+
+@torch.no_grad()
+def process_video_sharded(pipe, video, *, group=None, **kw):
+    """``process_video`` on ONE clip with every stage sharded over the ranks of ``group``: halo-exact VAE (B) and
+    sequence/head-parallel DiT (C).  All ranks must pass the same clip and the same ``posterior_noise`` / generator seed;
+    all ranks return the full SR clip, bit-identical to the single-GPU result."""
+    return process_video(_ShardedPipe(pipe, group), video, **kw)
