@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer DiT layers (result marked invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-clip", action="store_true",
+                    help="strong scaling: ONE clip sharded over all ranks (halo-exact VAE + Ulysses DiT, dove_amd.dist."
+                         "process_video_sharded) instead of one clip per rank; not the driver's default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,11 +116,16 @@ def main():
     t_build = time.time() - t_build
 
     up = 4
-    video = prepare_clip(synth_lr_clip(args.frames, args.height // up, args.width // up, seed=42 + rank, device=dev), up)
+    strong = args.single_clip and use_dist
+    video = prepare_clip(synth_lr_clip(args.frames, args.height // up, args.width // up, seed=42 + (0 if strong else rank),
+                                       device=dev), up)
     T = 1 + (args.frames - 1) // 4
     noise = torch.randn(1, 16, T, args.height // 8, args.width // 8, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
 
     def step():
+        if strong:
+            from dove_amd.dist import process_video_sharded
+            return process_video_sharded(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
         return process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
 
     def barrier():
@@ -147,7 +155,7 @@ def main():
     if rank == 0:
         macs = flops.clip_macs(v, t, args.frames, args.height, args.width)
         ms_step = elapsed / args.steps * 1e3
-        value = world * args.steps * args.frames / elapsed
+        value = (1 if strong else world) * args.steps * args.frames / elapsed
         # dominant kernel = conv3x3_halo4x_kernel (VAE 3x3x3 / up-sampling 3x3 convs, ~half of the step).  achieved = sum(algorithmic FLOP)
         # / sum(launch duration) over ITS launches inside the timed region (HIP events on the launch stream).
         def agg(recs):
@@ -182,9 +190,9 @@ def main():
         res = {
             "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"synthetic {args.frames}x{args.height}x{args.width} HR clip (LR {args.height//up}x{args.width//up}, 4x), "
-                                   f"one-step t=399, CogVideoX1.5-5B VAE + {t['num_layers']}-layer DiT random-init, 1 clip per GPU (BASELINE configs[1])",
+                                   f"one-step t=399, CogVideoX1.5-5B VAE + {t['num_layers']}-layer DiT random-init, " + ("ONE clip sharded over all GPUs (BASELINE configs[2])" if strong else "1 clip per GPU (BASELINE configs[1])"),
                        "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15},
             "frames_per_s_per_gpu": value / world,
             "whole_path_tflops_per_gpu": macs["flop"] * args.steps / elapsed / 1e12,
