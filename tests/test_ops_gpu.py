@@ -74,6 +74,10 @@ CONV_CASES = [
     ("c2d_up8", 128, 128, (3, 3), 2, 20, 40, {"up": 1, "pad": (1, 1)}),
     ("c2d_up8_t2", 64, 256, (3, 3), 3, 9, 17, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
     ("c2d_up8_t1", 256, 128, (3, 3), 2, 16, 16, {"up": 1, "pad": (1, 1), "tmode": 1, "t_out": 4}),
+    # persistent one-wave-per-SIMD kernel (conv3x3_halo4x): the shortest K walk it accepts (2 groups = 18 steps per tile,
+    # so the staging streams cross a tile boundary every 18 steps) with more tiles than workgroups, and a kt = 1 conv
+    ("c2d_halo4x_k64_many", 64, 128, (3, 3), 20, 64, 128, {}),
+    ("c2d_halo4x_kt1_resid", 128, 256, (3, 3), 2, 24, 40, {"resid": True}),
 ]
 
 
