@@ -39,3 +39,52 @@ def test_version_and_error_channel(lib):
     # argument validation happens before any HIP call, so it is safe without a GPU
     rc = lib.dove_axpby(None, None, None, 0, 0, 1.0, 1.0, None)
     assert rc == -1 and b"axpby" in lib.dove_last_error()
+
+
+def test_dispatch_rule_mirror(lib):
+    """`dove_conv_gn_partial_rows` is pure host logic (no HIP call): it answers "does this conv dispatch to the kernel that
+    fuses the GroupNorm statistics, and how many partial rows will it write".  The Python mirror of the dispatch rule
+    (dove_amd.ops.kernel_variant, used for reporting in bench.py) must agree with it on every shape class of the VAE."""
+    import ctypes as C
+
+    import torch
+
+    from dove_amd import ops
+
+    def desc(cin, cout, k, T, H, W, up=0, stride=1):
+        pc = ops.PackedConv(torch.empty(0), None, *( (1,) + k if len(k) == 2 else k), cin, (cin + 31) // 32 * 32, cout,
+                            (cout + 31) // 32 * 32)
+        d = L.ConvDesc()
+        d.x = d.w = d.out = 1                                   # never dereferenced by the rows query
+        d.t_in, d.h_in, d.w_in, d.cin = T, H, W, pc.cin_pad
+        d.t_out, d.h_out, d.w_out = T, H << up, W << up
+        if stride == 2:
+            d.h_out, d.w_out = (H + 1 - pc.kh) // 2 + 1, (W + 1 - pc.kw) // 2 + 1
+        d.cout_pad, d.cout_store = pc.cout_pad, pc.cout_store
+        d.kt, d.kh, d.kw, d.stride = pc.kt, pc.kh, pc.kw, stride
+        d.pad_h, d.pad_w = (0, 0) if stride == 2 else (1 if pc.kh == 3 else 0, 1 if pc.kw == 3 else 0)
+        d.up, d.tmode, d.act = up, 0, 0
+        d.ldo = pc.cout_store
+        return pc, d
+
+    cases = [  # cin, cout, k, T, H, W, up, stride, fused?
+        (128, 128, (3, 3, 3), 8, 720, 1280, 0, 1, True),     # encoder / decoder L0 resnet convs
+        (256, 256, (3, 3, 3), 4, 360, 640, 0, 1, True),
+        (512, 512, (3, 3, 3), 2, 90, 160, 0, 1, True),
+        (256, 256, (3, 3), 4, 360, 640, 1, 1, True),         # upsample-fused conv
+        (128, 128, (3, 3), 8, 720, 1280, 0, 2, False),       # stride-2 downsample: generic kernel, separate stats pass
+        (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1, False),     # conv_in (Cin padded 3 -> 32): 8-wave kernel
+        (128, 32, (3, 3, 3), 8, 720, 1280, 0, 1, False),     # conv_out (Cout 3 -> 32)
+        (512, 512, (3, 3, 3), 2, 8, 32, 0, 1, False),        # H < 16: 4-wave halo kernel
+        (3072, 9216, (1, 1, 1), 1, 1, 18226, 0, 1, False),   # a DiT linear
+    ]
+    for cin, cout, k, T, H, W, up, stride, fused in cases:
+        pc, d = desc(cin, cout, k, T, H, W, up, stride)
+        rows = int(lib.dove_conv_gn_partial_rows(C.byref(d)))
+        ph = pw = 1 if stride == 1 and pc.kh == 3 else 0
+        var = ops.kernel_variant(pc, stride, up, ph, pw, 0, 0, None, d.t_out, (d.h_out, d.w_out), (T, H, W))
+        assert (rows > 0) == fused, (cin, cout, k, H, W, rows)
+        assert (var == "conv3x3_halo4x_kernel") == fused, (cin, cout, k, H, W, var)
+        if fused:
+            assert rows == d.t_out * -(-d.h_out // 16) * -(-d.w_out // 32) * 4
+
