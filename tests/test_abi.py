@@ -88,3 +88,15 @@ def test_dispatch_rule_mirror(lib):
         if fused:
             assert rows == d.t_out * -(-d.h_out // 16) * -(-d.w_out // 32) * 4
 
+
+def test_graft_entry_build_version_check(lib):
+    """__graft_entry__.build() checks the loaded library against the header's DOVE_ABI_VERSION (not a literal)."""
+    import inspect
+
+    import __graft_entry__ as g
+    src = inspect.getsource(g.build)
+    assert "DOVE_ABI_VERSION" in src and "== 1" not in src
+    with open(os.path.join(ROOT, "include", "dove_hip.h")) as f:
+        want = int(re.search(r"#define\s+DOVE_ABI_VERSION\s+(\d+)", f.read()).group(1))
+    assert lib.dove_abi_version() == want
+
