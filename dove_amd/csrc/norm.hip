@@ -74,6 +74,28 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// raw fp64 (sum, sumsq) per group from the per-block partials (distributed pieces add these before finalising)
+__global__ __launch_bounds__(256) void gn_sums_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ sums) {
+  const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
+  double acc = 0.0;
+#pragma unroll 8
+  for (int b = part; b < nblocks; b += 4) acc += (double)partial[(long long)b * 64 + j];
+  __shared__ double sh[256];
+  sh[tid] = acc;
+  __syncthreads();
+  if (tid < 64) sums[tid] = (sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]);
+}
+__global__ void gn_finalize_sums_kernel(const double* __restrict__ sums, double count, float eps, float* __restrict__ stats) {
+  const int g = threadIdx.x;
+  if (g < 32) {
+    const double mean = sums[g * 2] / count;
+    double var = sums[g * 2 + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[g * 2] = (float)mean;
+    stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
 // partial rows written by a conv epilogue (one per tile x wave) -> 256 rows for gn_finalize_kernel; fp64, fixed order
 __global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ partial, long long rows,
                                                              float* __restrict__ out) {
@@ -102,6 +124,13 @@ extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long 
   return DOVE_OK;
 }
 
+extern "C" int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream) {
+  DOVE_CHECK_ARG(sums && stats && count > 0, "groupnorm_finalize_sums: bad arguments");
+  hipLaunchKernelGGL(gn_finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, stats);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_sums");
+  return DOVE_OK;
+}
+
 extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws,
                                           int ws_blocks, float* stats, void* stream) {
   DOVE_CHECK_ARG(x && partial_ws && stats, "groupnorm_stats: null pointer");
@@ -120,6 +149,25 @@ extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, f
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, blocks,
                      (double)npix * (double)(C / 32), eps, stats);
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
+  return DOVE_OK;
+}
+
+extern "C" int dove_groupnorm_sums_bf16(const void* x, long long npix, int C, void* partial_ws, int ws_blocks, double* sums,
+                                        void* stream) {
+  DOVE_CHECK_ARG(x && partial_ws && sums, "groupnorm_sums: null pointer");
+  DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_sums: C (%d) must be a power of two in [32,2048]", C);
+  DOVE_CHECK_ARG(npix > 0 && ws_blocks > 0, "groupnorm_sums: empty input");
+  int cpp_log = 0;
+  while ((1 << cpp_log) < C / 8) ++cpp_log;
+  const int nsub = 256 >> cpp_log;
+  long long want = (npix + nsub - 1) / nsub;
+  int blocks = (int)(want < ws_blocks ? want : ws_blocks);
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, npix, C, cpp_log, (float*)partial_ws);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_sums_bf16(partial)");
+  hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, blocks, sums);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_sums_bf16(sums)");
   return DOVE_OK;
 }
 

@@ -11,8 +11,10 @@ xGMI on the GPU box, "gloo" in CPU tests).  SURVEY.md 8(e).
     group per rank; every k_t=3 CausalConv3d of the first local batch receives its 2-frame temporal halo (the last
     two INPUT frames of that conv in the previous rank's last batch) with a point-to-point recv from rank-1, and
     the last local batch sends its own to rank+1 -- neighbour traffic on ONE xGMI link, in layer order, so ranks
-    run as a wavefront skewed by one layer.  GroupNorm statistics are per frame-batch, batches are never split
-    across ranks, hence no reduction is needed and results are bit-identical to the single-GPU path.
+    run as a wavefront skewed by one layer.  GroupNorm statistics are per frame-batch; with at most as many ranks as
+    frame-batches batches are never split, no reduction is needed and results are bit-identical to the single-GPU path.
+    With more ranks (8 GPUs on a 33-frame clip: BASELINE's "frame-chunk = 4") a batch is split into two pieces on a rank
+    pair which combines its GroupNorm sums with one send/recv per norm (``plan_pieces``).
     The DiT attends over all tokens of the clip (not frame-separable): moments are all-gathered and the DiT runs either
     replicated or (C) sequence/head-parallel.
 
@@ -116,17 +118,77 @@ class HaloCache(dict):
             self.bytes_sent += new.numel() * 2
 
 
-def _run_sharded(vae, x_cl, batches, world, rank, group, fn):
-    """Run ``fn(batch_tensor, cache)`` over this rank's contiguous group of frame-batches."""
-    groups = split_batches(batches, world)
-    mine = groups[rank]
-    active = sum(1 for g_ in groups if g_)        # ranks beyond the number of frame-batches own nothing and exchange nothing
+def plan_pieces(batches, world, kind):
+    """Work list per rank for the halo-exact VAE.  With at most as many ranks as frame-batches every rank gets a contiguous
+    group of whole batches (``split_batches``).  With more ranks, batches are split in two PIECES handed to consecutive
+    ranks (a rank pair): the conv halos flow rank -> rank+1 exactly as between batches, the GroupNorm statistics of the
+    batch are combined across the pair, and Upsample3D's first-frame rule is told which piece starts the batch.
+    Split points keep every temporal 2:1 pooling pair inside one piece: px-frame batches (``kind == "enc"``) of 8k(+1)
+    frames split at 4k(+1); latent batches (``kind == "dec"``) of 2 or 3 frames split before the last frame.
+    Returns (per-rank list of dicts {s, e, role, partner, odd}, number of active ranks)."""
+    nb = len(batches)
+    if world <= nb:
+        groups = split_batches(batches, world)
+        return [[dict(s=s, e=e, role=None, partner=None) for s, e in g_] for g_ in groups], sum(1 for g_ in groups if g_)
+    out, r = [[] for _ in range(world)], 0
+    for i, (s, e) in enumerate(batches):
+        n = e - s
+        spare = (world - r) - (nb - i)               # ranks we can still spend on splitting
+        if kind == "enc":
+            head = (n % 2) + 4 * ((n - n % 2) // 8)
+            can = n - (n % 2) >= 8 and (n - n % 2) % 8 == 0
+        else:
+            head = n - 1
+            can = n >= 2
+        if spare >= 1 and can:
+            odd = n % 2 == 1
+            out[r].append(dict(s=s, e=s + head, role="head" if odd else "tail", partner=r + 1, lower=True))
+            out[r + 1].append(dict(s=s + head, e=e, role="tail", partner=r, lower=False))
+            r += 2
+        else:
+            out[r].append(dict(s=s, e=e, role=None, partner=None))
+            r += 1
+    return out, r
+
+
+def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
+    """Run ``fn(tensor, cache)`` over this rank's frame-batches or pieces of frame-batches (``plan_pieces``)."""
+    from . import ops
+    plan, active = plan_pieces(batches, world, kind)
+    mine = plan[rank]
     cache = HaloCache(group, rank, active)
     outs = []
-    for i, (s, e) in enumerate(mine):
+
+    def gsrc(r):
+        return dist.get_global_rank(group, r) if group else r
+
+    for i, pc in enumerate(mine):
         first, last = i == 0, i == len(mine) - 1
         cache.phase = "both" if first and last else ("first" if first else ("last" if last else "mid"))
-        outs.append(fn(x_cl[s:e], cache))
+        if pc["partner"] is not None:
+            partner, lower = pc["partner"], pc["lower"]
+
+            def hook(x, partner=partner, lower=lower):
+                # whole-batch GroupNorm statistics = my piece's (sum, sumsq, count) + the partner's, same fp64 finalize
+                sums = ops.groupnorm_sums(x)
+                cnt = float(x.numel() // 32)
+                mine_msg = torch.cat([sums.reshape(-1), torch.tensor([cnt], dtype=torch.float64, device=sums.device)])
+                theirs = torch.empty_like(mine_msg)
+                if lower:
+                    dist.send(mine_msg, dst=gsrc(partner), group=group)
+                    dist.recv(theirs, src=gsrc(partner), group=group)
+                else:
+                    dist.recv(theirs, src=gsrc(partner), group=group)
+                    dist.send(mine_msg, dst=gsrc(partner), group=group)
+                a, b = (mine_msg, theirs) if lower else (theirs, mine_msg)      # same summation order on both ranks
+                tot = a + b
+                return ops.groupnorm_from_sums(tot[:64].reshape(32, 2).contiguous(), float(tot[64]), vae.eps)
+
+            vae._gn_hook, vae._piece_role = hook, pc["role"]
+        try:
+            outs.append(fn(x_cl[pc["s"]:pc["e"]], cache))
+        finally:
+            vae._gn_hook, vae._piece_role = None, None
     return outs, cache
 
 
@@ -169,7 +231,7 @@ def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0):
     assert z.shape[0] == 1
     z = z.to(vae.device).contiguous()
     z_cl = ops.cl_from_ncthw(z[0], vae.pc["decoder.conv_in"].cin_pad, scale=_prescale)
-    outs, cache = _run_sharded(vae, z_cl, frame_batches(z_cl.shape[0], vae.dec_batch), world, rank, group, vae._decoder)
+    outs, cache = _run_sharded(vae, z_cl, frame_batches(z_cl.shape[0], vae.dec_batch), world, rank, group, vae._decoder, "dec")
     full = _gather_time(outs, group, world, vae.device)          # [F,H,W,4] channels-last
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
     vae.last_halo_bytes = cache.bytes_sent

@@ -207,6 +207,27 @@ def groupnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
     return stats
 
 
+def groupnorm_sums(x: torch.Tensor) -> torch.Tensor:
+    """Raw per-group (sum, sum of squares) of one piece of a frame-batch, fp64 [32,2] (dove_amd.dist adds the pieces)."""
+    L.require_cuda(x)
+    assert x.dtype == torch.bfloat16
+    Cc = x.shape[-1]
+    sums = torch.empty(32, 2, dtype=torch.float64, device=x.device)
+    L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, Cc, L.ptr(_ws(x.device)), 2048, L.ptr(sums),
+                                              L.stream_ptr()), "dove_groupnorm_sums_bf16")
+    return sums
+
+
+def groupnorm_from_sums(sums: torch.Tensor, count: float, eps: float) -> torch.Tensor:
+    """stats [32,2] (mean, rstd) from summed fp64 (sum, sumsq) over ``count`` elements per group."""
+    L.require_cuda(sums)
+    assert sums.dtype == torch.float64 and sums.shape == (32, 2)
+    stats = torch.empty(32, 2, dtype=torch.float32, device=sums.device)
+    L.check(L.load().dove_groupnorm_finalize_sums(L.ptr(sums.contiguous()), float(count), eps, L.ptr(stats), L.stream_ptr()),
+            "dove_groupnorm_finalize_sums")
+    return stats
+
+
 def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
     """y = silu?(GN(x) [* Y + B]) with the SpatialNorm3D table yb [Tz,hz,wz,2C] gathered by nearest resize."""
     L.require_cuda(x, stats, gamma, beta, yb, out)

@@ -173,8 +173,17 @@ class AutoencoderKLCogVideoX:
             cache[name] = new
         return ops.conv(x, pc, cache=prev, **kw)
 
+    # set by dove_amd.dist while a rank runs a PIECE of a frame-batch (the batch is split over a rank pair):
+    #   _gn_hook(x) -> stats over the whole batch (pieces' sums combined);  _piece_role: "head" / "tail" for Upsample3D's
+    #   first-frame rule, which diffusers derives from the batch's frame-count parity
+    _gn_hook = None
+    _piece_role = None
+
     def _norm_silu(self, x, name, zq=None):
-        stats = ops.groupnorm_stats_of(x, self.eps)       # fused into the producing conv's epilogue when it could be
+        if self._gn_hook is not None:
+            stats = self._gn_hook(x)
+        else:
+            stats = ops.groupnorm_stats_of(x, self.eps)   # fused into the producing conv's epilogue when it could be
         g, b = self.aff[name]
         if zq is None:
             return ops.groupnorm_apply(x, stats, g, b, silu=True)
@@ -199,7 +208,11 @@ class AutoencoderKLCogVideoX:
 
     def _upsample(self, x, name, compress_time):
         T = x.shape[0]
-        if compress_time and T > 1:
+        if compress_time and self._piece_role is not None:
+            # a piece of a split frame-batch: the piece that starts an odd-length batch keeps its first frame single,
+            # every other piece doubles all of its frames (also a single-frame piece, which is not a 1-frame batch)
+            tmode, t_out = (2, 2 * T - 1) if self._piece_role == "head" else (1, 2 * T)
+        elif compress_time and T > 1:
             tmode, t_out = (2, 2 * T - 1) if T % 2 == 1 else (1, 2 * T)
         else:
             tmode, t_out = 0, T

@@ -78,6 +78,12 @@ int dove_groupnorm_finalize_partials(const float* partial, long long rows, doubl
  * partial_ws: >= ws_blocks*64 floats of scratch. */
 int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws, int ws_blocks,
                               float* stats, void* stream);
+/* Distributed form (dove_amd.dist, frame-batch split over a rank pair): raw per-group (sum, sum of squares) of one piece
+ * as fp64 [32][2] - the ranks add their pieces' sums (and element counts) and call the finalize below, which is the same
+ * fp64 mean / rstd arithmetic the single-call form ends with. */
+int dove_groupnorm_sums_bf16(const void* x, long long npix, int C, void* partial_ws, int ws_blocks, double* sums,
+                             void* stream);
+int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream);
 /* y = silu?( GN(x) [ * yb[z][0:C] + yb[z][C:2C] ] ): GroupNorm apply, optional SpatialNorm3D conditioning from the
  * [Tz,hz,wz,2C] table conv_y(zq)||conv_b(zq) on the latent grid (z = (tmap[t], h>>sshift, w>>sshift), i.e. the
  * nearest-neighbour resize of zq), optional SiLU. */

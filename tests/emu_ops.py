@@ -85,6 +85,18 @@ def groupnorm_stats(x, eps):
     return torch.stack([mean, 1.0 / torch.sqrt(var.clamp_min(0) + eps)], dim=1).float()
 
 
+def groupnorm_sums(x):
+    Cc = x.shape[-1]
+    xf = x.double().reshape(-1, 32, Cc // 32)
+    return torch.stack([xf.sum(dim=(0, 2)), (xf * xf).sum(dim=(0, 2))], dim=1)
+
+
+def groupnorm_from_sums(sums, count, eps):
+    mean = sums[:, 0] / count
+    var = (sums[:, 1] / count - mean * mean).clamp_min(0)
+    return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=1).float()
+
+
 def groupnorm_stats_of(x, eps):
     return groupnorm_stats(x, eps)
 
@@ -232,7 +244,7 @@ def postprocess_u8(video, Fo, Ho, Wo):
     return (v.float() * 255).clamp(0, 255).to(torch.uint8).contiguous()
 
 
-ALL = ["groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+ALL = ["groupnorm_sums", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

@@ -167,6 +167,20 @@ def test_groupnorm_stats_apply(C, T, H, W):
     close(f"gn_apply_{C}", got, ref)
 
 
+@pytest.mark.parametrize("C,T,H,W", [(128, 5, 20, 24), (512, 3, 6, 5)])
+def test_groupnorm_sums_pieces(C, T, H, W):
+    """Distributed form: raw fp64 (sum, sumsq) of two pieces of a frame-batch, added, finalised == statistics of the batch."""
+    x = (rnd(T, H, W, C, seed=8).float() * 1.3 - 0.4).to(BF).cuda()
+    cut = T // 2 + 1
+    sa, sb = ops.groupnorm_sums(x[:cut].contiguous()), ops.groupnorm_sums(x[cut:].contiguous())
+    got = ops.groupnorm_from_sums(sa + sb, float(x.numel() // 32), 1e-6)
+    ref = ops.groupnorm_stats(x, 1e-6)
+    emu = E.groupnorm_from_sums(E.groupnorm_sums(x.cpu()), float(x.numel() // 32), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.allclose(got.cpu(), ref.cpu(), rtol=2e-4, atol=2e-5)
+    assert torch.allclose(got.cpu(), emu, rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("C,Tf,Tz,hz,wz,sshift", [(128, 5, 3, 4, 6, 2), (512, 3, 3, 5, 4, 0), (256, 4, 2, 3, 5, 1), (128, 9, 3, 2, 3, 3)])
 def test_spatial_norm_apply(C, Tf, Tz, hz, wz, sshift):
     from dove_amd.vae import spatial_norm_tmap
