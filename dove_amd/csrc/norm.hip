@@ -124,6 +124,20 @@ extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long 
   return DOVE_OK;
 }
 
+extern "C" int dove_groupnorm_sums_from_partials(const float* partial, long long rows, void* ws, double* sums, void* stream) {
+  DOVE_CHECK_ARG(partial && ws && sums && rows > 0, "groupnorm_sums_from_partials: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (rows <= 1024) {
+    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, partial, (int)rows, sums);
+  } else {
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (float*)ws);
+    DOVE_CHECK_LAUNCH("dove_groupnorm_sums_from_partials(reduce)");
+    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, 256, sums);
+  }
+  DOVE_CHECK_LAUNCH("dove_groupnorm_sums_from_partials");
+  return DOVE_OK;
+}
+
 extern "C" int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream) {
   DOVE_CHECK_ARG(sums && stats && count > 0, "groupnorm_finalize_sums: bad arguments");
   hipLaunchKernelGGL(gn_finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, stats);

@@ -170,7 +170,7 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
 
             def hook(x, partner=partner, lower=lower):
                 # whole-batch GroupNorm statistics = my piece's (sum, sumsq, count) + the partner's, same fp64 finalize
-                sums = ops.groupnorm_sums(x)
+                sums = ops.groupnorm_sums_of(x)          # from the producing conv's epilogue rows when it wrote any
                 cnt = float(x.numel() // 32)
                 mine_msg = torch.cat([sums.reshape(-1), torch.tensor([cnt], dtype=torch.float64, device=sums.device)])
                 theirs = torch.empty_like(mine_msg)

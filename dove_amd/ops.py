@@ -156,12 +156,14 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if partial is None:
         if getattr(out, "gn_stats", None) is not None:      # a re-used `out` tensor must not keep statistics of old contents
             out.gn_stats = None
+            out.gn_rows = None
     else:
         stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
         count = float(t_out * hw_out[0] * hw_out[1]) * (pc.cout_store // 32)
         L.check(L.load().dove_groupnorm_finalize_partials(partial.data_ptr(), partial.shape[0], count, gn_eps, L.ptr(_ws(x.device)),
                                                           L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials")
         out.gn_stats = (stats, gn_eps)
+        out.gn_rows = partial                                  # raw per-tile sums: dove_amd.dist combines them across a rank pair
     return out
 
 
@@ -215,6 +217,17 @@ def groupnorm_sums(x: torch.Tensor) -> torch.Tensor:
     sums = torch.empty(32, 2, dtype=torch.float64, device=x.device)
     L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, Cc, L.ptr(_ws(x.device)), 2048, L.ptr(sums),
                                               L.stream_ptr()), "dove_groupnorm_sums_bf16")
+    return sums
+
+
+def groupnorm_sums_of(x: torch.Tensor) -> torch.Tensor:
+    """``groupnorm_sums`` of x, from the partial rows its producing conv wrote when there are any (no pass over x)."""
+    rows = getattr(x, "gn_rows", None)
+    if rows is None:
+        return groupnorm_sums(x)
+    sums = torch.empty(32, 2, dtype=torch.float64, device=x.device)
+    L.check(L.load().dove_groupnorm_sums_from_partials(L.ptr(rows), rows.shape[0], L.ptr(_ws(x.device)), L.ptr(sums), L.stream_ptr()),
+            "dove_groupnorm_sums_from_partials")
     return sums
 
 

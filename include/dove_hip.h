@@ -84,6 +84,8 @@ int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, v
 int dove_groupnorm_sums_bf16(const void* x, long long npix, int C, void* partial_ws, int ws_blocks, double* sums,
                              void* stream);
 int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream);
+/* the same raw sums from the partial rows a conv epilogue wrote (dove_conv_desc.gn_partial): no pass over the tensor */
+int dove_groupnorm_sums_from_partials(const float* partial, long long rows, void* ws, double* sums, void* stream);
 /* y = silu?( GN(x) [ * yb[z][0:C] + yb[z][C:2C] ] ): GroupNorm apply, optional SpatialNorm3D conditioning from the
  * [Tz,hz,wz,2C] table conv_y(zq)||conv_b(zq) on the latent grid (z = (tmap[t], h>>sshift, w>>sshift), i.e. the
  * nearest-neighbour resize of zq), optional SiLU. */

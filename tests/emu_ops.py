@@ -91,6 +91,10 @@ def groupnorm_sums(x):
     return torch.stack([xf.sum(dim=(0, 2)), (xf * xf).sum(dim=(0, 2))], dim=1)
 
 
+def groupnorm_sums_of(x):
+    return groupnorm_sums(x)
+
+
 def groupnorm_from_sums(sums, count, eps):
     mean = sums[:, 0] / count
     var = (sums[:, 1] / count - mean * mean).clamp_min(0)
@@ -244,7 +248,7 @@ def postprocess_u8(video, Fo, Ho, Wo):
     return (v.float() * 255).clamp(0, 255).to(torch.uint8).contiguous()
 
 
-ALL = ["groupnorm_sums", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+ALL = ["groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

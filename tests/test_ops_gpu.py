@@ -284,6 +284,9 @@ def test_conv_fused_gn_stats(cin, cout, k, T, H, W, up, resid):
     assert torch.equal(plain, y), "requesting the statistics must not change the conv output"
     assert torch.allclose(fused[0].cpu(), ref.cpu(), rtol=2e-4, atol=2e-5), (fused[0].cpu() - ref.cpu()).abs().max()
     assert torch.equal(ops.groupnorm_stats_of(y, 1e-6), fused[0])
+    s_rows, s_pass = ops.groupnorm_sums_of(y), ops.groupnorm_sums(y)      # raw sums for the distributed pair combine
+    torch.cuda.synchronize()
+    assert torch.allclose(s_rows.cpu(), s_pass.cpu(), rtol=2e-5, atol=1e-2), (s_rows.cpu() - s_pass.cpu()).abs().max()
     assert getattr(ops.conv(x.cuda(), pc_g, out=y, **kw), "gn_stats", None) is None    # re-used output drops stale stats
 
 
