@@ -1,14 +1,24 @@
 #!/bin/bash
 # Build libdove_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+#   build.sh            -> ../libdove_hip.so          (the product library)
+#   build.sh timing     -> ../libdove_hip_timing.so   (-DDOVE_TIMING_BUILD: ablation switches + s_memtime phase logs for
+#                                                      tools/*_timing.py and tools/microbench.py; never loaded by dove_amd)
 set -euo pipefail
 cd "$(dirname "$0")"
+MODE="${1:-product}"
 OUT=../libdove_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+OBJ=.
+EXTRA=""
+if [ "$MODE" = "timing" ]; then OUT=../libdove_hip_timing.so; OBJ=.timing; EXTRA="-DDOVE_TIMING_BUILD"; mkdir -p $OBJ; fi
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $EXTRA"
+SRCS="capi igemm norm attention elementwise"
 pids=()
-for f in capi igemm norm attention elementwise; do
-  hipcc $FLAGS -c $f.hip -o $f.o &
+for f in $SRCS; do
+  hipcc $FLAGS -c $f.hip -o $OBJ/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC capi.o igemm.o norm.o attention.o elementwise.o -o $OUT
+objs=""
+for f in $SRCS; do objs="$objs $OBJ/$f.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
 echo "built $(realpath $OUT)"

@@ -25,6 +25,15 @@
 #include "common.h"
 #include "../../include/dove_hip.h"
 
+// Work-skipping ablation switches and s_memtime phase logs exist ONLY in a -DDOVE_TIMING_BUILD library (built by the
+// tools/*_timing.py helpers into a separate file); in the product build DOVE_DBG() is the constant 0, the branches fold
+// away, no timing instantiation is emitted and no environment variable can make a kernel skip work.
+#ifdef DOVE_TIMING_BUILD
+#define DOVE_DBG(a) ((a).debug)
+#else
+#define DOVE_DBG(a) 0
+#endif
+
 struct IgemmArgs {
   const bf16_t* x;
   const bf16_t* cache;
@@ -41,7 +50,7 @@ struct IgemmArgs {
   long long ldo, ldr;
   long long gate_split;
   int tw_log2, tiles_w, tiles_h, tiles_n;
-  int debug;  // timing ablations only (DOVE_IGEMM_ABLATE): 1 skip A loads, 2 skip B loads, 4 skip MFMA
+  int debug;  // -DDOVE_TIMING_BUILD only (tools/, never the product library): 1 skip A loads, 2 skip B loads, 4 skip MFMA
   float* gn_partial;   // conv3x3_halo4x only: fused GroupNorm(32) partial sums of the stored output, [rows][32][2]
   int cpg_log;         // log2(channels per group) = log2(Cout / 32)
 };
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
     const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)s_fp, (short)0, (int)frame_bytes, 0x00020000);
     const auto srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)s_wp, (short)0, (int)wtap_bytes, 0x00020000);
     const int soff = s_kc * (BK * 2);
-    if (!(a.debug & 1)) {
+    if (!(DOVE_DBG(a) & 1)) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const unsigned voff = (mask[j] & s_tapbit) ? (unsigned)(rowoff[j] + s_tapdelta) : 0x80000000u;
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if (j * 256 + wave * 64 < Cf::B_SLOTS && !(a.debug & 2))
+      if (j * 256 + wave * 64 < Cf::B_SLOTS && !(DOVE_DBG(a) & 2))
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (lds_ptr_t)(smem + BUF * STAGE + A_BYTES + (j * 256 + wave * 64) * 16), 16,
                                                  (unsigned)boff_g[j], soff, 0, 0);
     }
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
       for (int p = 0; p < PT; ++p) xf[p] = *(const bf16x8*)(smem + BUF * STAGE + aoff[p][kk]);
 #pragma unroll
       for (int i = 0; i < CT; ++i) wf[i] = *(const bf16x8*)(smem + BUF * STAGE + A_BYTES + boff[i][kk]);
-      if (a.debug & 4) {
+      if (DOVE_DBG(a) & 4) {
 #pragma unroll
         for (int i = 0; i < CT; ++i)
 #pragma unroll
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
   int h_dt = 0, h_kc = 0;                  // group whose halo is being staged
   auto stage_halo_round = [&](auto rc, int buf) {   // one 4 KB round of group (h_dt, h_kc) into A[buf]
     constexpr int r = decltype(rc)::value;
-    if (a.debug & 1) return;
+    if (DOVE_DBG(a) & 1) return;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
                                              h_kc * ROWB, 0, 0);
@@ -567,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
     constexpr int buf = decltype(bc)::value;
     const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
-    if (!(a.debug & 2)) {
+    if (!(DOVE_DBG(a) & 2)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a)
       for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + (aaddr[p] ^ (kk << 5)));
 #pragma unroll
       for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
-      if (a.debug & 4) {
+      if (DOVE_DBG(a) & 4) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = rest % a.tiles_n; rest /= a.tiles_n;
   int t, twi, thi;
-  if (a.debug & 64) {          // A/B switch: old order (frame slowest)
+  if (DOVE_DBG(a) & 64) {          // A/B switch: old order (frame slowest)
     twi = rest % a.tiles_w; rest /= a.tiles_w;
     thi = rest % a.tiles_h;
     t = rest / a.tiles_h;
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   int h_dt = 0, h_kc = 0;
   auto stage_halo_round = [&](auto rc, int buf) {
     constexpr int r = decltype(rc)::value;
-    if (a.debug & 1) return;
+    if (DOVE_DBG(a) & 1) return;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 512 + wave * 64) * 16), 16, voffA[r],
                                              h_kc * ROWB, 0, 0);
@@ -826,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
     b_slot = (b_slot + 1 == B_RING) ? 0 : b_slot + 1;
     const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
     const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
-    if (!(a.debug & 2))
+    if (!(DOVE_DBG(a) & 2))
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + wave * 64 * 16), 16, voffB,
                                                b_kc * ROWB, 0, 0);
     if (++b_tap == 9) {
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   barrier();
   if (grp == 1) barrier();                      // stagger: group B runs one phase behind group A
-  if ((a.debug & 32) && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger group
+  if ((DOVE_DBG(a) & 32) && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger group
 
   const int abase0 = ((8 * grp + 4 * wm) * HWID + l31) * APITCH + hi * 16;   // byte address of (tile row 4wm, col l31), chunk hi
   // kUp: input halo row of output row (8grp+4wm+p) tap dh = 4grp + 2wm + 1 + ((p+dh-1)>>1); the "-1" case is folded into
@@ -938,13 +947,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
     barrier();
     stamp(2);
     // ---------------- phase 2: MFMAs from registers ----------------
-    if (a.debug & 4) {
+    if (DOVE_DBG(a) & 4) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(wf[kk][p & 1]), "v"(xf[kk][p])); }
     } else {
-    if (!(a.debug & 8)) __builtin_amdgcn_s_setprio(2);
+    if (!(DOVE_DBG(a) & 8)) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -952,7 +961,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a
 #pragma unroll
         for (int p = 0; p < 4; ++p)
           acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
-    if (!(a.debug & 8)) __builtin_amdgcn_s_setprio(0);
+    if (!(DOVE_DBG(a) & 8)) __builtin_amdgcn_s_setprio(0);
     }
     stamp(3);
     barrier();
@@ -2063,8 +2072,10 @@ static bool halo4x_applies(const dove_conv_desc* d) {
     enabled = (e && e[0] == '0') ? 0 : 1;                      // default on; 0 falls back to conv3x3_halo8
     const char* n = getenv("DOVE_IGEMM_NOHALO");
     no_halo = (n && n[0] == '1') ? 1 : 0;
+#ifdef DOVE_TIMING_BUILD
     const char* ab = getenv("DOVE_IGEMM_ABLATE");
     ablate = ab ? atoi(ab) : 0;
+#endif
   }
   if (!enabled || no_halo) return false;
   const bool common = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
@@ -2108,11 +2119,14 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
+  a.debug = 0;
+#ifdef DOVE_TIMING_BUILD
   {
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("DOVE_IGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.debug = ablate;
   }
+#endif
   // tile shape: 8x16 pixels for images, 1x128 for token-major (H == 1) tensors
   int twl = 7;
   if (d->h_out > 1) {
@@ -2143,7 +2157,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       const long long M = (long long)d->t_out * d->h_out * d->w_out;
       const bool g8_ok = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
                          d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 &&
-                         M >= 4096 && (long long)512 * d->cin * 2 < (1ll << 31) && use_g8 && !(a.debug & 127);
+                         M >= 4096 && (long long)512 * d->cin * 2 < (1ll << 31) && use_g8 && !(DOVE_DBG(a) & 127);
       // gemm4x: 256 x 256 tiles, one wave per SIMD, persistent (DOVE_GEMM4X=0 falls back to gemm8 / igemm_fast)
       static int use_g4 = -1;
       if (use_g4 < 0) { const char* e = getenv("DOVE_GEMM4X"); use_g4 = (e && e[0] == '0') ? 0 : 1; }
@@ -2168,7 +2182,8 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
         const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
         DOVE_CHECK_ARG(nt > 0 && nt < (1ll << 31), "conv_igemm: grid too large");
         const unsigned grid4 = nt > pgrid4 ? (unsigned)pgrid4 : (unsigned)nt;
-        if (d->debug_buf && d->act == 0 && !d->gate) {   // TIMING build (tools/gemm4x_timing.py)
+#ifdef DOVE_TIMING_BUILD
+        if (d->debug_buf && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
           static bool attrt = false;
           if (!attrt) {
             (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
@@ -2176,7 +2191,9 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
           }
           a.zero = (const bf16_t*)d->debug_buf;
           hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-        } else if (d->gate) {
+        } else
+#endif
+        if (d->gate) {
           DOVE_CHECK_ARG(d->act == 0, "conv_igemm: gate with activation is not a path of the reference");
           hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
         } else if (d->act == 1) {
@@ -2208,7 +2225,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     const bool halo_up_ok = d->kt == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 1 && d->pad_h == 1 && d->pad_w == 1 &&
                             d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in &&
                             d->h_out >= 16 && d->w_out >= 32 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) && !no_halo &&
-                            !(a.debug & 7);
+                            !(DOVE_DBG(a) & 7);
     static int halo4x = -1, h4cfg = 0;
     if (halo4x < 0) {
       const char* e = getenv("DOVE_CONV_HALO4X");
@@ -2218,7 +2235,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     }
     DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
                    "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
-    (void)halo4x;
+    (void)halo4x; (void)h4cfg;
     if (halo4x_applies(d)) {
       a.gn_partial = d->gn_partial;
       a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
@@ -2227,13 +2244,17 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       a.tiles_n = d->cout_pad / 128;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
+#ifdef DOVE_TIMING_BUILD
       const bool timing = h4cfg == 9 && d->debug_buf;
       if (timing) a.gate = (const float*)d->debug_buf;
+#endif
       static bool attr4 = false;
       if (!attr4) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+#ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+#endif
         attr4 = true;
       }
       // persistent: one workgroup per CU walks its share of the tiles (DOVE_HALO4X_GRID=0: one workgroup per tile)
@@ -2246,8 +2267,11 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
         pgrid = ge ? atoi(ge) : cus;
       }
       const unsigned grid = (pgrid > 0 && g4 > pgrid) ? (unsigned)pgrid : (unsigned)g4;
+#ifdef DOVE_TIMING_BUILD
       if (timing && !d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      else if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else
+#endif
+      if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
       return DOVE_OK;
@@ -2271,7 +2295,9 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       static bool attr8 = false;
       if (!attr8) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+#ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+#endif
         (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
         attr8 = true;
       }
@@ -2280,11 +2306,13 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
       a.tiles_n = d->cout_pad / 128;
       const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
-      if (d->debug_buf) {   // timing build: per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
+#ifdef DOVE_TIMING_BUILD
+      if (d->debug_buf) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
         a.gate = (const float*)d->debug_buf;
         hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
         a.gate = nullptr;
       } else
+#endif
       hipLaunchKernelGGL((conv3x3_halo8_kernel<false, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
       return DOVE_OK;

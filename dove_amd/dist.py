@@ -208,6 +208,46 @@ def _gather_time(parts, group, world, device):
     return torch.cat([b[: int(s[0])] for b, s in zip(bufs, shape)], dim=0).view(torch.bfloat16)
 
 
+def _bcast_from_first(t, group):
+    """Every rank ends up with rank 0's tensor (bf16 moves as bytes: gloo has no bf16 wire type)."""
+    src = dist.get_global_rank(group, 0) if group else 0
+    wire = t.contiguous()
+    dist.broadcast(wire.view(torch.uint8) if wire.dtype == torch.bfloat16 else wire, src=src, group=group)
+    return wire
+
+
+class _SharedPosterior(DiagonalGaussianDistribution):
+    """Posterior of the sharded encode.  Every rank patchifies only ITS rows of the sampled latent, so all ranks must
+    hold the same sample: a draw from each rank's own device RNG (what ``sample()`` does by default, like diffusers) would
+    silently mix shards of different samples.  The noise - injected, drawn from ``generator`` or from the global RNG - is
+    therefore always rank 0's, broadcast over the group."""
+
+    def __init__(self, moments_cl, latent_channels, dtype, group):
+        super().__init__(moments_cl, latent_channels, dtype)
+        self._group = group
+
+    def sample(self, generator=None, noise=None):
+        T, h, w, _ = self._m[0].shape
+        if noise is None:
+            noise = torch.randn(len(self._m), self._L, T, h, w, generator=generator, device=self._m[0].device, dtype=self._dtype)
+        noise = _bcast_from_first(noise.to(self._m[0].device), self._group)
+        return super().sample(noise=noise)
+
+
+class _SharedScheduler:
+    """``pipe.scheduler`` for the sharded path: the `--noise_step` pre-noising draws eps with torch.randn_like on every
+    rank (ref :449-457); rank 0's draw is the one all ranks use."""
+
+    def __init__(self, sched, group):
+        self._sched, self._group, self.config = sched, group, sched.config
+
+    def get_velocity(self, *a, **k):
+        return self._sched.get_velocity(*a, **k)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        return self._sched.add_noise(original_samples, _bcast_from_first(noise, self._group), timesteps)
+
+
 @torch.no_grad()
 def encode_sharded(vae, x, group=None):
     """vae.encode with frame-batches sharded over ranks + temporal halo exchange.  Every rank returns the full
@@ -220,7 +260,7 @@ def encode_sharded(vae, x, group=None):
     outs, cache = _run_sharded(vae, x_cl, frame_batches(x_cl.shape[0], vae.enc_batch), world, rank, group, vae._encoder)
     moments = _gather_time(outs, group, world, vae.device)
     vae.last_halo_bytes = cache.bytes_sent
-    return DiagonalGaussianDistribution([moments], vae.lat, vae.dtype)
+    return _SharedPosterior([moments], vae.lat, vae.dtype, group)
 
 
 @torch.no_grad()
@@ -374,7 +414,8 @@ class _ShardedPipe:
         self._pipe, self._group = pipe, group
         self.vae = _ShardedVAE(pipe.vae, group)
         self.transformer = _ShardedTransformer(pipe.transformer, group)
-        self.scheduler, self.tokenizer, self.text_encoder = pipe.scheduler, pipe.tokenizer, pipe.text_encoder
+        self.scheduler = _SharedScheduler(pipe.scheduler, group)
+        self.tokenizer, self.text_encoder = pipe.tokenizer, pipe.text_encoder
 
     def decode_latents(self, latents, _range01=False):
         z = latents.permute(0, 2, 1, 3, 4).contiguous()
@@ -385,6 +426,7 @@ class _ShardedPipe:
 @torch.no_grad()
 def process_video_sharded(pipe, video, *, group=None, **kw):
     """``process_video`` on ONE clip with every stage sharded over the ranks of ``group``: halo-exact VAE (B) and
-    sequence/head-parallel DiT (C).  All ranks must pass the same clip and the same ``posterior_noise`` / generator seed;
-    all ranks return the full SR clip, bit-identical to the single-GPU result."""
+    sequence/head-parallel DiT (C).  All ranks must pass the same clip; random draws (posterior sample, optional
+    pre-noising) are rank 0's, broadcast, so the ranks stay consistent whatever their RNG states.  All ranks return the
+    full SR clip, bit-identical to the single-GPU result given rank 0's noise."""
     return process_video(_ShardedPipe(pipe, group), video, **kw)

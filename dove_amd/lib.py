@@ -58,6 +58,18 @@ PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)])}
 
 
+def use_timing_build():
+    """tools/ only: bind the separate -DDOVE_TIMING_BUILD library (ablation switches, s_memtime phase logs; built by
+    ``dove_amd/csrc/build.sh timing``) instead of the product library.  Must be called before the first ``load()``."""
+    global LIB_PATH
+    assert _lib is None, "use_timing_build() must precede the first load()"
+    path = os.path.join(_HERE, "libdove_hip_timing.so")
+    if not os.path.exists(path):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh"), "timing"])
+    LIB_PATH = path
+
+
 def load():
     """Load libdove_hip.so (built by ``__graft_entry__.build()`` / dove_amd/csrc/build.sh)."""
     global _lib
@@ -101,8 +113,17 @@ def dt_code(t: torch.Tensor) -> int:
 
 
 def require_cuda(*tensors):
+    cur = None
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError("dove_amd ops need tensors on the HIP device (`cuda`); there is no CPU path")
+        if t is not None:
+            # kernels launch on the CURRENT device's stream (stream_ptr) and the library keeps per-device state keyed by
+            # hipGetDevice(): a tensor of another GPU would be dereferenced there
+            if cur is None:
+                cur = torch.cuda.current_device()
+            if t.device.index != cur:
+                raise RuntimeError(f"dove_amd op called with a tensor on cuda:{t.device.index} while cuda:{cur} is current; "
+                                   "wrap the call in torch.cuda.device(tensor.device)")
         if t is not None and not t.is_contiguous():
             raise RuntimeError("dove_amd ops need contiguous tensors")

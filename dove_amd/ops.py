@@ -162,7 +162,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         count = float(t_out * hw_out[0] * hw_out[1]) * (pc.cout_store // 32)
         L.check(L.load().dove_groupnorm_finalize_partials(partial.data_ptr(), partial.shape[0], count, gn_eps, L.ptr(_ws(x.device)),
                                                           L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials")
-        out.gn_stats = (stats, gn_eps)
+        out.gn_stats = (stats, gn_eps, out._version)           # torch's in-place counter: a later torch write voids them
         out.gn_rows = partial                                  # raw per-tile sums: dove_amd.dist combines them across a rank pair
     return out
 
@@ -171,7 +171,7 @@ def groupnorm_stats_of(x: torch.Tensor, eps: float) -> torch.Tensor:
     """GroupNorm(32) statistics of x: the ones its producing conv already computed (``conv(..., gn_eps=eps)``), else a
     pass over x."""
     have = getattr(x, "gn_stats", None)
-    if have is not None and have[1] == eps:
+    if have is not None and have[1] == eps and have[2] == x._version:
         return have[0]
     return groupnorm_stats(x, eps)
 
@@ -370,6 +370,9 @@ def blend_edge(a: torch.Tensor, b: torch.Tensor, extent: int, axis: int) -> torc
     assert a.dtype == b.dtype == torch.bfloat16 and a.shape[0] == b.shape[0] and a.shape[3] == b.shape[3]
     L.check(L.load().dove_blend_edge_bf16(L.ptr(a), L.ptr(b), b.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2],
                                           b.shape[3], extent, axis, L.stream_ptr()), "dove_blend_edge_bf16")
+    if getattr(b, "gn_stats", None) is not None:             # b changed in place: statistics its producing conv attached are stale
+        b.gn_stats = None
+        b.gn_rows = None
     return b
 
 

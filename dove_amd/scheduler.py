@@ -22,9 +22,11 @@ class CogVideoXDPMScheduler:
         else:
             raise NotImplementedError(f"beta_schedule {sched}")
         ac = torch.cumprod(1.0 - betas, dim=0)
-        s = c.get("snr_shift_scale", 1.0)
+        # absent keys take diffusers' CogVideoXDPMScheduler class defaults (snr_shift_scale 3.0, rescale_betas_zero_snr False);
+        # the CogVideoX1.5 / DOVE scheduler_config.json states both explicitly (1.0 / true; dove_amd.config.SCHEDULER_CONFIG)
+        s = c.get("snr_shift_scale", 3.0)
         ac = ac / (s + (1 - s) * ac)
-        if c.get("rescale_betas_zero_snr", True):
+        if c.get("rescale_betas_zero_snr", False):
             r = ac.sqrt()
             r0, rT = r[0].clone(), r[-1].clone()
             r = (r - rT) * r0 / (r0 - rT)
@@ -46,6 +48,8 @@ class CogVideoXDPMScheduler:
         a = self.alphas_cumprod.to(dtype)[ts.pop()]
         return float(a ** 0.5), float((1 - a) ** 0.5)
 
+    # a*x + b*y is ONE fp32 FMA chain rounded once to the sample dtype; diffusers rounds each bf16 product and the sum
+    # separately (<= 1 bf16 ulp apart; covered by the stage tolerances of tests/test_parity_gpu.py)
     def get_velocity(self, sample, noise, timesteps):
         sa, s1 = self._coeffs(timesteps, sample.dtype)
         return ops.axpby(noise.contiguous(), sample.contiguous(), sa, -s1)

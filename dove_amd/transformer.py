@@ -145,14 +145,17 @@ class CogVideoXTransformer3DModel:
     # ---- forward -----------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, hidden_states, encoder_hidden_states, timestep, timestep_cond=None, ofs=None,
-                 image_rotary_emb=None, attention_kwargs=None, return_dict: bool = True):
+                 image_rotary_emb=None, attention_kwargs=None, return_dict: bool = True, _trace: dict | None = None):
+        """``_trace`` (parity tests): filled with the residual stream [N, D] after the embedding (``embed``) and after
+        every block (``block{i}``), like the oracle's trace."""
         if image_rotary_emb is None:
             raise ValueError("image_rotary_emb is required (use_rotary_positional_embeddings=True)")
         B = hidden_states.shape[0]
         ts = [int(v) for v in timestep.reshape(-1).tolist()]
         if len(ts) == 1:
             ts = ts * B
-        outs = [self._forward_one(hidden_states[b], encoder_hidden_states[b], ts[b], image_rotary_emb) for b in range(B)]
+        outs = [self._forward_one(hidden_states[b], encoder_hidden_states[b], ts[b], image_rotary_emb, _trace if b == 0 else None)
+                for b in range(B)]
         out = torch.stack(outs)
         if return_dict:
             class _O:  # Transformer2DModelOutput-like
@@ -162,7 +165,7 @@ class CogVideoXTransformer3DModel:
 
     forward = __call__
 
-    def _forward_one(self, hidden, text, t, rope):
+    def _forward_one(self, hidden, text, t, rope, trace=None):
         D, Lh = self.D, self.heads
         T, Cc, H, W = hidden.shape
         p, pt = self.p, self.pt
@@ -181,7 +184,9 @@ class CogVideoXTransformer3DModel:
         ops.linear(text, self.pe_text, out=hs[:Lt])
         ops.linear(tok, self.pe_proj, out=hs[Lt:])
         qscale = (self.hd ** -0.5) * math.log2(math.e)
-        for blk, md in zip(self.blocks, blocks_mod):
+        if trace is not None:
+            trace["embed"] = hs.clone()
+        for bi, (blk, md) in enumerate(zip(self.blocks, blocks_mod)):
             n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], self.eps, md["m1"], Lt)
             qkv = ops.linear(n1, blk["qkv"])
             ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
@@ -191,6 +196,8 @@ class CogVideoXTransformer3DModel:
             n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
             f1 = ops.linear(n2, blk["ff1"], act=1)
             ops.linear(f1, blk["ff2"], resid=hs, gate=md["gate2"], gate_split=Lt, out=hs)
+            if trace is not None:
+                trace[f"block{bi}"] = hs.clone()
         xv = hs[Lt:]
         xv = ops.layernorm_modulate(xv, self.norm_final[0], self.norm_final[1], self.eps)
         xv = ops.layernorm_modulate(xv, self.norm_out[0], self.norm_out[1], self.eps, final_mod, 0)

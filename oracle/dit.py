@@ -59,9 +59,9 @@ def alphas_cumprod(cfg: dict) -> torch.Tensor:
     else:
         raise NotImplementedError(sched)
     ac = torch.cumprod(1.0 - betas, dim=0)
-    s = cfg.get("snr_shift_scale", 1.0)
+    s = cfg.get("snr_shift_scale", 3.0)            # diffusers class defaults for absent keys (DOVE's config states 1.0 / true)
     ac = ac / (s + (1 - s) * ac)
-    if cfg.get("rescale_betas_zero_snr", True):
+    if cfg.get("rescale_betas_zero_snr", False):
         r = ac.sqrt()
         r0, rT = r[0].clone(), r[-1].clone()
         r = (r - rT) * r0 / (r0 - rT)
@@ -86,11 +86,28 @@ def timestep_sinusoid(t: torch.Tensor, dim: int, flip_sin_to_cos=True, freq_shif
     return emb
 
 
+class WeightView:
+    """``weights[name].to(cpu, dtype)`` on access: the source may be a plain dict or a lazily generated mapping
+    (dove_amd.weights.LazyStateDict), so a 42-layer DiT never has to be resident in host memory."""
+
+    def __init__(self, src, dtype):
+        self.src, self.dtype = src, dtype
+
+    def __getitem__(self, k):
+        return self.src[k].to("cpu", self.dtype)
+
+    def get(self, k, default=None):
+        return self[k] if k in self.src else default
+
+    def __contains__(self, k):
+        return k in self.src
+
+
 class OracleDiT:
-    def __init__(self, cfg: dict, weights: dict, dtype=torch.float32):
+    def __init__(self, cfg: dict, weights, dtype=torch.float32):
         self.cfg = cfg
         self.dtype = dtype
-        self.w = {k: v.to(dtype) for k, v in weights.items()}
+        self.w = WeightView(weights, dtype)
         self.heads = cfg["num_attention_heads"]
         self.hd = cfg["attention_head_dim"]
         self.D = self.heads * self.hd
@@ -164,13 +181,24 @@ class OracleDiT:
 
 # ---- the whole op ------------------------------------------------------------------------------
 @torch.no_grad()
+def add_noise(ac, original, noise, t: int):
+    """CogVideoXDPMScheduler.add_noise: sqrt(a)*x + sqrt(1-a)*eps, alpha cast to the sample dtype before the sqrt
+    (/root/reference/inference_script.py:449-457)."""
+    a = ac.to(original.dtype)[t]
+    return (a ** 0.5) * original + ((1 - a) ** 0.5) * noise
+
+
+@torch.no_grad()
 def process_video(vae, dit, sched_cfg, video, text, noise, sr_noise_step=399, scaling_factor=0.7,
-                  trace: dict | None = None):
+                  trace: dict | None = None, noise_step: int = 0, add_noise_eps=None):
     """Restatement of /root/reference/inference_script.py:394-503 on oracle modules, with the VAE
-    posterior noise injected (the reference draws it from the global RNG).  video [B,3,F,H,W] in
+    posterior noise injected (the reference draws it from the global RNG; ``add_noise_eps`` [B,T,C,h,w] is the
+    injected draw of the optional ``--noise_step`` pre-noising, ref :449-457).  video [B,3,F,H,W] in
     [-1,1] -> [B,3,F,H,W] in [0,1]."""
     dt = vae.dtype
     params = vae.encode(video)
+    if trace is not None:
+        trace["moments"] = params.clone()
     latent = vae.sample(params, noise) * scaling_factor
     pt = dit.pt
     ncopy = latent.shape[2] % pt
@@ -178,6 +206,8 @@ def process_video(vae, dit, sched_cfg, video, text, noise, sr_noise_step=399, sc
     assert latent.shape[2] % pt == 0
     B, C, T, h, w = latent.shape
     latent = latent.permute(0, 2, 1, 3, 4)
+    if noise_step != 0:
+        latent = add_noise(alphas_cumprod(sched_cfg), latent, add_noise_eps.to(dt), noise_step)
     rope = rope_3d(dit.hd, (T + pt - 1) // pt, h // dit.p, w // dit.p)
     ts = torch.full((B,), sr_noise_step, dtype=torch.long)
     v = dit.forward(latent, text.to(dt).expand(B, -1, -1), ts, rope, trace)
@@ -190,4 +220,6 @@ def process_video(vae, dit, sched_cfg, video, text, noise, sr_noise_step=399, sc
         trace["x0"] = x0.clone()
     z = x0.permute(0, 2, 1, 3, 4) * (1.0 / scaling_factor)
     out = vae.decode(z)
+    if trace is not None:
+        trace["decoded"] = out.clone()              # pre-clamp decoder output in ~[-1,1]
     return (out * 0.5 + 0.5).clamp(0.0, 1.0)

@@ -32,7 +32,8 @@ class OracleVAE:
     def __init__(self, cfg: dict, weights: dict, dtype=torch.float32):
         self.cfg = cfg
         self.dtype = dtype
-        self.w = {k: v.to(dtype) for k, v in weights.items()}
+        from .dit import WeightView
+        self.w = WeightView(weights, dtype)
         self.groups = cfg.get("norm_num_groups", 32)
         self.eps = cfg.get("norm_eps", 1e-6)
         self.boc = list(cfg["block_out_channels"])

@@ -12,9 +12,51 @@ import math
 import torch
 import torch.nn.functional as F
 
-from dove_amd.ops import PackedConv, pack_conv  # noqa: F401  (pure torch packing, shared)
+from dataclasses import dataclass
 
 BF = torch.bfloat16
+
+
+@dataclass
+class EmuConv:
+    """The emulation's OWN weight container: the bf16-rounded weight in its natural Conv3d layout [cout, cin, kt, kh, kw]
+    (no tap-major repacking, no channel padding) - deliberately independent of dove_amd.ops.pack_conv, so a packing bug
+    in the product (tap order, padded rows, transposed operands) shows up in every operator case of tests/test_ops_gpu.py.
+    Only the channel-padding RULE of the interface (how many channels the activation tensors carry) is restated."""
+    wn: torch.Tensor
+    bias: torch.Tensor | None
+    kt: int
+    kh: int
+    kw: int
+    cin: int
+    cin_pad: int
+    cout: int
+    cout_pad: int
+
+    @property
+    def cout_store(self) -> int:
+        return (self.cout + 3) // 4 * 4
+
+
+def pack_conv(weight, bias, device="cpu"):
+    w = weight.detach().float()
+    if w.dim() == 2:
+        w = w[:, :, None, None, None]
+    elif w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    cin_pad = cin if (cin > 32 and cin % 64 == 0) else (cin + 31) // 32 * 32      # include/dove_hip.h: activation channel rule
+    cout_pad = (cout + 31) // 32 * 32
+    return EmuConv(w.to(BF).float(), None if bias is None else bias.detach().float(), kt, kh, kw, cin, cin_pad, cout, cout_pad)
+
+
+def _natural(pc):
+    """(weight [cout, cin, kt, kh, kw] fp32, bias [cout] fp32 | None) of either container.  A product PackedConv (CPU
+    host-graph tests run the product's packer) is read back through its documented layout [tap][cout_pad][cin_pad]."""
+    if isinstance(pc, EmuConv):
+        return pc.wn, pc.bias
+    w = pc.w.float().view(pc.kt, pc.kh, pc.kw, pc.cout_pad, pc.cin_pad).permute(3, 4, 0, 1, 2)[: pc.cout, : pc.cin]
+    return w, (None if pc.bias is None else pc.bias.float()[: pc.cout])
 
 
 def _frame_index(t, tmode):
@@ -31,7 +73,10 @@ def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=
     if hw_out is None:
         hw_out = (H << up, W << up) if stride == 1 else ((H + 1 - pc.kh) // stride + 1, (W + 1 - pc.kw) // stride + 1)
     ldo = pc.cout_store if ldo is None else ldo
-    xf = x.float()
+    wn, bn = _natural(pc)
+    xf = x.float()[..., : pc.cin]
+    if cache is not None:
+        cache = cache[..., : pc.cin]
     if pc.kt > 1:
         k = pc.kt - 1
         front = cache.float() if cache is not None else xf[:1].expand(k, -1, -1, -1)
@@ -45,14 +90,13 @@ def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=
     need_h = (hw_out[0] - 1) * stride + pc.kh - ph
     need_w = (hw_out[1] - 1) * stride + pc.kw - pw
     xp = F.pad(xf.permute(3, 0, 1, 2)[None], (pw, max(need_w - We, 0), ph, max(need_h - He, 0)))
-    w = pc.w.float().view(pc.kt, pc.kh, pc.kw, pc.cout_pad, pc.cin_pad).permute(3, 4, 0, 1, 2)
-    y = F.conv3d(xp, w, None, stride=(1, stride, stride))[0]            # [cout_pad, T, H, W]
+    y = F.conv3d(xp, wn, None, stride=(1, stride, stride))[0]           # [cout, T, H, W]
     y = y[:, :t_out, : hw_out[0], : hw_out[1]].permute(1, 2, 3, 0)
-    if pc.bias is not None:
-        y = y + pc.bias.float()
+    if bn is not None:
+        y = y + bn
     if act == 1:
         y = F.gelu(y, approximate="tanh")
-    y = y[..., : pc.cout_store]
+    y = F.pad(y, (0, pc.cout_store - pc.cout))                           # channels cout..cout_store of the output are zero
     if resid is not None:
         r = resid.float().reshape(t_out, hw_out[0], hw_out[1], -1)[..., : pc.cout_store]
         if gate is not None:

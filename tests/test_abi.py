@@ -100,3 +100,13 @@ def test_graft_entry_build_version_check(lib):
         want = int(re.search(r"#define\s+DOVE_ABI_VERSION\s+(\d+)", f.read()).group(1))
     assert lib.dove_abi_version() == want
 
+
+
+def test_product_library_has_no_work_skipping_switches():
+    """ablation switches (skip A/B loads, skip MFMA) and s_memtime timing instantiations live only in the
+    separate -DDOVE_TIMING_BUILD library; the product .so must not even contain the environment variable's name."""
+    import os
+    from dove_amd import lib as L
+    blob = open(L.LIB_PATH, "rb").read()
+    assert b"DOVE_IGEMM_ABLATE" not in blob
+    assert not os.path.basename(L.LIB_PATH).endswith("_timing.so")

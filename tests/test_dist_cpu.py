@@ -49,6 +49,22 @@ def _worker(rank, world, port, mode, q):
                                           generator=torch.Generator().manual_seed(100 + i))
                     tiling.stitch(ref, wc2, piece.float(), reg)
                 q.put(("farm", bool(torch.equal(out, ref)), int(wc.min()), int(wc.max())))
+        elif mode == "rng":
+            # no injected noise and a DIFFERENT global RNG state on every rank (what a real multi-process launch has): the
+            # sharded op must still run ONE consistent sample - rank 0's draws, broadcast (posterior sample AND --noise_step eps)
+            from dove_amd.inference import process_video
+            video = (torch.rand(1, 3, 17, 16, 32, generator=g) * 2 - 1).to(torch.bfloat16)
+            torch.manual_seed(1000 + rank)
+            out = ddist.process_video_sharded(pipe, video, empty_prompt_embedding=text, noise_step=100)
+            outs = [torch.empty(out.shape, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(outs, out.float())
+            if rank == 0:
+                torch.manual_seed(1000)
+                ref = process_video(pipe, video, empty_prompt_embedding=text, noise_step=100)
+                torch.manual_seed(1001)
+                other = process_video(pipe, video, empty_prompt_embedding=text, noise_step=100)
+                q.put(("rng", all(bool(torch.equal(o, outs[0])) for o in outs), float((out.float() - ref.float()).abs().max()),
+                       float((out.float() - other.float()).abs().max())))
         elif mode.startswith("ulysses"):
             F = 17
             video = (torch.rand(1, 3, F, 16, 32, generator=g) * 2 - 1).to(torch.bfloat16)
@@ -132,6 +148,17 @@ def test_ulysses_dit_and_sharded_process_video(world):
     assert dit_equal, "sequence/head-parallel DiT differs from the single-process forward"
     assert e2e_equal, "fully sharded process_video differs from the single-process result"
     assert shape == (1, 3, 17, 16, 32)
+
+
+def test_sharded_op_shares_rank0_random_draws():
+    """every rank has its own RNG state; the sharded op must not mix shards of different posterior samples."""
+    res = dict((r[0], r[1:]) for r in _run(2, "rng", 0))
+    all_same, err_rank0_draws, err_rank1_draws = res["rng"]
+    assert all_same, "ranks returned different clips"
+    # vs the single-process run seeded like rank 0: equal up to the CPU emulation's shape-dependent summation order (torch's
+    # CPU GEMM blocks a row shard differently from the full matrix; <= 2 bf16 ulp of the [0,1] output) - and far from the run
+    # seeded like rank 1, i.e. the draws really are rank 0's
+    assert err_rank0_draws <= 2 ** -4 and err_rank1_draws > 4 * max(err_rank0_draws, 2 ** -6), (err_rank0_draws, err_rank1_draws)
 
 
 @pytest.mark.parametrize("world", [8, 6, 5])

@@ -2,7 +2,10 @@
 posterior noise, text embedding).  Model = CogVideoX1.5-5B widths with 2 DiT layers so the oracle runs in
 seconds; every kernel shape class of the full model is exercised.
 Tolerance (floating point, stated): PSNR(HIP-bf16, oracle-fp32) must be >= PSNR(oracle-bf16-emulation of the
-reference's rounding points, oracle-fp32) - 0.05 dB, and > 35 dB absolute."""
+reference's rounding points, oracle-fp32) - 0.05 dB, and > 35 dB absolute.  Random-init weights saturate ~40 % of the
+[0,1] output, so the PRE-CLAMP decoder output is gated as well (RMS-relative error, hip <= 1.25 x what the reference's
+own bf16 run loses); per-stage gates are RMS-relative, not max-norm.  Full depth (42 layers) and the configs[0] size:
+tests/test_parity_gpu.py."""
 import os
 
 import pytest
@@ -20,6 +23,11 @@ pytestmark = pytest.mark.gpu
 def psnr(a, b):
     mse = ((a.float() - b.float()) ** 2).flatten(3).mean(-1)      # per frame
     return float((10 * torch.log10(1.0 / (mse + 1e-8))).mean())
+
+
+def rms_rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt().clamp_min(1e-20))
 
 
 @pytest.fixture(scope="module")
@@ -55,17 +63,67 @@ def test_process_video_psnr(setup, F, H, W):
     noise = torch.randn(1, 16, T, H // 8, W // 8, generator=torch.Generator().manual_seed(1))
     got = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda()).float().cpu()
     torch.cuda.synchronize()
-    ref32 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise)
+    tr32 = {}
+    ref32 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise, trace=tr32)
     assert got.shape == ref32.shape == (1, 3, F, H, W)
     p_got = psnr(got, ref32)
-    print(f"[e2e {F}x{H}x{W}] PSNR(hip, fp32 oracle) = {p_got:.2f} dB")
+    sat = float(((ref32 <= 0) | (ref32 >= 1)).float().mean())
+    # the same computation up to the decoder output BEFORE the clamp (no saturated pixels hiding error)
+    lat = pipe.vae.encode(video.cuda().to(torch.bfloat16)).latent_dist.sample(noise=noise.cuda()) * 0.7
+    ncopy = lat.shape[2] % 2
+    lat = torch.cat([lat[:, :, :1].repeat(1, 1, ncopy, 1, 1), lat], dim=2).permute(0, 2, 1, 3, 4).contiguous()
+    from dove_amd.rope import prepare_rotary_positional_embeddings
+    rope = prepare_rotary_positional_embeddings(height=H, width=W, num_frames=lat.shape[1], transformer_config=pipe.transformer.config,
+                                                vae_scale_factor_spatial=8, device=lat.device)
+    ts = torch.full((1,), 399, dtype=torch.long, device=lat.device)
+    vel = pipe.transformer(hidden_states=lat, encoder_hidden_states=text[None].cuda(), timestep=ts, image_rotary_emb=rope,
+                           return_dict=False)[0]
+    dec = pipe.decode_latents(pipe.scheduler.get_velocity(vel, lat, ts)[:, ncopy:].contiguous())
+    assert torch.equal(got, (dec.float() * 0.5 + 0.5).clamp(0, 1).to(torch.bfloat16).float().cpu())
+    e_dec = rms_rel(dec, tr32["decoded"])
+    print(f"[e2e {F}x{H}x{W}] PSNR(hip, fp32 oracle) = {p_got:.2f} dB ({100 * sat:.1f} % of the pixels saturated); "
+          f"pre-clamp decoder output rms-rel {e_dec:.3e}")
     if (F, H, W) == (9, 64, 64):
+        trbf = {}
         refbf = odit.process_video(OracleVAE(v, wv, torch.bfloat16), odit.OracleDiT(t, wt, torch.bfloat16), s, video,
-                                   text[None], noise).float()
+                                   text[None], noise, trace=trbf).float()
         p_bf = psnr(refbf, ref32)
-        print(f"[e2e] PSNR(bf16-emulated reference, fp32 oracle) = {p_bf:.2f} dB")
+        e_bf = rms_rel(trbf["decoded"], tr32["decoded"])
+        print(f"[e2e] bf16-emulated reference vs fp32 oracle: PSNR {p_bf:.2f} dB, pre-clamp rms-rel {e_bf:.3e}; per stage " +
+              " ".join(f"{k} {rms_rel(trbf[k], tr32[k]):.2e}" for k in ("moments", "v", "x0")))
         assert p_got >= p_bf - 0.05, (p_got, p_bf)
+        assert e_dec <= 1.25 * e_bf, (e_dec, e_bf)
     assert p_got > 35.0, p_got
+    assert e_dec < 4e-2, e_dec
+
+
+def test_noise_step_pre_noising(setup):
+    """`--noise_step` (ref :449-457): latent <- add_noise(latent, eps, noise_step) before the DiT.  The reference draws eps
+    from the global RNG; here the same draw is reproduced for the oracle by re-seeding (the posterior noise is injected,
+    so eps is the only draw)."""
+    pipe, (v, t, s), wv, wt, text = setup
+    F, H, W = 9, 64, 64
+    video = synth_clip(F, H, W, seed=13)
+    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=torch.Generator().manual_seed(2))
+    torch.manual_seed(4242)
+    got = process_video(pipe, video.cuda(), noise_step=200, empty_prompt_embedding=text, posterior_noise=noise.cuda()).float().cpu()
+    torch.manual_seed(4242)
+    eps = torch.randn(1, 4, 16, H // 8, W // 8, device="cuda", dtype=torch.bfloat16).float().cpu()
+    base = process_video(pipe, video.cuda(), noise_step=0, empty_prompt_embedding=text, posterior_noise=noise.cuda()).float().cpu()
+    tr = {}
+    ref = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise, noise_step=200,
+                             add_noise_eps=eps, trace=tr)
+    ref0 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise)
+    p, p_wrong = psnr(got, ref), psnr(base, ref)
+    print(f"[noise_step=200] PSNR(hip, oracle) {p:.2f} dB; (hip without pre-noising vs oracle with) {p_wrong:.2f} dB; "
+          f"oracle 200 vs 0: {psnr(ref, ref0):.2f} dB")
+    assert p > 35.0 and p > p_wrong + 6.0, (p, p_wrong)
+    # scheduler coefficients at t=200 through the bf16 cast (diffusers casts alphas_cumprod to the sample dtype first)
+    a = pipe.scheduler.alphas_cumprod.to(torch.bfloat16)[200]
+    x = torch.randn(1, 4, 16, 8, 8, device="cuda", dtype=torch.bfloat16)
+    n = torch.randn_like(x)
+    want = (float(a ** 0.5) * x.float() + float((1 - a) ** 0.5) * n.float()).to(torch.bfloat16)
+    assert torch.equal(pipe.scheduler.add_noise(x, n, torch.tensor([200], device="cuda")), want)
 
 
 def test_stage_parity(setup):
@@ -77,8 +135,8 @@ def test_stage_parity(setup):
     p_ref = ov.encode(video)
     p = pipe.vae.encode(video.cuda().to(torch.bfloat16)).latent_dist.parameters.float().cpu()
     rel = float((p - p_ref).abs().max() / p_ref.abs().max())
-    print(f"[stage] encode moments rel-max-err {rel:.4f}")
-    assert rel < 0.05
+    print(f"[stage] encode moments rel-max-err {rel:.4f} rms-rel {rms_rel(p, p_ref):.3e}")
+    assert rel < 0.05 and rms_rel(p, p_ref) < 1.5e-2
     g = torch.Generator().manual_seed(3)
     hidden = torch.randn(1, 4, 16, H // 8, W // 8, generator=g)
     rope = odit.rope_3d(64, 2, H // 16, W // 16)
@@ -87,14 +145,14 @@ def test_stage_parity(setup):
     v_got = pipe.transformer(hidden_states=hidden.cuda().to(torch.bfloat16), encoder_hidden_states=text[None].cuda(),
                              timestep=ts.cuda(), image_rotary_emb=tuple(r.cuda() for r in rope), return_dict=False)[0].float().cpu()
     rel = float((v_got - v_ref).abs().max() / v_ref.abs().max())
-    print(f"[stage] DiT velocity rel-max-err {rel:.4f}")
-    assert rel < 0.05
+    print(f"[stage] DiT velocity rel-max-err {rel:.4f} rms-rel {rms_rel(v_got, v_ref):.3e}")
+    assert rel < 0.05 and rms_rel(v_got, v_ref) < 1.5e-2
     z = torch.randn(1, 16, 3, H // 8, W // 8, generator=g)
     d_ref = ov.decode(z)
     d = pipe.vae.decode(z.cuda().to(torch.bfloat16)).sample.float().cpu()
     rel = float((d - d_ref).abs().max() / d_ref.abs().max())
-    print(f"[stage] decode rel-max-err {rel:.4f}")
-    assert rel < 0.05
+    print(f"[stage] decode rel-max-err {rel:.4f} rms-rel {rms_rel(d, d_ref):.3e}")
+    assert rel < 0.05 and rms_rel(d, d_ref) < 1.5e-2
 
 
 def test_vae_tiling_gpu(golden_dir):
@@ -163,3 +221,87 @@ def test_fullsize_vae_causal_prefix_and_determinism(setup):
     assert torch.equal(dec, dec2), "decode is not deterministic"
     assert torch.equal(dpre, dec[:, :, :9]), "decoder output of a frame-batch-aligned prefix changed with later latents"
 
+
+
+def test_from_pretrained_and_lora_through_hip(setup, tmp_path):
+    """SURVEY 8(f) row 3 on the GPU: a DOVE-layout checkpoint directory (transformer as sharded fp32 safetensors + index
+    json, /root/reference/finetune/scripts/prepare_sft_ckpt.py:43-69; vae single file; scheduler config) is loaded by
+    `CogVideoXPipeline.from_pretrained`, packed for the kernels and run; then a rank-4 LoRA on to_q / to_k / to_v /
+    to_out.0 (/root/reference/inference_script.py:616-621) is fused and `process_video` must follow the oracle run on
+    W + (alpha/r) B A - and must NOT match the oracle on the un-adapted weights."""
+    import json
+
+    from safetensors.torch import save_file
+    _, (v, t, s), wv, wt, text = setup
+    root = str(tmp_path / "ckpt")
+    for d in ("vae", "transformer", "scheduler"):
+        os.makedirs(os.path.join(root, d))
+    json.dump(v, open(os.path.join(root, "vae", "config.json"), "w"))
+    json.dump(t, open(os.path.join(root, "transformer", "config.json"), "w"))
+    json.dump(dict(s, _class_name="CogVideoXDPMScheduler", _diffusers_version="0.32.0"),
+              open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    save_file({k: x.contiguous() for k, x in wv.items()}, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    keys = list(wt)
+    cuts = [0, len(keys) // 3, 2 * len(keys) // 3, len(keys)]
+    wmap = {}
+    for i in range(3):
+        fn = f"diffusion_pytorch_model-{i + 1:05d}-of-00003.safetensors"
+        save_file({k: wt[k].float().contiguous() for k in keys[cuts[i]:cuts[i + 1]]}, os.path.join(root, "transformer", fn))
+        wmap.update({k: fn for k in keys[cuts[i]:cuts[i + 1]]})
+    json.dump({"metadata": {"total_size": 0}, "weight_map": wmap},
+              open(os.path.join(root, "transformer", "diffusion_pytorch_model.safetensors.index.json"), "w"))
+    pipe = CogVideoXPipeline.from_pretrained(root, torch_dtype=torch.bfloat16).to("cuda")
+    F, H, W = 9, 64, 64
+    video = synth_clip(F, H, W, seed=17)
+    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=torch.Generator().manual_seed(6))
+    run = lambda p: process_video(p, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda()).float().cpu()  # noqa: E731
+    got0 = run(pipe)
+    ref0 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt), s, video, text.float()[None], noise)
+    p0 = psnr(got0, ref0)
+    # adapter: rank 4, alpha 8 (scale alpha/r = 2), strong enough to move the output well above the bf16 noise floor
+    D = t["num_attention_heads"] * t["attention_head_dim"]
+    g = torch.Generator().manual_seed(8)
+    lora, wt2 = {}, dict(wt)
+    for i in range(t["num_layers"]):
+        for m in ("to_q", "to_k", "to_v", "to_out.0"):
+            mod = f"transformer_blocks.{i}.attn1.{m}"
+            A = torch.randn(4, D, generator=g) * D ** -0.5
+            B = torch.randn(D, 4, generator=g) * 0.5
+            lora[f"transformer.{mod}.lora_A.weight"], lora[f"transformer.{mod}.lora_B.weight"] = A, B
+            wt2[mod + ".weight"] = wt[mod + ".weight"] + 2.0 * (B @ A)
+    os.makedirs(tmp_path / "lora")
+    save_file(lora, str(tmp_path / "lora" / "pytorch_lora_weights.safetensors"),
+              metadata={"lora_adapter_metadata": json.dumps({"r": 4, "lora_alpha": 8})})
+    pipe.load_lora_weights(str(tmp_path / "lora"), weight_name="pytorch_lora_weights.safetensors", adapter_name="test_1")
+    pipe.fuse_lora(components=["transformer"], lora_scale=1.0)
+    got1 = run(pipe)
+    ref1 = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt2), s, video, text.float()[None], noise)
+    p1, p_cross = psnr(got1, ref1), psnr(got1, ref0)
+    print(f"[ckpt+lora] PSNR loaded ckpt vs oracle {p0:.2f} dB; fused LoRA vs oracle(W+2BA) {p1:.2f} dB; "
+          f"fused vs oracle(W) {p_cross:.2f} dB")
+    assert p0 > 35.0 and p1 > 35.0, (p0, p1)
+    assert p_cross < p1 - 6.0, (p_cross, p1)                 # the adapter really changed what the kernels compute
+
+
+def test_diffusers_stage_goldens(golden_dir):
+    """Consumes tests/golden/diffusers_stages.safetensors (tools/capture_goldens.py, run where diffusers + the DOVE
+    checkpoint exist) when present: the REAL reference's per-stage tensors pin both the oracle and the HIP path.  Needs
+    the same checkpoint here (DOVE_MODEL_PATH); skipped otherwise - until someone provides both, model-arithmetic
+    parity stays 'pinned vs the clean-room oracle, unpinned vs diffusers' (DESIGN.md section 2)."""
+    from safetensors.torch import load_file
+    path = os.path.join(golden_dir, "diffusers_stages.safetensors")
+    model = os.environ.get("DOVE_MODEL_PATH", "")
+    if not os.path.exists(path) or not os.path.isdir(model):
+        pytest.skip("diffusers_stages.safetensors and/or DOVE_MODEL_PATH not available")
+    gold = load_file(path)
+    pipe = CogVideoXPipeline.from_pretrained(model, torch_dtype=torch.bfloat16)
+    video, text, noise = gold["video"], gold["text"][0].to(torch.bfloat16), gold["noise"]
+    p = pipe.vae.encode(video.cuda().to(torch.bfloat16)).latent_dist.parameters
+    assert rms_rel(p, gold["moments"]) < 2e-2
+    rope = (gold["rope_cos"].cuda(), gold["rope_sin"].cuda())
+    ts = torch.tensor([399], device="cuda")
+    vel = pipe.transformer(hidden_states=gold["latent"].cuda().to(torch.bfloat16), encoder_hidden_states=text[None].cuda(),
+                           timestep=ts, image_rotary_emb=rope, return_dict=False)[0]
+    assert rms_rel(vel, gold["velocity"]) < 6e-2
+    out = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda())
+    assert psnr(out.float().cpu(), gold["sr"]) > 35.0

@@ -6,7 +6,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from dove_amd import ops  # noqa: E402
+from dove_amd import lib as _L, ops  # noqa: E402
+
+_L.use_timing_build()          # s_memtime phase logs live only in the -DDOVE_TIMING_BUILD library
 
 cin, cout = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (128, 128)
 w = torch.randn(cout, cin, 3, 3, 3, device="cuda") * (cin * 27) ** -0.5
