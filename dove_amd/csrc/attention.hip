@@ -7,14 +7,25 @@
 // scale*log2e), K' [H][Npad][64], V^T [H][64][Npad]; pad rows/columns are zero.
 // Workgroup = 4 waves = 128 query rows (32 per wave); KV tiles of 64 keys are staged K and V^T alike with
 // 16-byte buffer_load ... lds into XOR-swizzled LDS (per-thread constant offsets, the tile index rides in
-// soffset), double-buffered, one barrier per tile, loop unrolled x2 so every ds_read address is a per-lane
-// constant + immediate.
+// soffset).  Four 16 KB stages = two PAIRS of tiles: ONE workgroup barrier per two tiles (128 keys), the next pair in
+// flight while the current one is multiplied; every ds_read address is a per-lane constant + immediate.
 // Swapped products keep the softmax lane-local (guide T12): S^T = K Q^T puts one query column in each
-// lane (row max/sum = in-lane + one cross-half shuffle), P^T is packed with v_cvt_pk_bf16_f32 and re-laid
-// to the MFMA B layout with v_permlane32_swap, and O^T = V^T P^T accumulates with the same query-per-lane
-// ownership.  The O rescale is skipped (wave-uniformly) on tiles where no query's running max moved.
-// v1 of this kernel was VALU-bound (PMC: 31 VALU instructions per MFMA, software bf16 rounding + 64-bit
-// address math); see profiles/r01_pmc_halo_attn.txt.
+// lane (row max/sum = in-lane + one half exchange by v_permlane32_swap), P^T is packed with v_cvt_pk_bf16_f32 and
+// re-laid to the MFMA B layout with v_permlane32_swap, and O^T = V^T P^T accumulates with the same query-per-lane
+// ownership.
+// Softmax shift without VALU work: the running max m enters the S accumulator through the MFMA's C operand (16 registers
+// holding -m; the first MFMA of each S chain is issued with C != D, which the builtin cannot express), so the MFMA
+// result is already S - m.  m is updated lazily (guide T13): only on a query block's first tile and when some score
+// exceeds it by THR = 2^6; then O, l, the current tile's S and the -m registers are rescaled once, BEFORE the tile's
+// P is exponentiated (the safe order of T13).  P <= 64 in bf16 keeps its 8-bit relative precision and O / l accumulate
+// in fp32, so the result matches the exact-max formulation to rounding (tests: spiked keys early / late, full tensor).
+// Measured on MI355X at N = 18226, 48 heads (tools/attn_ab.py, within-run A/B; profiles/r02_attn_ab.log): 0.93-0.95 PF vs
+// 0.89-0.91 for the round-1 kernel.  What did NOT pay (same harness): row sum on the matrix pipe (ones x P^T, -2 %), four
+// partial sums / v_pk_add (0 %), the shift as a fifth K slice (+1 % but 2x the rounding error), two query blocks per
+// wave (+3 % only with the fifth slice; 248 registers).  An instruction-rate microbenchmark (tools/ubench.py) puts a
+// wave64 v_exp_f32 / v_permlane32_swap at ~9 cycles per SIMD, v_max3 / v_cvt_pk at ~4.4, v_add at ~2.4, and a dense
+// random-data 32x32x16 MFMA storm at 27 ns per instruction per SIMD (1.24 PF: the chip is power-limited there), so at
+// head_dim 64 the kernel sits at ~75 % of what the matrix pipe sustains on this data.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -30,42 +41,40 @@ __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// QB = query blocks (of 32 rows) per wave.  QB = 2: every K / V^T fragment read from LDS feeds two MFMAs and the two
-// independent softmax chains give the scheduler VALU work to hide under the other block's MFMAs.
-template <int QB>
+// D = A B + C with the accumulator INPUT in other registers than the output (C = -m broadcast, D = S - m).  The builtin
+// ties C to D and the compiler would copy the 16 registers first.  `s_nop 1`: a VALU write of C (rare rescale path) needs
+// two wait states before an MFMA reads it and hipcc pads nothing inside an asm statement (guide 5.7 item 2).
+__device__ __forceinline__ f32x16 mfma_c_in(bf16x8 a, bf16x8 b, const f32x16& c) {
+  f32x16 d;
+  asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                           long long N, long long Npad, long long ldo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384, VOFF = 8192;
-  constexpr int QROWS = 32 * QB;                 // query rows per wave
+  constexpr float THR = 6.0f;                    // rescale when a score exceeds the running max by 2^6
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y;
-  const long long q0 = (long long)blockIdx.x * (4 * QROWS) + wave * QROWS;
+  const long long q0 = (long long)blockIdx.x * 128 + wave * 32;
 
-  bf16x8 qf[QB][4];
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    long long qrow = q0 + qb * 32 + l31;
+  bf16x8 qf[4];
+  {
+    long long qrow = q0 + l31;
     if (qrow >= Npad) qrow = Npad - 1;           // rows past the padded end are never stored; keep the load in range
     const bf16_t* qp = Qh + ((long long)h * Npad + qrow) * 64 + hi * 8;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[qb][kk] = *(const bf16x8*)(qp + kk * 16);
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + kk * 16);
   }
 
-  f32x16 o[QB][2];
-  float m[QB], lsum[QB];
+  f32x16 o[2], negm;
+  float m = 0.f, lsum = 0.f;                     // m becomes a real maximum on the first tile
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    m[qb] = -1e30f;
-    lsum[qb] = 0.f;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
 
   const int ntiles = (int)((N + 63) / 64);
   const int srow = tid >> 3;
@@ -101,79 +110,73 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
   auto compute = [&](auto bufc, int tile) {
     constexpr int BUF = decltype(bufc)::value;
-    // ---- S^T[kv][q] = K Q^T : each K fragment feeds QB MFMAs ----
-    f32x16 st[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[qb][kb][r] = 0.f;
+    // ---- (S - m)^T[kv][q] = K Q^T - m : the shift rides in the C operand of the first MFMA of each chain ----
+    f32x16 st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const bf16x8 kf = *(const bf16x8*)(smem + BUF * STAGE + koff[kb][kk]);
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][kk], st[qb][kb], 0, 0, 0);
+        if (kk == 0) st[kb] = mfma_c_in(kf, qf[kk], negm);
+        else st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
       }
     const long long kv0 = (long long)tile * 64;
     if (kv0 + 64 > N) {
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const long long kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (kv >= N) st[qb][kb][r] = -1e30f;
-          }
-    }
-    // ---- online softmax per query block (base 2; Q carries scale*log2e) ----
-    bf16x8 pf[QB][2][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float mt = st[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[qb][kb][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      if (__any(mt > m[qb])) {   // wave-uniform: rescale only when some query's running max moved
-        const float mnew = fmaxf(m[qb], mt);
-        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mnew);
-        m[qb] = mnew;
-        lsum[qb] *= alpha;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha;
-      }
-      float ps = 0.f;
-#pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(st[qb][kb][r] - m[qb]);
-          st[qb][kb][r] = p;
-          ps += p;
-        }
-      lsum[qb] += ps;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-          const int b = 8 * k2;
-          const uint32_t a0 = pack_bf2(st[qb][kb][b + 0], st[qb][kb][b + 1]);
-          const uint32_t a1 = pack_bf2(st[qb][kb][b + 2], st[qb][kb][b + 3]);
-          const uint32_t b0 = pack_bf2(st[qb][kb][b + 4], st[qb][kb][b + 5]);
-          const uint32_t b1 = pack_bf2(st[qb][kb][b + 6], st[qb][kb][b + 7]);
-          const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-          const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-          pf[qb][kb][k2] = make_frag(r0[0], r1[0], r0[1], r1[1]);
+          const long long kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= N) st[kb][r] = -1e30f;
         }
     }
-    // ---- O^T[d][q] += V^T P^T : each V^T fragment feeds QB MFMAs ----
+    // ---- lazy online softmax (base 2; Q carries scale*log2e) ----
+    float mt = st[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));        // the other half of the same query column
+    }
+    const bool first = tile == 0;
+    if (first || __any(mt > THR)) {              // wave-uniform and rare after the first tiles
+      // everything still expressed against the old max is rescaled exactly once, before this tile's P exists
+      const float delta = first ? mt : fmaxf(mt, 0.f);
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // first tile: O = l = 0, and 2^(-mt) may overflow
+      m += delta;
+      lsum *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= alpha; o[1][r] *= alpha; st[0][r] -= delta; st[1][r] -= delta; negm[r] = -m;
+      }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kb][r]);
+        st[kb][r] = p;
+        ps += p;
+      }
+    lsum += ps;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int b = 8 * k2;
+        const uint32_t a0 = pack_bf2(st[kb][b + 0], st[kb][b + 1]);
+        const uint32_t a1 = pack_bf2(st[kb][b + 2], st[kb][b + 3]);
+        const uint32_t b0 = pack_bf2(st[kb][b + 4], st[kb][b + 5]);
+        const uint32_t b1 = pack_bf2(st[kb][b + 6], st[kb][b + 7]);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        pf[kb][k2] = make_frag(r0[0], r1[0], r0[1], r1[1]);
+      }
+    // ---- O^T[d][q] += V^T P^T ----
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -181,49 +184,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
           const bf16x8 vf = *(const bf16x8*)(smem + BUF * STAGE + VOFF + koff[db][kb * 2 + k2]);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) o[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kb][k2], o[qb][db], 0, 0, 0);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][k2], o[db], 0, 0, 0);
         }
   };
 
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
+  using B2 = std::integral_constant<int, 2>;
+  using B3 = std::integral_constant<int, 3>;
   stage(B0{}, 0);
-  int it = 0;
-  for (; it + 2 <= ntiles; it += 2) {
+  if (1 < ntiles) stage(B1{}, 1);
+  for (int it = 0; it < ntiles; it += 4) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage(B1{}, it + 1);
+    if (it + 2 < ntiles) stage(B2{}, it + 2);
+    if (it + 3 < ntiles) stage(B3{}, it + 3);
     compute(B0{}, it);
+    if (it + 1 < ntiles) compute(B1{}, it + 1);
+    if (it + 2 >= ntiles) break;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (it + 2 < ntiles) stage(B0{}, it + 2);
-    compute(B1{}, it + 1);
-  }
-  if (ntiles & 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    compute(B0{}, ntiles - 1);
+    if (it + 4 < ntiles) stage(B0{}, it + 4);
+    if (it + 5 < ntiles) stage(B1{}, it + 5);
+    compute(B2{}, it + 2);
+    if (it + 3 < ntiles) compute(B3{}, it + 3);
   }
 
+  const float l = lsum + __shfl_xor(lsum, 32);
+  const float inv = 1.0f / l;
+  const long long q = q0 + l31;
+  if (q < N) {
+    bf16_t* op = O + q * ldo + h * 64;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const float l = lsum[qb] + __shfl_xor(lsum[qb], 32);
-    const float inv = 1.0f / l;
-    const long long q = q0 + qb * 32 + l31;
-    if (q < N) {
-      bf16_t* op = O + q * ldo + h * 64;
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = db * 32 + 8 * g + 4 * hi;
-          uint2 w;
-          w.x = pack_bf2(o[qb][db][g * 4 + 0] * inv, o[qb][db][g * 4 + 1] * inv);
-          w.y = pack_bf2(o[qb][db][g * 4 + 2] * inv, o[qb][db][g * 4 + 3] * inv);
-          *(uint2*)(op + d) = w;
-        }
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hi;
+        uint2 w;
+        w.x = pack_bf2(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+        w.y = pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+        *(uint2*)(op + d) = w;
+      }
   }
 }
 
@@ -234,15 +235,14 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128, "attention_fwd: Npad must be N rounded up to 128");
   DOVE_CHECK_ARG(Npad * 128 < (1ll << 31), "attention_fwd: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
-  // QB = 2 (64 queries per wave) measured SLOWER on MI355X (805 vs 845 TFLOP/s at N = 18226: 256 VGPRs + spills), so the
-  // one-block-per-wave instantiation is the only one dispatched.
+  constexpr int LDS = 4 * 16384;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
   dim3 grid((unsigned)(Npad / 128), heads);
-  hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, dim3(256), 32768, (hipStream_t)stream, (const bf16_t*)Qh,
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
                      (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
