@@ -52,6 +52,8 @@ SIGNATURES = {
     "dove_blend_edge_bf16": [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP],
     "dove_preprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _I, _VP],
     "dove_postprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP],
+    "dove_mx_quant_bf16": [_VP, _LL, _I, _VP, _VP, _VP],
+    "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_conv_gn_partial_rows": (C.c_longlong, [C.POINTER(ConvDesc)]),

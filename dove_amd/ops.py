@@ -395,3 +395,51 @@ def postprocess_u8(video: torch.Tensor, Fo: int, Ho: int, Wo: int) -> torch.Tens
     L.check(L.load().dove_postprocess_u8(L.ptr(video), L.dt_code(video), F, H, W, Fo, Ho, Wo, L.ptr(out), L.stream_ptr()),
             "dove_postprocess_u8")
     return out
+
+
+# ---- MXFP8 linears (BASELINE configs[4]; csrc/mxfp8.hip) ------------------------------------------------------------------
+@dataclass
+class PackedMx:
+    """One operand in OCP MXFP8: q [rows][K] e4m3fn bytes, s [K/256][rows][2] words of four E8M0 block scales each."""
+    q: torch.Tensor
+    s: torch.Tensor
+    rows: int
+    K: int
+    bias: torch.Tensor | None = None
+
+
+def mx_quant(x: torch.Tensor) -> PackedMx:
+    """x [rows, K] bf16 (K % 256 == 0) -> MXFP8 (per 32-element block: scale 2^ceil(log2(amax/448)), RNE to e4m3fn)."""
+    L.require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2
+    rows, K = x.shape
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+    s = torch.empty(K // 256, rows, 2, dtype=torch.int32, device=x.device)
+    L.check(L.load().dove_mx_quant_bf16(L.ptr(x), rows, K, L.ptr(q), L.ptr(s), L.stream_ptr()), "dove_mx_quant_bf16")
+    return PackedMx(q, s, rows, K)
+
+
+def pack_linear_mx(weight: torch.Tensor, bias: torch.Tensor | None, device) -> PackedMx:
+    """nn.Linear weight [N, K] -> MXFP8 operand (quantised on the GPU from its bf16 rounding, like the bf16 path's weights)."""
+    w = weight.detach().to(device=device, dtype=torch.bfloat16).contiguous()
+    pm = mx_quant(w)
+    if bias is not None:
+        pm.bias = bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    return pm
+
+
+def linear_mx(x: PackedMx, w: PackedMx, *, resid: torch.Tensor | None = None, gate: torch.Tensor | None = None, gate_split: int = 0,
+              act: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out [M, N] bf16 = epilogue(dequant(x) @ dequant(w)^T + bias); same epilogue contract as ``linear``."""
+    M, N, K = x.rows, w.rows, w.K
+    assert x.K == K
+    L.require_cuda(x.q, x.s, w.q, w.s, resid, gate, out)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.q.device)
+    assert out.dtype == torch.bfloat16 and out.shape[0] == M
+    if gate is not None:
+        assert gate.dtype == torch.float32 and gate.shape == (2, N)
+    L.check(L.load().dove_linear_mxfp8(L.ptr(x.q), L.ptr(x.s), L.ptr(w.q), L.ptr(w.s), L.ptr(w.bias), L.ptr(resid), L.ptr(gate), L.ptr(out),
+                                       M, N, K, out.shape[1], resid.shape[1] if resid is not None else 0, gate_split, act,
+                                       L.stream_ptr()), "dove_linear_mxfp8")
+    return out

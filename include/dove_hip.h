@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 2
+#define DOVE_ABI_VERSION 3
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -143,6 +143,19 @@ int dove_postprocess_u8(const void* video, int dtype, int F, int H, int W, int F
 /* M = 1 linear with optional SiLU on the input (time_embedding MLP, norm*.linear modulation vectors) */
 int dove_gemv_bf16(const void* W, const float* bias, const float* x, int in_features, int out_features, int act_in,
                    float* y, void* stream);
+
+/* ---- MXFP8 linears (BASELINE configs[4]: fp8 MFMA path of the DiT, PSNR-gated against the bf16 path) --------------------
+ * OCP microscaling FP8: e4m3fn elements, one E8M0 (power-of-two) scale per 32 consecutive K elements of a row, for BOTH
+ * operands of an nn.Linear of CogVideoXBlock (attn1.to_q/k/v fused, attn1.to_out.0, ff.net.0.proj, ff.net.2;
+ * /root/reference/inference_script.py:483-489).  The scales are applied inside v_mfma_scale_f32_32x32x64_f8f6f4.
+ * dove_mx_quant_bf16: x bf16 [rows][K] (K % 256 == 0) -> q u8 [rows][K] and scales u32 [K/256][rows][2]; word (c, r, h),
+ *   byte u = E8M0 scale of row r's block 8c + 2u + h; scale = 2^ceil(log2(amax/448)) (no clipping), q = RNE_e4m3(x/scale).
+ * dove_linear_mxfp8: out [M][ldo] bf16 = epilogue((xq.xs) (wq.ws)^T + bias) with the epilogue of dove_conv_igemm_bf16
+ *   (act 1 = GELU(tanh); resid / gate [2][N] fp32 / gate_split as there); N % 256 == 0, K % 256 == 0. */
+int dove_mx_quant_bf16(const void* x, long long rows, int K, void* q, void* scales, void* stream);
+int dove_linear_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, const void* resid,
+                      const float* gate, void* out, long long M, int N, int K, long long ldo, long long ldr, long long gate_split,
+                      int act, void* stream);
 
 #ifdef __cplusplus
 }

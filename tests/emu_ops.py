@@ -305,3 +305,47 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for n in ALL:
         monkeypatch.setattr(real, n, getattr(me, n))
+
+
+# ---- MXFP8 (OCP microscaling) restatement: per 32-element block one power-of-two scale, elements e4m3fn ---------------------
+def mx_quant_ref(x):
+    """x [rows, K] -> (q float8_e4m3fn [rows, K], e uint8 [rows, K/32] biased E8M0 exponents): scale = 2^ceil(log2(amax/448))."""
+    rows, K = x.shape
+    xb = x.float().reshape(rows, K // 32, 32)
+    amax = xb.abs().amax(dim=2)
+    r = amax / 448.0
+    e = torch.where(amax > 0, torch.ceil(torch.log2(r.clamp_min(1e-45))).clamp(-127, 127) + 127, torch.zeros_like(r))
+    # exact powers of two: log2 is exact for them in fp32, ceil leaves them alone
+    scale = torch.pow(2.0, e - 127)
+    q = (xb / scale[..., None]).to(torch.float8_e4m3fn)
+    return q.reshape(rows, K), e.to(torch.uint8)
+
+
+def mx_scale_words(e):
+    """[rows, K/32] exponents -> the kernel's layout int32 [K/256][rows][2]: word (c, r, h), byte u = block 8c + 2u + h."""
+    rows, nb = e.shape
+    w = e.reshape(rows, nb // 8, 4, 2).permute(1, 0, 3, 2).contiguous().to(torch.int64)       # [c][r][h][u]
+    return (w[..., 0] | (w[..., 1] << 8) | (w[..., 2] << 16) | (w[..., 3] << 24)).to(torch.int64).to(torch.int32)
+
+
+def mx_dequant(q, e):
+    rows, K = q.shape
+    return (q.float().reshape(rows, K // 32, 32) * torch.pow(2.0, e.float() - 127)[..., None]).reshape(rows, K)
+
+
+def linear_mx_ref(x, weight, bias, *, resid=None, gate=None, gate_split=0, act=0):
+    """bf16 x [M,K], weight [N,K] (any float): quantise both to MXFP8, multiply the dequantised values in fp32."""
+    xq, xe = mx_quant_ref(x)
+    wq, we = mx_quant_ref(weight.to(BF))
+    y = mx_dequant(xq, xe) @ mx_dequant(wq, we).t()
+    if bias is not None:
+        y = y + bias.float()
+    if act == 1:
+        y = F.gelu(y, approximate="tanh")
+    if resid is not None:
+        if gate is not None:
+            cls = (torch.arange(x.shape[0]) >= gate_split).long()
+            y = resid.float() + gate.float()[cls] * y
+        else:
+            y = resid.float() + y
+    return y.to(BF)

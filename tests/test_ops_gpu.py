@@ -429,3 +429,51 @@ def test_fallback_kernels_in_subprocess():
                         "-k", "(test_conv or test_linear) and not fused and not fullsize"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
+
+
+# ---- MXFP8 linears (BASELINE configs[4]) -------------------------------------------------------------------------------------
+def test_mx_quant_bit_exact():
+    """dove_mx_quant_bf16 vs the torch restatement (float8_e4m3fn cast, power-of-two block scales): identical bytes and
+    identical E8M0 exponents, incl. all-zero blocks, a block of subnormal-range values, huge and tiny magnitudes."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(300, 512, generator=g) * torch.exp(torch.randn(300, 1, generator=g) * 3)
+    x[5, 32:64] = 0.0
+    x[6, :32] = 448.0 * 4
+    x[7, 64:96] *= 1e-6
+    x[8, 96:128] = torch.tensor([2.0 ** k for k in range(-20, 12)])
+    x = x.to(BF)
+    pm = ops.mx_quant(x.cuda())
+    torch.cuda.synchronize()
+    q_ref, e_ref = E.mx_quant_ref(x)
+    assert torch.equal(pm.s.cpu(), E.mx_scale_words(e_ref)), "E8M0 scales differ"
+    assert torch.equal(pm.q.cpu(), q_ref.view(torch.uint8)), "e4m3 bytes differ"
+
+
+@pytest.mark.parametrize("M,N,K,act,resid,gate", [
+    (300, 256, 512, 0, False, False),           # one ragged row tile, two scale chunks
+    (1000, 768, 1024, 1, False, False),         # GELU epilogue, several tiles per workgroup
+    (700, 512, 3072, 0, True, True),            # gated residual (attn1.to_out.0 / ff.net.2 epilogue), DiT K
+    (513, 256, 12288, 0, True, False),          # deep K (ff.net.2), plain residual
+])
+def test_linear_mxfp8(M, N, K, act, resid, gate):
+    """HIP MXFP8 GEMM (block scales applied inside v_mfma_scale_f32_32x32x64_f8f6f4) vs dequantise-then-fp32-matmul of the
+    SAME quantised operands.  Only the accumulation order differs: tolerance as for the bf16 linears."""
+    g = torch.Generator().manual_seed(43)
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(1, K, generator=g))).to(BF)      # per-channel spread: scales matter
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g).to(BF) if resid else None
+    gt = torch.randn(2, N, generator=g) if gate else None
+    split = 226 if gate else 0
+    ref = E.linear_mx_ref(x, w, b, resid=r, gate=gt, gate_split=split, act=act)
+    pw = ops.pack_linear_mx(w, b, "cuda")
+    got = ops.linear_mx(ops.mx_quant(x.cuda()), pw, resid=None if r is None else r.cuda(), gate=None if gt is None else gt.cuda(),
+                        gate_split=split, act=act)
+    torch.cuda.synchronize()
+    close(f"linear_mxfp8_{M}x{N}x{K}", got, ref)
+    # and the quantisation itself costs what MXFP8 should cost against the bf16 linear: a few 1e-2 relative RMS
+    full = (x.float() @ w.to(BF).float().t() + b)
+    if act == 0 and not resid:
+        rel = float((got.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt())
+        print(f"[mxfp8 {M}x{N}x{K}] rms-rel vs the unquantised product {rel:.3e}")
+        assert rel < 6e-2
