@@ -292,7 +292,46 @@ def postprocess_u8(video, Fo, Ho, Wo):
     return (v.float() * 255).clamp(0, 255).to(torch.uint8).contiguous()
 
 
-ALL = ["groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+@dataclass
+class EmuMx:
+    """Emulation-side MXFP8 operand: dequantised values (what the block-scaled MFMA multiplies) + optional bias."""
+    deq: torch.Tensor
+    rows: int
+    K: int
+    bias: torch.Tensor | None = None
+
+
+def mx_quant(x):
+    q, e = mx_quant_ref(x)
+    return EmuMx(mx_dequant(q, e), x.shape[0], x.shape[1])
+
+
+def pack_linear_mx(weight, bias, device="cpu"):
+    pm = mx_quant(weight.detach().to(BF))
+    pm.bias = None if bias is None else bias.detach().float()
+    return pm
+
+
+def linear_mx(x, w, *, resid=None, gate=None, gate_split=0, act=0, out=None):
+    y = x.deq @ w.deq.t()
+    if w.bias is not None:
+        y = y + w.bias
+    if act == 1:
+        y = F.gelu(y, approximate="tanh")
+    if resid is not None:
+        if gate is not None:
+            cls = (torch.arange(x.rows) >= gate_split).long()
+            y = resid.float() + gate.float()[cls] * y
+        else:
+            y = resid.float() + y
+    y = y.to(BF)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+ALL = ["mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

@@ -305,3 +305,48 @@ def test_diffusers_stage_goldens(golden_dir):
     assert rms_rel(vel, gold["velocity"]) < 6e-2
     out = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda())
     assert psnr(out.float().cpu(), gold["sr"]) > 35.0
+
+
+def test_long_clip_chunked_tiled_configs3(golden_dir):
+    """BASELINE configs[3] on ONE GPU: a 129x1088x1920 clip (the script's padding of 1080p) through the reference's chunk loop
+    (`--chunk_len 33 --overlap_t 8`: chunks (0,33),(25,58),(50,83),(75,129), ref :249-279) with the FULL 42-layer model and
+    diffusers' VAE spatial tiling switched on (`--is_vae_st`, 240x360-px tiles with linear blends) - "tiled VAE + chunked DiT".
+    No oracle run exists at this size; checked: exact-once coverage of the stitched clip (the reference's own check, ref
+    :705-729), finiteness, the first chunk's kept region == `process_video` on that chunk alone (bit-exact: chunks are
+    independent calls), and that tiling really ran (a tiled decode differs from the untiled one)."""
+    from safetensors.torch import load_file
+
+    from dove_amd import tiling
+    from dove_amd.inference import run_clip
+    v, t, s = config.default_configs()
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=1234, device="cuda", init_device="cuda")
+    pipe.vae.enable_tiling()
+    text = load_file(os.path.join(golden_dir, "empty_prompt_embedding.safetensors"))["prompt_embedding"]
+    F, H, W = 129, 1088, 1920
+    lr = synth_clip(F, H // 8, W // 8, seed=9)[0].cuda()                              # cheap content, upsampled x8
+    video = torch.nn.functional.interpolate(lr.permute(1, 0, 2, 3), size=(H, W), mode="bilinear",
+                                            align_corners=False).permute(1, 0, 2, 3)[None].to(torch.bfloat16).contiguous()
+    torch.cuda.reset_peak_memory_stats()
+    import time
+    t0 = time.time()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    out, wc = run_clip(pipe, video, chunk_len=33, overlap_t=8, empty_prompt_embedding=text, generator=gen)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"[configs3] 129x1088x1920, 4 chunks, tiled VAE, 42 layers: {dt:.1f} s ({F / dt:.1f} frames/s), "
+          f"peak HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    assert out.shape == (1, 3, F, H, W) and int(wc.min()) == 1 and int(wc.max()) == 1
+    assert bool(torch.isfinite(out).all())
+    items = tiling.plan(video.shape, 33, 8, (0, 0), (32, 32))
+    assert [it[0][:2] for it in items] == [(0, 33), (25, 58), (50, 83), (75, 129)]
+    (t0_, t1_, h0, h1, w0, w1), region = items[0]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    piece = process_video(pipe, video[:, :, t0_:t1_], empty_prompt_embedding=text, generator=gen).float().cpu()
+    ref_out, ref_wc = torch.zeros_like(out), torch.zeros_like(wc)
+    tiling.stitch(ref_out, ref_wc, piece, region)
+    kept = ref_wc.bool()
+    assert torch.equal(out[kept], ref_out[kept]), "chunk 0 of the stitched clip differs from process_video on that chunk"
+    pipe.vae.disable_tiling()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    untiled = process_video(pipe, video[:, :, :33], empty_prompt_embedding=text, generator=gen).float().cpu()
+    assert not torch.equal(untiled, piece), "enable_tiling() had no effect at 1088x1920"

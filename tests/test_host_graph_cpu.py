@@ -257,3 +257,28 @@ def test_from_pretrained_and_lora_fuse(monkeypatch, tmp_path):
     assert rel(got, want) < 0.05 and rel(base, want) > 2 * rel(got, want)     # the adapter really changed the output
     with pytest.raises(RuntimeError, match="before load_lora_weights"):
         pipe.fuse_lora()
+
+
+def test_dit_mxfp8_host_path(monkeypatch):
+    """linear_precision="mxfp8": the four big linears of every block go through mx_quant + linear_mx with the same epilogue
+    wiring (bias, GELU, gated residual, in-place residual stream) as the bf16 path.  With the operators emulated the result
+    must sit at MXFP8 distance from the bf16 graph (quantisation noise only: a mis-wired gate or residual would be O(1))."""
+    emu_ops.install(monkeypatch)
+    from dove_amd.transformer import CogVideoXTransformer3DModel
+    v, t, s = config.tiny_configs()
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), 41)
+    torch.manual_seed(3)
+    hidden = torch.randn(1, 4, 16, 8, 12).to(torch.bfloat16)
+    text = torch.randn(1, 226, t["text_embed_dim"]).to(torch.bfloat16)
+    rope = odit.rope_3d(64, 2, 4, 6)
+    ts = torch.tensor([399])
+    outs = {}
+    for prec in ("bf16", "mxfp8"):
+        tr = CogVideoXTransformer3DModel(t, wt, "cpu", linear_precision=prec)
+        outs[prec] = tr(hidden_states=hidden, encoder_hidden_states=text, timestep=ts, image_rotary_emb=rope, return_dict=False)[0].float()
+    want = odit.OracleDiT(t, wt).forward(hidden.float(), text.float(), ts, rope)
+    e_bf, e_mx = rel(outs["bf16"], want), rel(outs["mxfp8"], want)
+    print(f"tiny DiT rel-max-err vs fp32 oracle: bf16 graph {e_bf:.4f}, mxfp8 graph {e_mx:.4f}")
+    assert e_bf < 0.03 and e_mx < 0.15
+    with pytest.raises(ValueError):
+        CogVideoXTransformer3DModel(t, wt, "cpu", linear_precision="fp4")
