@@ -52,6 +52,9 @@ SIGNATURES = {
     "dove_blend_edge_bf16": [_VP, _VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP],
     "dove_preprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _I, _VP],
     "dove_postprocess_u8": [_VP, _I, _I, _I, _I, _I, _I, _I, _VP, _VP],
+    "dove_rmsnorm_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP],
+    "dove_gated_gelu_bf16": [_VP, _VP, _LL, _I, _VP],
+    "dove_attention_bias_bf16": [_VP, _VP, _VP, _LL, _VP, _VP, _LL, _I, _I, _I, _VP],
     "dove_mx_quant_bf16": [_VP, _LL, _I, _VP, _VP, _VP],
     "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }

@@ -443,3 +443,33 @@ def linear_mx(x: PackedMx, w: PackedMx, *, resid: torch.Tensor | None = None, ga
                                        M, N, K, out.shape[1], resid.shape[1] if resid is not None else 0, gate_split, act,
                                        L.stream_ptr()), "dove_linear_mxfp8")
     return out
+
+
+# ---- T5 text-encoder operators (csrc/t5.hip) --------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    L.require_cuda(x, weight)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and weight.dtype == torch.float32
+    y = torch.empty_like(x)
+    L.check(L.load().dove_rmsnorm_bf16(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], eps, L.ptr(weight), L.stream_ptr()), "dove_rmsnorm_bf16")
+    return y
+
+
+def gated_gelu(x: torch.Tensor) -> torch.Tensor:
+    """x [M, 2F] (wi_0 x || wi_1 x) -> gelu_new(x[:, :F]) * x[:, F:]."""
+    L.require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] % 16 == 0
+    y = torch.empty(x.shape[0], x.shape[1] // 2, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_gated_gelu_bf16(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1] // 2, L.stream_ptr()), "dove_gated_gelu_bf16")
+    return y
+
+
+def attention_bias(qkv: torch.Tensor, bias: torch.Tensor, heads: int) -> torch.Tensor:
+    """T5 self-attention on the fused projection qkv [N, 3*heads*64] with additive fp32 bias [heads, N, N] -> [N, heads*64]."""
+    L.require_cuda(qkv, bias)
+    N, D = qkv.shape[0], heads * 64
+    assert qkv.dtype == torch.bfloat16 and qkv.shape[1] == 3 * D and bias.dtype == torch.float32 and bias.shape == (heads, N, N)
+    out = torch.empty(N, D, dtype=torch.bfloat16, device=qkv.device)
+    base = qkv.data_ptr()
+    L.check(L.load().dove_attention_bias_bf16(C.c_void_p(base), C.c_void_p(base + 2 * D), C.c_void_p(base + 4 * D), 3 * D, L.ptr(bias),
+                                              L.ptr(out), D, N, heads, 64, L.stream_ptr()), "dove_attention_bias_bf16")
+    return out

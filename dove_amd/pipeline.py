@@ -20,17 +20,20 @@ class _Unavailable:
         self._what = what
 
     def __call__(self, *a, **k):
-        raise NotImplementedError(f"{self._what} is not part of the accelerated path: DOVE runs with the cached empty-prompt "
-                                  "embedding (ref :423-428); non-empty prompts are a SURVEY 8(f) follow-up")
+        raise NotImplementedError(f"this pipeline was built without a {self._what} (the checkpoint has no such directory, or it "
+                                  "is a random-init pipeline): only the empty prompt with the cached embedding (ref :423-428) "
+                                  "can run; load a checkpoint with text_encoder/ and tokenizer/ for non-empty prompts")
 
     __getattr__ = lambda self, n: self.__call__()   # noqa: E731
 
 
 class CogVideoXPipeline:
-    def __init__(self, vae, transformer, scheduler):
+    def __init__(self, vae, transformer, scheduler, text_encoder=None, tokenizer=None):
         self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
-        self.tokenizer = _Unavailable("tokenizer")
-        self.text_encoder = _Unavailable("text_encoder (T5)")
+        # only a non-empty prompt needs them (ref :429-444); a checkpoint without text_encoder/ or tokenizer/ still runs the
+        # documented empty-prompt path
+        self.tokenizer = tokenizer if tokenizer is not None else _Unavailable("tokenizer")
+        self.text_encoder = text_encoder if text_encoder is not None else _Unavailable("text_encoder (T5)")
 
     # ---- constructors ---------------------------------------------------------------------------
     @classmethod
@@ -42,8 +45,17 @@ class CogVideoXPipeline:
         tcfg, tsd = W.load_component(os.path.join(model_path, "transformer"), W.dit_param_shapes)
         with open(os.path.join(model_path, "scheduler", "scheduler_config.json")) as f:
             scfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        text_encoder = tokenizer = None
+        if os.path.isdir(os.path.join(model_path, "text_encoder")):
+            from .t5 import T5EncoderModel
+            text_encoder = T5EncoderModel.from_pretrained(os.path.join(model_path, "text_encoder"), device, torch_dtype)
+        if os.path.isdir(os.path.join(model_path, "tokenizer")):
+            # host-side text processing: transformers' own T5 tokenizer, exactly what the reference's pipeline holds
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "tokenizer"))
         return cls(AutoencoderKLCogVideoX(vcfg, vsd, device, torch_dtype),
-                   CogVideoXTransformer3DModel(tcfg, tsd, device, torch_dtype, dit_linear_precision), CogVideoXDPMScheduler(**scfg))
+                   CogVideoXTransformer3DModel(tcfg, tsd, device, torch_dtype, dit_linear_precision), CogVideoXDPMScheduler(**scfg),
+                   text_encoder, tokenizer)
 
     @classmethod
     def from_config(cls, vae_config=None, transformer_config=None, scheduler_config=None, seed: int = 1234,

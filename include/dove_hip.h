@@ -157,6 +157,18 @@ int dove_linear_mxfp8(const void* xq, const void* xs, const void* wq, const void
                       const float* gate, void* out, long long M, int N, int K, long long ldo, long long ldr, long long gate_split,
                       int act, void* stream);
 
+/* ---- T5 text encoder operators (non-empty prompts only: `pipe.text_encoder(ids)[0]`, /root/reference/inference_script.py:429-444;
+ * transformers' T5EncoderModel of CogVideoX1.5: T5-v1.1-XXL, 24 blocks, d_model 4096, 64 heads x 64, gated-GELU d_ff 10240) ----
+ * T5LayerNorm: y = weight * x * rsqrt(mean(x^2) + eps) (fp32 statistics; no mean subtraction, no bias) */
+int dove_rmsnorm_bf16(const void* x, void* y, long long rows, int D, float eps, const float* weight, void* stream);
+/* T5DenseGatedActDense: y [M][F] = gelu_new(x[:, :F]) * x[:, F:2F] on the fused wi_0 || wi_1 projection */
+int dove_gated_gelu_bf16(const void* x, void* y, long long M, int F, void* stream);
+/* T5Attention (encoder self-attention, no mask): out [N][ldo] = softmax(q k^T + bias[h]) v per head; q/k/v token-major with
+ * row stride ld (views into the fused projection), head h at columns [64h, 64h+64); NO 1/sqrt(d) scaling; bias [H][N][N]
+ * fp32 = relative_attention_bias gathered by bucket; N <= 1024 */
+int dove_attention_bias_bf16(const void* q, const void* k, const void* v, long long ld, const float* bias, void* out, long long ldo,
+                             int N, int heads, int head_dim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

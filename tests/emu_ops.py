@@ -331,7 +331,25 @@ def linear_mx(x, w, *, resid=None, gate=None, gate_split=0, act=0, out=None):
     return y
 
 
-ALL = ["mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+def rmsnorm(x, weight, eps):
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * weight.float()).to(BF)
+
+
+def gated_gelu(x):
+    Fh = x.shape[1] // 2
+    return (F.gelu(x.float()[:, :Fh], approximate="tanh").to(BF).float() * x.float()[:, Fh:]).to(BF)
+
+
+def attention_bias(qkv, bias, heads):
+    N, D = qkv.shape[0], heads * 64
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64).permute(1, 0, 2) for i in range(3))
+    s = (torch.einsum("hqd,hkd->hqk", q, k).to(BF).float() + bias.to(BF).float()).to(BF).float()
+    p = torch.softmax(s, dim=-1).to(BF).float()
+    return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
+
+
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 
