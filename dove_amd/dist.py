@@ -89,33 +89,76 @@ def split_batches(batches, world):
 
 
 class HaloCache(dict):
-    """conv_cache dict whose misses on the first local batch are filled by a recv from rank-1 and whose final
-    entries are sent to rank+1.  ``phase`` is set by the VAE driver loop: 'first' / 'last' / 'both' / 'mid'."""
+    """conv_cache dict whose misses on the first local batch are filled by a receive from rank-1 and whose final entries
+    are sent to rank+1.  ``phase`` is set by the VAE driver loop: 'first' / 'last' / 'both' / 'mid'.
 
-    def __init__(self, group, rank, world):
+    The exchange overlaps with compute (~75 ms of halo traffic vs ~118 ms of compute per rank at 8 GPUs):
+      * sends are ``isend``: on RCCL the transfer runs on the communicator's stream behind an event recorded at the call, so
+        the producing stream goes straight on to the conv; the handles (and tensors) are kept until ``finish()``;
+      * receives are PRE-POSTED: the order and shapes of a stage's causal convs are a function of (stage, input shape)
+        only, so the first run with a given shape records the plan (blocking receives) and every later run posts all of
+        its ``irecv``s up front, in conv order, into preallocated buffers - conv k's halo streams in while convs < k run,
+        and ``fetch`` merely waits on its handle (a stream-side wait on RCCL).
+    Order and bytes on the wire are those of the blocking version; results are bit-identical (gloo tests)."""
+
+    _plans: dict = {}                                   # (stage key) -> [(name, shape)] of the first local batch
+
+    def __init__(self, group, rank, world, plan_key=None):
         super().__init__()
         self.group, self.rank, self.world = group, rank, world
         self.phase = "mid"
         self.bytes_sent = 0
+        self.plan_key = plan_key
+        self._record = []
+        self._posted = {}                               # name -> (buffer, work)
+        self._sends = []
+        self._dev = None
 
     def _wire(self, t):
         return t.view(torch.uint8) if dist.get_backend(self.group) != "nccl" else t
 
+    def _peer(self, r):
+        return dist.get_global_rank(self.group, r) if self.group else r
+
+    def prepost(self, device):
+        """Post every receive of the first local batch when this (stage, shape) has been seen before."""
+        self._dev = device
+        plan = HaloCache._plans.get(self.plan_key)
+        if plan is None or self.rank == 0:
+            return
+        for name, shape in plan:
+            buf = torch.empty(shape, dtype=torch.bfloat16, device=device)
+            self._posted[name] = (buf, dist.irecv(self._wire(buf), src=self._peer(self.rank - 1), group=self.group))
+
     def fetch(self, name, like_shape, device):
         """Halo for conv ``name`` of the first local batch (None on rank 0: replicate-first-frame padding)."""
         if self.phase in ("first", "both") and self.rank > 0:
+            if name in self._posted:
+                buf, work = self._posted.pop(name)
+                assert tuple(buf.shape) == tuple(like_shape), (name, buf.shape, like_shape)
+                work.wait()
+                return buf
             buf = torch.empty(like_shape, dtype=torch.bfloat16, device=device)
-            dist.recv(self._wire(buf), src=dist.get_global_rank(self.group, self.rank - 1) if self.group else self.rank - 1,
-                      group=self.group)
+            dist.recv(self._wire(buf), src=self._peer(self.rank - 1), group=self.group)
+            self._record.append((name, tuple(like_shape)))
             return buf
         return self.get(name)
 
     def publish(self, name, new):
         self[name] = new
         if self.phase in ("last", "both") and self.rank < self.world - 1:
-            dist.send(self._wire(new.contiguous()), dst=dist.get_global_rank(self.group, self.rank + 1) if self.group else self.rank + 1,
-                      group=self.group)
+            t = new.contiguous()
+            self._sends.append((t, dist.isend(self._wire(t), dst=self._peer(self.rank + 1), group=self.group)))
             self.bytes_sent += new.numel() * 2
+
+    def finish(self):
+        """End of the stage: every send has left, every posted receive was consumed, the plan is remembered."""
+        for _, work in self._sends:
+            work.wait()
+        self._sends.clear()
+        assert not self._posted, f"pre-posted halos never consumed: {list(self._posted)}"
+        if self._record and self.plan_key is not None:
+            HaloCache._plans[self.plan_key] = list(self._record)
 
 
 def plan_pieces(batches, world, kind):
@@ -151,16 +194,37 @@ def plan_pieces(batches, world, kind):
     return out, r
 
 
+_side_groups: dict = {}
+
+
+def _side_group(group):
+    """A second communicator over the same ranks for the GroupNorm pair exchange of split frame-batches.  Point-to-point
+    messages between two ranks are matched strictly in order per communicator (RCCL has no tags), and pre-posted halo
+    receives would otherwise pair up with the partner's GroupNorm sums sent in between.  Created collectively on first use
+    for the default group; for a sub-group (whose non-members never get here) there is none and receives stay un-posted."""
+    if group is not None and group is not dist.group.WORLD:
+        return None
+    if "world" not in _side_groups:
+        _side_groups["world"] = dist.new_group(backend=dist.get_backend())
+    return _side_groups["world"]
+
+
 def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
     """Run ``fn(tensor, cache)`` over this rank's frame-batches or pieces of frame-batches (``plan_pieces``)."""
     from . import ops
     plan, active = plan_pieces(batches, world, kind)
     mine = plan[rank]
-    cache = HaloCache(group, rank, active)
+    paired = any(pc["partner"] is not None for r in plan for pc in r)
+    gn_group = _side_group(group) if paired else group
+    cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, id(group)))
+    if not paired or gn_group is not None:
+        cache.prepost(x_cl.device)
+    if gn_group is None:
+        gn_group = group
     outs = []
 
     def gsrc(r):
-        return dist.get_global_rank(group, r) if group else r
+        return dist.get_global_rank(group, r) if group else r      # the side group spans the same ranks in the same order
 
     for i, pc in enumerate(mine):
         first, last = i == 0, i == len(mine) - 1
@@ -175,11 +239,11 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
                 mine_msg = torch.cat([sums.reshape(-1), torch.tensor([cnt], dtype=torch.float64, device=sums.device)])
                 theirs = torch.empty_like(mine_msg)
                 if lower:
-                    dist.send(mine_msg, dst=gsrc(partner), group=group)
-                    dist.recv(theirs, src=gsrc(partner), group=group)
+                    dist.send(mine_msg, dst=gsrc(partner), group=gn_group)
+                    dist.recv(theirs, src=gsrc(partner), group=gn_group)
                 else:
-                    dist.recv(theirs, src=gsrc(partner), group=group)
-                    dist.send(mine_msg, dst=gsrc(partner), group=group)
+                    dist.recv(theirs, src=gsrc(partner), group=gn_group)
+                    dist.send(mine_msg, dst=gsrc(partner), group=gn_group)
                 a, b = (mine_msg, theirs) if lower else (theirs, mine_msg)      # same summation order on both ranks
                 tot = a + b
                 return ops.groupnorm_from_sums(tot[:64].reshape(32, 2).contiguous(), float(tot[64]), vae.eps)
@@ -189,12 +253,37 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
             outs.append(fn(x_cl[pc["s"]:pc["e"]], cache))
         finally:
             vae._gn_hook, vae._piece_role = None, None
+    cache.finish()
     return outs, cache
 
 
-def _gather_time(parts, group, world, device):
-    """All-gather variable-length [T_r, ...] tensors along T (every rank gets the whole clip)."""
+def _gather_time(parts, group, world, device, to="all"):
+    """Gather variable-length [T_r, ...] tensors along T.  ``to="all"``: every rank gets the whole tensor (all_gather);
+    ``to="writer"``: only rank 0 does (the others send their frames once and return None) - the decoded clip is 183 MB and
+    nobody but the writer needs it."""
     local = torch.cat(parts, dim=0) if parts else None
+    if to == "writer":
+        rank = dist.get_rank(group)
+        peer = (lambda r: dist.get_global_rank(group, r)) if group else (lambda r: r)
+        wire = (lambda t: t.view(torch.uint8)) if dist.get_backend(group) != "nccl" else (lambda t: t)
+        meta = torch.tensor(list(local.shape) if local is not None else [0, 0, 0, 0], dtype=torch.int64, device=device)
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=group)
+        if rank != 0:
+            if local is not None:
+                dist.send(wire(local.contiguous()), dst=peer(0), group=group)
+            return None
+        pieces = []
+        for r, m in enumerate(metas):
+            if int(m[0]) == 0:
+                continue
+            if r == 0:
+                pieces.append(local)
+                continue
+            buf = torch.empty(tuple(int(v) for v in m), dtype=torch.bfloat16, device=device)
+            dist.recv(wire(buf), src=peer(r), group=group)
+            pieces.append(buf)
+        return torch.cat(pieces, dim=0)
     shape = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
     mine = torch.tensor(list(local.shape) if local is not None else [0, 0, 0, 0], dtype=torch.int64, device=device)
     dist.all_gather(shape, mine, group=group)
@@ -264,31 +353,32 @@ def encode_sharded(vae, x, group=None):
 
 
 @torch.no_grad()
-def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0):
-    """vae.decode with latent frame-batches sharded over ranks; every rank returns the full [1,3,F,H,W] video."""
+def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0, gather="all"):
+    """vae.decode with latent frame-batches sharded over ranks.  ``gather``: "all" - every rank returns the full [1,3,F,H,W]
+    video; "writer" - rank 0 does, the others return None; "none" - every rank returns only ITS frames [1,3,F_r,H,W]
+    (no data-path collective at all: each rank writes its own frames, like the chunk farm)."""
     from . import ops
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     assert z.shape[0] == 1
     z = z.to(vae.device).contiguous()
     z_cl = ops.cl_from_ncthw(z[0], vae.pc["decoder.conv_in"].cin_pad, scale=_prescale)
     outs, cache = _run_sharded(vae, z_cl, frame_batches(z_cl.shape[0], vae.dec_batch), world, rank, group, vae._decoder, "dec")
-    full = _gather_time(outs, group, world, vae.device)          # [F,H,W,4] channels-last
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
     vae.last_halo_bytes = cache.bytes_sent
+    if gather == "none":
+        if not outs:
+            return None
+        local = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        return ops.ncthw_from_cl(local.contiguous(), vae.config["out_channels"], vae.dtype, **post)[None]
+    full = _gather_time(outs, group, world, vae.device, to=gather)          # [F,H,W,4] channels-last
+    if full is None:
+        return None
     return ops.ncthw_from_cl(full, vae.config["out_channels"], vae.dtype, **post)[None]
 
 
 # ---- (C) sequence / head parallel DiT -------------------------------------------------------------------
 def _row_bounds(n, world):
     return [(i * n) // world for i in range(world + 1)]
-
-
-def _a2a(out_splits, inp, in_splits, group):
-    """all_to_all_single on a flat bf16 tensor (moved as bytes: gloo has no bf16 wire type)."""
-    out = torch.empty(sum(out_splits), dtype=inp.dtype, device=inp.device)
-    dist.all_to_all_single(out.view(torch.uint8), inp.contiguous().view(torch.uint8), [2 * v for v in out_splits],
-                           [2 * v for v in in_splits], group=group)
-    return out
 
 
 @torch.no_grad()
@@ -331,38 +421,54 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     cos_l, sin_l = cos[v0:v1].contiguous(), sin[v0:v1].contiguous()
     if v1 == v0:                                               # a text-only shard still hands a valid table to the kernel
         cos_l, sin_l = cos[:1].contiguous(), sin[:1].contiguous()
-    nlpad = (nloc + 127) // 128 * 128
+    # Buffers are allocated ONCE per call and reused by all layers.  Rank-local head-major operands are packed with row
+    # stride nloc (no pad rows), so "my rows of rank j's heads" is one contiguous chunk and Ql / Kl / Vl ARE the all-to-all
+    # send buffers; the receive buffers are persistent too and the only per-layer data movement besides the collective is
+    # the re-interleave of the received [source rank][head][rows] blocks into the kernel's [head][all rows] layout.
     z = lambda *shp: torch.zeros(*shp, dtype=torch.bfloat16, device=dev)   # noqa: E731
-    Ql, Kl, Vl = z(heads, nlpad, 64), z(heads, nlpad, 64), z(heads, 64, nlpad)
-    Qh, Kh, Vt = z(hloc, npad, 64), z(hloc, npad, 64), z(hloc, 64, npad)
+    e = lambda *shp: torch.empty(*shp, dtype=torch.bfloat16, device=dev)   # noqa: E731
+    Ql, Kl, Vl = e(heads, nloc, 64), e(heads, nloc, 64), e(heads, 64, nloc)
+    Qh, Kh, Vt = z(hloc, npad, 64), z(hloc, npad, 64), z(hloc, 64, npad)     # pad rows / columns stay zero across layers
     qscale = (tr.hd ** -0.5) * math.log2(math.e)
     blk_in = [c * hloc * 64 for c in counts]                    # elements I receive from each source rank
+    blk_out = [nloc * hloc * 64] * world
+    rq, rk, rv = e(N * hloc * 64), e(N * hloc * 64), e(N * hloc * 64)
+    att = e(N, hloc * 64)
+    back = e(nloc * hloc * 64 * world)
+    att_loc = e(nloc, D)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c * hloc * 64)
 
-    def rows_to_heads(loc, transposed):
-        # loc: [heads, nloc, 64] (or [heads, 64, nloc]); destination j gets my rows of ITS heads
-        src = (loc[:, :, :nloc] if transposed else loc[:, :nloc]).contiguous()
-        got = _a2a(blk_in, src.view(-1), [nloc * hloc * 64] * world, group)
-        parts, off = [], 0
-        for c in counts:
-            blk = got[off:off + c * hloc * 64]
-            parts.append(blk.view(hloc, 64, c) if transposed else blk.view(hloc, c, 64))
-            off += c * hloc * 64
-        return torch.cat(parts, dim=2 if transposed else 1)
+    def a2a(out, inp, out_splits, in_splits):
+        dist.all_to_all_single(out.view(torch.uint8), inp.view(torch.uint8), [2 * v for v in out_splits], [2 * v for v in in_splits],
+                               group=group)
+
+    def place(dst, got, transposed):
+        # got = [source rank i][hloc][rows of i][64] (or [hloc][64][rows of i]); dst = [hloc][all rows][64] (or [hloc][64][all rows])
+        for i, c in enumerate(counts):
+            blk = got[offs[i]:offs[i + 1]]
+            if transposed:
+                dst[:, :, bounds[i]:bounds[i + 1]] = blk.view(hloc, 64, c)
+            else:
+                dst[:, bounds[i]:bounds[i + 1]] = blk.view(hloc, c, 64)
 
     for blk, md in zip(tr.blocks, blocks_mod):
         n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], tr.eps, md["m1"], lt_loc)
         qkv = ops.linear(n1, blk["qkv"])
-        ops.qkv_post(qkv, nloc, nlpad, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
+        ops.qkv_post(qkv, nloc, nloc, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
                      qscale, 1e-6, Ql, Kl, Vl)
-        Qh[:, :N] = rows_to_heads(Ql, False)
-        Kh[:, :N] = rows_to_heads(Kl, False)
-        Vt[:, :, :N] = rows_to_heads(Vl, True)
-        att = torch.empty(N, hloc * 64, dtype=torch.bfloat16, device=dev)
+        a2a(rq, Ql.view(-1), blk_in, blk_out)
+        a2a(rk, Kl.view(-1), blk_in, blk_out)
+        a2a(rv, Vl.view(-1), blk_in, blk_out)
+        place(Qh, rq, False)
+        place(Kh, rk, False)
+        place(Vt, rv, True)
         ops.attention(Qh, Kh, Vt, N, npad, hloc, att)
         # heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
-        back = _a2a([nloc * hloc * 64] * world, att.view(-1), blk_in, group)
-        att_loc = torch.cat([back[i * nloc * hloc * 64:(i + 1) * nloc * hloc * 64].view(nloc, hloc * 64) for i in range(world)],
-                            dim=1).contiguous()
+        a2a(back, att.view(-1), blk_out, blk_in)
+        for i in range(world):
+            att_loc[:, i * hloc * 64:(i + 1) * hloc * 64] = back[i * nloc * hloc * 64:(i + 1) * nloc * hloc * 64].view(nloc, hloc * 64)
         ops.linear(att_loc, blk["out"], resid=hs, gate=md["gate1"], gate_split=lt_loc, out=hs)
         n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], tr.eps, md["m2"], lt_loc, out=n1)
         f1 = ops.linear(n2, blk["ff1"], act=1)
@@ -410,8 +516,8 @@ class _ShardedTransformer:
 class _ShardedPipe:
     """Duck-typed ``pipe`` whose VAE and transformer run sharded over ``group`` (what process_video touches, nothing more)."""
 
-    def __init__(self, pipe, group):
-        self._pipe, self._group = pipe, group
+    def __init__(self, pipe, group, gather="all"):
+        self._pipe, self._group, self._gather = pipe, group, gather
         self.vae = _ShardedVAE(pipe.vae, group)
         self.transformer = _ShardedTransformer(pipe.transformer, group)
         self.scheduler = _SharedScheduler(pipe.scheduler, group)
@@ -420,13 +526,14 @@ class _ShardedPipe:
     def decode_latents(self, latents, _range01=False):
         z = latents.permute(0, 2, 1, 3, 4).contiguous()
         return decode_sharded(self._pipe.vae, z, self._group, _range01=_range01,
-                              _prescale=1.0 / float(self._pipe.vae.config["scaling_factor"]))
+                              _prescale=1.0 / float(self._pipe.vae.config["scaling_factor"]), gather=self._gather)
 
 
 @torch.no_grad()
-def process_video_sharded(pipe, video, *, group=None, **kw):
+def process_video_sharded(pipe, video, *, group=None, gather="all", **kw):
     """``process_video`` on ONE clip with every stage sharded over the ranks of ``group``: halo-exact VAE (B) and
     sequence/head-parallel DiT (C).  All ranks must pass the same clip; random draws (posterior sample, optional
     pre-noising) are rank 0's, broadcast, so the ranks stay consistent whatever their RNG states.  All ranks return the
-    full SR clip, bit-identical to the single-GPU result given rank 0's noise."""
-    return process_video(_ShardedPipe(pipe, group), video, **kw)
+    full SR clip (``gather="all"``), only rank 0 does (``"writer"``), or every rank keeps just the frames it decoded
+    (``"none"``) - bit-identical to the single-GPU result given rank 0's noise."""
+    return process_video(_ShardedPipe(pipe, group, gather), video, **kw)

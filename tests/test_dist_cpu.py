@@ -88,6 +88,27 @@ def _worker(rank, world, port, mode, q):
             z = torch.randn(1, 16, p_sh.shape[2], 2, 4, generator=g).to(torch.bfloat16)
             d_sh = ddist.decode_sharded(pipe.vae, z, _range01=True)
             halo = pipe.vae.last_halo_bytes
+            # second pass: the halo plan of this (stage, shape) is known now, so every receive is PRE-POSTED (irecv) and the
+            # sends are isend - the overlapped path must give the same bits; then the cheaper gather modes
+            assert ddist.HaloCache._plans or rank == 0 or world == 1
+            p_again = ddist.encode_sharded(pipe.vae, video).parameters
+            d_again = ddist.decode_sharded(pipe.vae, z, _range01=True)
+            assert torch.equal(p_again, p_sh) and torch.equal(d_again, d_sh), "pre-posted halo exchange changed the result"
+            d_writer = ddist.decode_sharded(pipe.vae, z, _range01=True, gather="writer")
+            assert (d_writer is None) == (rank != 0) and (rank != 0 or torch.equal(d_writer, d_sh))
+            d_mine = ddist.decode_sharded(pipe.vae, z, _range01=True, gather="none")
+            nf = torch.tensor([0 if d_mine is None else d_mine.shape[2]])
+            dist.all_reduce(nf)
+            assert int(nf) == d_sh.shape[2], "per-rank frame slices do not add up to the clip"
+            if d_mine is not None:
+                f0 = torch.tensor([0 if d_mine is None else d_mine.shape[2]])
+                starts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+                dist.all_gather(starts, f0)
+                s0 = int(sum(int(x) for x in starts[:rank]))
+                assert torch.equal(d_mine, d_sh[:, :, s0:s0 + d_mine.shape[2]])
+            else:
+                starts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+                dist.all_gather(starts, torch.zeros(1, dtype=torch.long))
             if rank == 0:
                 p_ref = pipe.vae.encode(video).latent_dist.parameters
                 d_ref = pipe.vae.decode(z, _range01=True).sample
