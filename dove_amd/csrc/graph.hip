@@ -1,0 +1,904 @@
+// Graph-level entry points (SURVEY.md 8(b) "proposed C-ABI beneath the facade"): a context that owns the packed weights and
+// one workspace arena and runs whole stages of the one-step SR operator - so a host in any language drives the path with a
+// handful of calls and no per-operator allocation:
+//     dove_create -> dove_set_weight (diffusers state-dict names) x N -> dove_finalize_weights
+//     dove_vae_encode / dove_dit_forward / dove_vae_decode, or dove_sr_clip = process_video
+//     (/root/reference/inference_script.py:394-503: encode -> sample * scaling -> first-frame pad -> DiT -> get_velocity ->
+//      decode -> (x*0.5+0.5).clamp(0,1)).
+// This file is HOST orchestration only (plus two trivial conversion kernels): every FLOP goes through the operator entry
+// points of this library, called in exactly the order dove_amd/vae.py and dove_amd/transformer.py call them, so the results
+// are bit-identical to the Python facade (tests/test_graph_gpu.py) - the arithmetic is diffusers' (SURVEY.md App. A.1-A.6).
+// Memory: activations come from ONE arena (first-fit free list, stream-ordered reuse: a block is released as soon as the
+// last kernel reading it has been enqueued); causal-conv caches (diffusers' conv_cache: the last two input frames of every
+// k_t = 3 convolution) are copied out of the batch's activations into per-conv buffers, so nothing outlives its frame-batch.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "../../include/dove_hip.h"
+
+namespace {
+
+#define CHK(expr)            \
+  do {                       \
+    const int rc__ = (expr); \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+#define HIPCHK(expr)                                                              \
+  do {                                                                            \
+    const hipError_t e__ = (expr);                                                \
+    if (e__ != hipSuccess) {                                                      \
+      dove_set_error("%s failed: %s", #expr, hipGetErrorString(e__));             \
+      return DOVE_ELAUNCH;                                                        \
+    }                                                                             \
+  } while (0)
+
+inline long long ru(long long x, long long m) { return (x + m - 1) / m * m; }
+
+// ---- conversion kernels (weight packing happens once, at dove_finalize_weights) -----------------------------------------------
+__device__ inline float load_any(const void* p, int dt, long long i) {
+  return dt == DOVE_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+}
+// src [cout][cin][taps] (Conv3d / Conv2d / Linear weight, natural layout) -> dst rows [row0, row0+cout) of [taps][cout_pad][cin_pad] bf16
+__global__ void pack_weight_kernel(const void* src, int dt, int cout, int cin, int taps, int cout_pad, int cin_pad, int row0, bf16_t* dst) {
+  const long long n = (long long)taps * cout * cin_pad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin_pad);
+    const long long r = i / cin_pad;
+    const int co = (int)(r % cout), t = (int)(r / cout);
+    const float v = ci < cin ? load_any(src, dt, ((long long)co * cin + ci) * taps + t) : 0.f;
+    dst[((long long)t * cout_pad + row0 + co) * cin_pad + ci] = f2bf(v);
+  }
+}
+__global__ void to_f32_kernel(const void* src, int dt, long long n, float* dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = load_any(src, dt, i);
+}
+__global__ void to_bf16_kernel(const void* src, int dt, long long n, bf16_t* dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = f2bf(load_any(src, dt, i));
+}
+
+// rows of `width` bytes (multiple of 2) between pitched device buffers (hipMemcpy2DAsync rejects some pitches)
+__global__ void copy2d_kernel(char* dst, long long dpitch, const char* src, long long spitch, long long width, int height) {
+  const long long w2 = width >> 1, n = w2 * height;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / w2, c = i - r * w2;
+    ((uint16_t*)(dst + r * dpitch))[c] = ((const uint16_t*)(src + r * spitch))[c];
+  }
+}
+inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int height, hipStream_t s) {
+  const long long n = (long long)(width >> 1) * height;
+  const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, (char*)dst, (long long)dpitch, (const char*)src, (long long)spitch,
+                     (long long)width, height);
+  return hipGetLastError() == hipSuccess ? 0 : DOVE_ELAUNCH;
+}
+
+struct Raw { const void* p; std::vector<long long> shape; int dt; long long numel() const { long long n = 1; for (auto d : shape) n *= d; return n; } };
+struct Packed { bf16_t* w = nullptr; float* bias = nullptr; int kt = 1, kh = 1, kw = 1, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
+                int cout_store() const { return (int)ru(cout, 4); } };
+struct Tensor { bf16_t* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long long elems() const { return (long long)T * H * W * C; } size_t bytes() const { return (size_t)elems() * 2; } };
+struct Stats { float* stats = nullptr; };
+
+// first-fit arena over one device allocation; offsets 256-byte aligned
+struct Arena {
+  char* base = nullptr; size_t cap = 0; bool owned = false; size_t used = 0, high = 0;   // high = peak of bytes in use
+  std::map<size_t, size_t> free_;                       // offset -> size
+  std::unordered_map<void*, size_t> live;
+  void reset() { free_.clear(); live.clear(); used = 0; if (cap) free_[0] = cap; }
+  // transient activations are carved first-fit from the FRONT; long-lived blocks (conv caches, which persist for a whole stage)
+  // from the BACK, so they do not fragment the space the big per-layer tensors cycle through
+  void* alloc(size_t n, bool from_back = false) {
+    n = (size_t)ru((long long)(n ? n : 1), 256);
+    if (from_back) {
+      for (auto it = free_.rbegin(); it != free_.rend(); ++it) {
+        if (it->second >= n) {
+          const size_t off = it->first, sz = it->second;
+          free_.erase(std::next(it).base());
+          if (sz > n) free_[off] = sz - n;
+          void* p = base + off + (sz - n);
+          live[p] = n;
+          used += n;
+          if (used > high) high = used;
+          return p;
+        }
+      }
+      return nullptr;
+    }
+    for (auto it = free_.begin(); it != free_.end(); ++it) {
+      if (it->second >= n) {
+        const size_t off = it->first, rest = it->second - n;
+        free_.erase(it);
+        if (rest) free_[off + n] = rest;
+        void* p = base + off;
+        live[p] = n;
+        used += n;
+        if (used > high) high = used;
+        return p;
+      }
+    }
+    return nullptr;
+  }
+  void release(void* p) {
+    if (!p) return;
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    size_t off = (char*)p - base, n = it->second;
+    live.erase(it);
+    used -= n;
+    auto nx = free_.lower_bound(off);
+    if (nx != free_.end() && off + n == nx->first) { n += nx->second; nx = free_.erase(nx); }
+    if (nx != free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; n += pv->second; free_.erase(pv); } }
+    free_[off] = n;
+  }
+};
+
+struct DitBlock {
+  bf16_t *mod1_w, *mod2_w; float *mod1_b, *mod2_b;      // norm1.linear / norm2.linear (M = 1 GEMV operands)
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *nq_g, *nq_b, *nk_g, *nk_b;
+  Packed qkv, out, ff1, ff2;
+  float *m1 = nullptr, *g1 = nullptr, *m2 = nullptr, *g2 = nullptr;   // per-timestep: mod [2][2][D], gate [2][D]
+};
+
+}  // namespace
+
+struct dove_ctx {
+  dove_model_config cfg;
+  int device = 0;
+  std::unordered_map<std::string, Raw> raw;
+  std::unordered_map<std::string, Packed> pc;           // VAE convs by diffusers module path (+ ".yb" for SpatialNorm conv_y || conv_b)
+  std::unordered_map<std::string, std::pair<float*, float*>> aff;
+  std::vector<void*> owned;                             // weight memory owned by the library
+  bool finalized = false;
+  // DiT
+  Packed pe_proj, pe_text, proj_out;
+  bf16_t *te1_w = nullptr, *te2_w = nullptr, *modout_w = nullptr; float *te1_b = nullptr, *te2_b = nullptr, *modout_b = nullptr;
+  float *nf_g = nullptr, *nf_b = nullptr, *no_g = nullptr, *no_b = nullptr, *final_mod = nullptr;
+  std::vector<DitBlock> blocks;
+  int mod_t = -1;
+  float *emb = nullptr, *e1 = nullptr, *temb = nullptr, *vtmp = nullptr;
+  // rope cache
+  std::vector<float> rope_host; float* rope_dev = nullptr; int rope_t = 0, rope_h = 0, rope_w = 0;
+  // attention operand buffers (pad rows must stay zero)
+  bf16_t *Qh = nullptr, *Kh = nullptr, *Vt = nullptr; long long attn_n = 0;
+  // VAE
+  std::unordered_map<std::string, Tensor> cache;        // conv_cache of the running clip (views or copies)
+  std::unordered_map<std::string, void*> cache_owner;   // arena block a cache entry keeps alive (a retained conv input) or the copy itself
+  float* gn_ws = nullptr;
+  Arena arena;
+  std::string err;
+};
+
+namespace {
+
+int dev_alloc(dove_ctx* c, size_t bytes, void** out) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, bytes ? bytes : 4));
+  c->owned.push_back(p);
+  *out = p;
+  return 0;
+}
+int need(dove_ctx* c, const std::string& name, const Raw** out, int ndim_min = 1) {
+  auto it = c->raw.find(name);
+  if (it == c->raw.end()) { dove_set_error("weight '%s' was never set", name.c_str()); return DOVE_EINVAL; }
+  if ((int)it->second.shape.size() < ndim_min) { dove_set_error("weight '%s' has too few dimensions", name.c_str()); return DOVE_EINVAL; }
+  *out = &it->second;
+  return 0;
+}
+int to_f32(dove_ctx* c, const std::string& name, float** out, long long expect = -1) {
+  const Raw* r; CHK(need(c, name, &r));
+  if (expect >= 0 && r->numel() != expect) { dove_set_error("weight '%s' has %lld elements, expected %lld", name.c_str(), r->numel(), expect); return DOVE_EINVAL; }
+  void* p; CHK(dev_alloc(c, (size_t)r->numel() * 4, &p));
+  hipLaunchKernelGGL(to_f32_kernel, dim3(256), dim3(256), 0, 0, r->p, r->dt, r->numel(), (float*)p);
+  *out = (float*)p;
+  return 0;
+}
+int to_bf16(dove_ctx* c, const std::string& name, bf16_t** out) {
+  const Raw* r; CHK(need(c, name, &r));
+  void* p; CHK(dev_alloc(c, (size_t)r->numel() * 2, &p));
+  hipLaunchKernelGGL(to_bf16_kernel, dim3(1024), dim3(256), 0, 0, r->p, r->dt, r->numel(), (bf16_t*)p);
+  *out = (bf16_t*)p;
+  return 0;
+}
+// pack one or several weights (stacked along cout) + optional biases into the implicit-GEMM layout (dove_amd/ops.py pack_conv)
+int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, Packed* out) {
+  Packed q;
+  int cout = 0;
+  std::vector<const Raw*> ws;
+  for (auto& n : wnames) {
+    const Raw* r; CHK(need(c, n, &r, 2));
+    ws.push_back(r);
+    const auto& s = r->shape;
+    const int nd = (int)s.size();
+    const int kt = nd == 5 ? (int)s[2] : 1, kh = nd >= 4 ? (int)s[nd - 2] : 1, kw = nd >= 4 ? (int)s[nd - 1] : 1;
+    if (cout == 0) { q.kt = kt; q.kh = kh; q.kw = kw; q.cin = (int)s[1]; }
+    else if (q.kt != kt || q.kh != kh || q.kw != kw || q.cin != (int)s[1]) { dove_set_error("cannot stack '%s': shape mismatch", n.c_str()); return DOVE_EINVAL; }
+    cout += (int)s[0];
+  }
+  q.cout = cout;
+  q.cin_pad = (q.cin <= 32 || q.cin % 64) ? (int)ru(q.cin, 32) : q.cin;
+  q.cout_pad = (int)ru(cout, 32);
+  const int taps = q.kt * q.kh * q.kw;
+  const size_t wbytes = (size_t)taps * q.cout_pad * q.cin_pad * 2;
+  void* wp; CHK(dev_alloc(c, wbytes, &wp));
+  HIPCHK(hipMemsetAsync(wp, 0, wbytes, 0));
+  int row0 = 0;
+  for (auto r : ws) {
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(1024), dim3(256), 0, 0, r->p, r->dt, (int)r->shape[0], q.cin, taps, q.cout_pad, q.cin_pad, row0, (bf16_t*)wp);
+    row0 += (int)r->shape[0];
+  }
+  q.w = (bf16_t*)wp;
+  if (!bnames.empty()) {
+    void* bp; CHK(dev_alloc(c, (size_t)q.cout_pad * 4, &bp));
+    HIPCHK(hipMemsetAsync(bp, 0, (size_t)q.cout_pad * 4, 0));
+    int off = 0;
+    for (auto& n : bnames) {
+      const Raw* r; CHK(need(c, n, &r));
+      hipLaunchKernelGGL(to_f32_kernel, dim3(16), dim3(256), 0, 0, r->p, r->dt, r->numel(), (float*)bp + off);
+      off += (int)r->numel();
+    }
+    q.bias = (float*)bp;
+  }
+  *out = q;
+  return 0;
+}
+bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
+
+// ---- operator wrappers (allocation from the arena + argument marshalling; mirrors dove_amd/ops.py) -----------------------------
+int alloc_t(dove_ctx* c, int T, int H, int W, int C, Tensor* t) {
+  t->T = T; t->H = H; t->W = W; t->C = C;
+  t->p = (bf16_t*)c->arena.alloc(t->bytes());
+  if (!t->p) { dove_set_error("workspace exhausted: need %zu more bytes (capacity %zu); call dove_workspace_bytes / dove_set_workspace", t->bytes(), c->arena.cap); return DOVE_EINVAL; }
+  return 0;
+}
+void free_t(dove_ctx* c, Tensor& t) { c->arena.release(t.p); t.p = nullptr; }
+
+struct ConvOpt { const Tensor* cache = nullptr; int stride = 1, pad_h = -1, pad_w = -1, up = 0, tmode = 0, t_out = -1, act = 0;
+                 const bf16_t* resid = nullptr; int ldr = 0; const float* gate = nullptr; long long gate_split = 0; bf16_t* out = nullptr; int ldo = -1;
+                 float gn_eps = -1.f; float** gn_stats = nullptr; };
+// x [T,H,W,cin_pad] -> out (allocated unless opt.out).  When opt.gn_eps >= 0 and the kernel fuses GroupNorm statistics, *opt.gn_stats
+// receives [32][2] (mean, rstd) from the arena (caller releases); otherwise it is left NULL.
+int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tensor* out, void* stream) {
+  if (x.C != pc.cin_pad) { dove_set_error("conv: input has %d channels, packed weight expects %d", x.C, pc.cin_pad); return DOVE_EINVAL; }
+  const int ph = o.pad_h < 0 ? (pc.kh - 1) / 2 : o.pad_h, pw = o.pad_w < 0 ? (pc.kw - 1) / 2 : o.pad_w;
+  const int t_out = o.t_out < 0 ? x.T : o.t_out;
+  int ho, wo;
+  if (o.stride == 1) { ho = x.H << o.up; wo = x.W << o.up; }
+  else { ho = (x.H + 1 - pc.kh) / o.stride + 1; wo = (x.W + 1 - pc.kw) / o.stride + 1; }
+  const int ldo = o.ldo < 0 ? pc.cout_store() : o.ldo;
+  Tensor y;
+  if (o.out) { y.p = o.out; y.T = t_out; y.H = ho; y.W = wo; y.C = ldo; }
+  else CHK(alloc_t(c, t_out, ho, wo, ldo, &y));
+  dove_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
+  d.t_in = x.T; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
+  d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
+  d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
+  d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;
+  float* partial = nullptr;
+  long long rows = 0;
+  if (o.gn_eps >= 0.f && o.gn_stats && ldo == pc.cout_store()) {
+    rows = dove_conv_gn_partial_rows(&d);
+    if (rows > 0) {
+      partial = (float*)c->arena.alloc((size_t)rows * 64 * 4);
+      if (!partial) { dove_set_error("workspace exhausted (GroupNorm partials)"); return DOVE_EINVAL; }
+      d.gn_partial = partial;
+    }
+  }
+  CHK(dove_conv_igemm_bf16(&d, stream));
+  if (o.gn_stats) *o.gn_stats = nullptr;
+  if (partial) {
+    float* st = (float*)c->arena.alloc(64 * 4);
+    const double count = (double)t_out * ho * wo * (pc.cout_store() / 32);
+    CHK(dove_groupnorm_finalize_partials(partial, rows, count, o.gn_eps, c->gn_ws, st, stream));
+    c->arena.release(partial);
+    *o.gn_stats = st;
+  }
+  *out = y;
+  return 0;
+}
+int linear(dove_ctx* c, const bf16_t* x, long long N, const Packed& pc, ConvOpt o, bf16_t** out, void* stream) {
+  Tensor xt; xt.p = (bf16_t*)x; xt.T = 1; xt.H = 1; xt.W = (int)N; xt.C = pc.cin_pad;
+  Tensor y;
+  CHK(conv(c, xt, pc, o, &y, stream));
+  *out = y.p;
+  return 0;
+}
+
+// ---- VAE (dove_amd/vae.py) ------------------------------------------------------------------------------------------------------
+void frame_batches(int n, int batch, std::vector<std::pair<int, int>>* out) {
+  const int nb = n / batch > 0 ? n / batch : 1, rem = n % batch;
+  for (int i = 0; i < nb; ++i) {
+    const int s = batch * i + (i == 0 ? 0 : rem), e = batch * (i + 1) + rem;
+    out->push_back({s, e < n ? e : n});
+  }
+}
+void spatial_norm_tmap(int tf, int tz, std::vector<int>* m) {
+  m->resize(tf);
+  if (tf > 1 && tf % 2 == 1) {
+    for (int t = 0; t < tf; ++t) (*m)[t] = tz == 1 ? 0 : (t == 0 ? 0 : 1 + ((t - 1) * (tz - 1)) / (tf - 1));
+  } else {
+    for (int t = 0; t < tf; ++t) (*m)[t] = (int)(((long long)t * tz) / tf);
+  }
+}
+// CogVideoXCausalConv3d with conv_cache (the last kt-1 INPUT frames of this conv, consumed by the next frame-batch).
+// `x_owned`: x is an arena block the caller is done with.  Then, memory permitting, the cache simply KEEPS x alive and points at
+// its last frames (what the Python facade's tensor views do; no copy) - the block is released when the next batch's conv has
+// replaced the entry.  Otherwise (x is a view, the arena is tight, or x has fewer frames than the halo) the frames are copied into
+// a small block at the back of the arena and x is released here.  Either way x must not be touched by the caller afterwards.
+int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt o, Tensor* out, void* stream) {
+  const Packed& pc = c->pc.at(name);
+  if (pc.kt == 1) {
+    CHK(conv(c, x, pc, o, out, stream));
+    if (x_owned) free_t(c, x);
+    return 0;
+  }
+  const int k = pc.kt - 1;
+  auto it = c->cache.find(name);
+  Tensor prev;
+  const bool have = it != c->cache.end();
+  if (have) prev = it->second;
+  o.cache = have ? &prev : nullptr;
+  CHK(conv(c, x, pc, o, out, stream));
+  const long long frame = (long long)x.H * x.W * x.C;
+  hipStream_t s = (hipStream_t)stream;
+  void* old_owner = have ? c->cache_owner[name] : nullptr;
+  Tensor nc; nc.T = k; nc.H = x.H; nc.W = x.W; nc.C = x.C;
+  if (x_owned && x.T >= k && c->arena.cap - c->arena.used > 8 * x.bytes()) {
+    nc.p = x.p + (long long)(x.T - k) * frame;               // retain: a view of x's last k frames, x stays alive
+    c->cache[name] = nc; c->cache_owner[name] = x.p;
+    c->arena.release(old_owner);                              // the conv that read the old entry is already enqueued
+    x.p = nullptr;
+    return 0;
+  }
+  nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
+  if (!nc.p) { dove_set_error("workspace exhausted (conv cache of %s: %zu bytes)", name.c_str(), nc.bytes()); return DOVE_EINVAL; }
+  if (x.T >= k) {
+    HIPCHK(hipMemcpyAsync(nc.p, x.p + (long long)(x.T - k) * frame, (size_t)k * frame * 2, hipMemcpyDeviceToDevice, s));
+  } else {                                                    // fewer frames than the halo: slide the padded window
+    for (int j = 0; j < k - x.T; ++j) {
+      const bf16_t* src = have ? prev.p + (long long)(j + x.T) * frame : x.p;   // old cache frames move up / frame 0 replicated
+      HIPCHK(hipMemcpyAsync(nc.p + (long long)j * frame, src, (size_t)frame * 2, hipMemcpyDeviceToDevice, s));
+    }
+    HIPCHK(hipMemcpyAsync(nc.p + (long long)(k - x.T) * frame, x.p, (size_t)x.T * frame * 2, hipMemcpyDeviceToDevice, s));
+  }
+  c->cache[name] = nc; c->cache_owner[name] = nc.p;
+  c->arena.release(old_owner);
+  if (x_owned) free_t(c, x);
+  return 0;
+}
+int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::string& name, const Tensor* zq, Tensor* out, void* stream) {
+  const float eps = c->cfg.vae_norm_eps;
+  float* stats = fused_stats;
+  if (!stats) {
+    stats = (float*)c->arena.alloc(64 * 4);
+    CHK(dove_groupnorm_stats_bf16(x.p, x.elems() / x.C, x.C, eps, c->gn_ws, 2048, stats, stream));
+  }
+  const auto& gb = c->aff.at(name);
+  CHK(alloc_t(c, x.T, x.H, x.W, x.C, out));
+  if (!zq) {
+    CHK(dove_groupnorm_apply_bf16(x.p, out->p, x.T, x.H, x.W, x.C, stats, gb.first, gb.second, 1, nullptr, 0, 0, 0, nullptr, stream));
+  } else {
+    Tensor yb;
+    CHK(conv(c, *zq, c->pc.at(name + ".yb"), ConvOpt(), &yb, stream));
+    const int ratio = x.H / zq->H;
+    int sshift = 0;
+    while ((1 << sshift) < ratio) ++sshift;
+    std::vector<int> tmap;
+    spatial_norm_tmap(x.T, zq->T, &tmap);
+    CHK(dove_groupnorm_apply_bf16(x.p, out->p, x.T, x.H, x.W, x.C, stats, gb.first, gb.second, 1, yb.p, yb.H, yb.W, sshift, tmap.data(), stream));
+    free_t(c, yb);
+  }
+  c->arena.release(stats);
+  return 0;
+}
+// x (+ its fused stats, consumed) -> block output (+ its fused stats).  x is released.
+int resnet(dove_ctx* c, Tensor* x, float** xstats, const std::string& name, const Tensor* zq, void* stream) {
+  const float eps = c->cfg.vae_norm_eps;
+  Tensor h1, h, h2, y;
+  CHK(norm_silu(c, *x, *xstats, name + ".norm1", zq, &h1, stream));
+  float* hs = nullptr;
+  ConvOpt o1; o1.gn_eps = eps; o1.gn_stats = &hs;
+  CHK(cconv(c, h1, true, name + ".conv1", o1, &h, stream));
+  CHK(norm_silu(c, h, hs, name + ".norm2", zq, &h2, stream));
+  free_t(c, h);
+  Tensor sc = *x;
+  bool own_sc = false;
+  auto it = c->pc.find(name + ".conv_shortcut");
+  if (it != c->pc.end()) { CHK(conv(c, *x, it->second, ConvOpt(), &sc, stream)); own_sc = true; }
+  float* ys = nullptr;
+  ConvOpt o2; o2.resid = sc.p; o2.ldr = sc.C; o2.gn_eps = eps; o2.gn_stats = &ys;
+  CHK(cconv(c, h2, true, name + ".conv2", o2, &y, stream));
+  if (own_sc) free_t(c, sc);
+  free_t(c, *x);
+  *x = y; *xstats = ys;
+  return 0;
+}
+int encoder(dove_ctx* c, const Tensor& x, Tensor* out, void* stream) {
+  const auto& cf = c->cfg;
+  Tensor h; float* hs = nullptr;
+  Tensor xin = x;
+  CHK(cconv(c, xin, false, "encoder.conv_in", ConvOpt(), &h, stream));
+  char nm[128];
+  int n_tdown = 0;
+  for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
+  for (int i = 0; i < cf.vae_num_blocks; ++i) {
+    for (int j = 0; j < cf.vae_layers_per_block; ++j) { snprintf(nm, sizeof nm, "encoder.down_blocks.%d.resnets.%d", i, j); CHK(resnet(c, &h, &hs, nm, nullptr, stream)); }
+    if (i < cf.vae_num_blocks - 1) {
+      snprintf(nm, sizeof nm, "encoder.down_blocks.%d.downsamplers.0", i);
+      if (hs) { c->arena.release(hs); hs = nullptr; }
+      Tensor p = h;
+      if (i < n_tdown && h.T > 1) {
+        const int To = h.T % 2 ? 1 + (h.T - 1) / 2 : h.T / 2;
+        CHK(alloc_t(c, To, h.H, h.W, h.C, &p));
+        CHK(dove_avgpool_time_bf16(h.p, h.T, (long long)h.H * h.W * h.C, p.p, stream));
+        free_t(c, h);
+      }
+      ConvOpt od; od.stride = 2; od.pad_h = 0; od.pad_w = 0;
+      Tensor d;
+      CHK(conv(c, p, c->pc.at(nm), od, &d, stream));
+      free_t(c, p);
+      h = d;
+    }
+  }
+  for (int j = 0; j < 2; ++j) { snprintf(nm, sizeof nm, "encoder.mid_block.resnets.%d", j); CHK(resnet(c, &h, &hs, nm, nullptr, stream)); }
+  Tensor n;
+  CHK(norm_silu(c, h, hs, "encoder.norm_out", nullptr, &n, stream));
+  free_t(c, h);
+  CHK(cconv(c, n, true, "encoder.conv_out", ConvOpt(), out, stream));
+  return 0;
+}
+int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
+  const auto& cf = c->cfg;
+  Tensor h; float* hs = nullptr;
+  Tensor zin = z;
+  CHK(cconv(c, zin, false, "decoder.conv_in", ConvOpt(), &h, stream));
+  char nm[128];
+  int n_tdown = 0;
+  for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
+  for (int j = 0; j < 2; ++j) { snprintf(nm, sizeof nm, "decoder.mid_block.resnets.%d", j); CHK(resnet(c, &h, &hs, nm, &z, stream)); }
+  for (int i = 0; i < cf.vae_num_blocks; ++i) {
+    for (int j = 0; j < cf.vae_layers_per_block + 1; ++j) { snprintf(nm, sizeof nm, "decoder.up_blocks.%d.resnets.%d", i, j); CHK(resnet(c, &h, &hs, nm, &z, stream)); }
+    if (i < cf.vae_num_blocks - 1) {
+      snprintf(nm, sizeof nm, "decoder.up_blocks.%d.upsamplers.0", i);
+      if (hs) { c->arena.release(hs); hs = nullptr; }
+      ConvOpt ou; ou.up = 1; ou.pad_h = 1; ou.pad_w = 1; ou.gn_eps = cf.vae_norm_eps; ou.gn_stats = &hs;
+      if (i < n_tdown && h.T > 1) { ou.tmode = h.T % 2 ? 2 : 1; ou.t_out = h.T % 2 ? 2 * h.T - 1 : 2 * h.T; }
+      Tensor u;
+      CHK(conv(c, h, c->pc.at(nm), ou, &u, stream));
+      free_t(c, h);
+      h = u;
+    }
+  }
+  Tensor n;
+  CHK(norm_silu(c, h, hs, "decoder.norm_out", &z, &n, stream));
+  free_t(c, h);
+  CHK(cconv(c, n, true, "decoder.conv_out", ConvOpt(), out, stream));
+  return 0;
+}
+void clear_caches(dove_ctx* c) {
+  for (auto& kv : c->cache_owner) c->arena.release(kv.second);
+  c->cache.clear();
+  c->cache_owner.clear();
+}
+
+// ---- DiT (dove_amd/transformer.py) ------------------------------------------------------------------------------------------------
+int modulation(dove_ctx* c, int t, const float* temb_in, void* stream) {
+  if (c->mod_t == t && !temb_in) return 0;
+  const auto& cf = c->cfg;
+  const int D = cf.dit_heads * cf.dit_head_dim, te = cf.dit_time_embed_dim;
+  hipStream_t s = (hipStream_t)stream;
+  if (temb_in) {
+    HIPCHK(hipMemcpyAsync(c->temb, temb_in, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    // Timesteps(): [sin | cos] of t * exp(-ln(1e4) i / (half - shift)), flipped to [cos | sin], cast to the model dtype (bf16)
+    std::vector<float> h(D);
+    const int half = D / 2;
+    for (int i = 0; i < half; ++i) {
+      const float ang = (float)t * expf(-logf(10000.0f) * (float)i / ((float)half - cf.dit_freq_shift));
+      const float sn = sinf(ang), cs = cosf(ang);
+      if (cf.dit_flip_sin_to_cos) { h[i] = cs; h[half + i] = sn; } else { h[i] = sn; h[half + i] = cs; }
+    }
+    for (auto& v : h) { uint32_t u; memcpy(&u, &v, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; memcpy(&v, &u, 4); }
+    HIPCHK(hipMemcpyAsync(c->temb, h.data(), (size_t)D * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));                          // h goes out of scope
+  }
+  CHK(dove_gemv_bf16(c->te1_w, c->te1_b, c->temb, D, te, 0, c->e1, stream));
+  CHK(dove_gemv_bf16(c->te2_w, c->te2_b, c->e1, te, te, 1, c->emb, stream));
+  auto regroup = [&](const float* v, float* m, float* g, int i_sh, int i_sc, int i_g, int e_sh, int e_sc, int e_g) -> int {
+    // mod[class][shift|scale][D] (class 0 = text rows), gate[class][D]
+    const int idx[4] = {e_sh, e_sc, i_sh, i_sc};
+    for (int q = 0; q < 4; ++q) HIPCHK(hipMemcpyAsync(m + (size_t)q * D, v + (size_t)idx[q] * D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g, v + (size_t)e_g * D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g + D, v + (size_t)i_g * D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+  };
+  for (auto& b : c->blocks) {
+    CHK(dove_gemv_bf16(b.mod1_w, b.mod1_b, c->emb, te, 6 * D, 1, c->vtmp, stream));
+    CHK(regroup(c->vtmp, b.m1, b.g1, 0, 1, 2, 3, 4, 5));
+    CHK(dove_gemv_bf16(b.mod2_w, b.mod2_b, c->emb, te, 6 * D, 1, c->vtmp, stream));
+    CHK(regroup(c->vtmp, b.m2, b.g2, 0, 1, 2, 3, 4, 5));
+  }
+  CHK(dove_gemv_bf16(c->modout_w, c->modout_b, c->emb, te, 2 * D, 1, c->vtmp, stream));      // (shift, scale)
+  for (int cls = 0; cls < 2; ++cls) HIPCHK(hipMemcpyAsync(c->final_mod + (size_t)cls * 2 * D, c->vtmp, (size_t)2 * D * 4, hipMemcpyDeviceToDevice, s));
+  c->mod_t = temb_in ? -1 : t;
+  return 0;
+}
+// get_3d_rotary_pos_embed(grid_type="slice"): [t | h | w] split 16/24/24 of head_dim 64, theta 1e4, each frequency twice (dove_amd/rope.py)
+int rope_tables(dove_ctx* c, int gt, int gh, int gw, const float** cosp, const float** sinp, void* stream) {
+  const long long nv = (long long)gt * gh * gw;
+  const int hd = c->cfg.dit_head_dim;
+  if (!(c->rope_dev && c->rope_t == gt && c->rope_h == gh && c->rope_w == gw)) {
+    const int dt = hd / 4, dh = hd / 8 * 3, dw = dh;
+    std::vector<float> tab((size_t)2 * nv * hd);
+    auto fill = [&](int dim, int n, std::vector<float>& cs, std::vector<float>& sn) {
+      cs.resize((size_t)n * dim); sn.resize((size_t)n * dim);
+      for (int i = 0; i < dim / 2; ++i) {
+        const float f = 1.0f / powf(10000.0f, (float)(2 * i) / (float)dim);
+        for (int p = 0; p < n; ++p) { const float a = (float)p * f; cs[(size_t)p * dim + 2 * i] = cs[(size_t)p * dim + 2 * i + 1] = cosf(a); sn[(size_t)p * dim + 2 * i] = sn[(size_t)p * dim + 2 * i + 1] = sinf(a); }
+      }
+    };
+    std::vector<float> ct, st, ch, sh, cw, sw;
+    fill(dt, gt, ct, st); fill(dh, gh, ch, sh); fill(dw, gw, cw, sw);
+    for (int a = 0; a < gt; ++a) for (int b = 0; b < gh; ++b) for (int d = 0; d < gw; ++d) {
+      float* co = &tab[(((size_t)a * gh + b) * gw + d) * hd];
+      float* so = co + (size_t)nv * hd;
+      memcpy(co, &ct[(size_t)a * dt], dt * 4); memcpy(co + dt, &ch[(size_t)b * dh], dh * 4); memcpy(co + dt + dh, &cw[(size_t)d * dw], dw * 4);
+      memcpy(so, &st[(size_t)a * dt], dt * 4); memcpy(so + dt, &sh[(size_t)b * dh], dh * 4); memcpy(so + dt + dh, &sw[(size_t)d * dw], dw * 4);
+    }
+    if (c->rope_dev) (void)hipFree(c->rope_dev);
+    HIPCHK(hipMalloc((void**)&c->rope_dev, tab.size() * 4));
+    HIPCHK(hipMemcpy(c->rope_dev, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    c->rope_t = gt; c->rope_h = gh; c->rope_w = gw;
+  }
+  *cosp = c->rope_dev; *sinp = c->rope_dev + nv * hd;
+  return 0;
+}
+
+}  // namespace
+
+// ==================================================================================================================================
+extern "C" int dove_create(int device, const dove_model_config* cfg, dove_ctx** out) {
+  DOVE_CHECK_ARG(cfg && out, "dove_create: null pointer");
+  DOVE_CHECK_ARG(cfg->dit_head_dim == 64, "dove_create: head_dim must be 64");
+  DOVE_CHECK_ARG(cfg->vae_num_blocks >= 1 && cfg->vae_num_blocks <= 8 && cfg->dit_patch_t >= 1 && cfg->dit_patch >= 1, "dove_create: bad config");
+  HIPCHK(hipSetDevice(device));
+  dove_ctx* c = new dove_ctx();
+  c->cfg = *cfg;
+  c->device = device;
+  *out = c;
+  return DOVE_OK;
+}
+extern "C" void dove_destroy(dove_ctx* c) {
+  if (!c) return;
+  clear_caches(c);
+  for (void* p : c->owned) (void)hipFree(p);
+  if (c->rope_dev) (void)hipFree(c->rope_dev);
+  if (c->Qh) { (void)hipFree(c->Qh); (void)hipFree(c->Kh); (void)hipFree(c->Vt); }
+  if (c->arena.owned && c->arena.base) (void)hipFree(c->arena.base);
+  delete c;
+}
+extern "C" int dove_set_weight(dove_ctx* c, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype) {
+  DOVE_CHECK_ARG(c && name && dev_ptr && shape && ndim >= 1 && ndim <= 5, "dove_set_weight: bad argument");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "dove_set_weight: dtype must be DOVE_F32 or DOVE_BF16");
+  DOVE_CHECK_ARG(!c->finalized, "dove_set_weight: weights are already finalized");
+  Raw r; r.p = dev_ptr; r.dt = dtype; r.shape.assign(shape, shape + ndim);
+  c->raw[name] = r;
+  return DOVE_OK;
+}
+extern "C" int dove_finalize_weights(dove_ctx* c) {
+  DOVE_CHECK_ARG(c && !c->finalized, "dove_finalize_weights: bad context");
+  HIPCHK(hipSetDevice(c->device));
+  const auto& cf = c->cfg;
+  // ---- VAE: every conv by its diffusers module path (dove_amd/vae.py _pack) ----
+  std::vector<std::string> names;
+  for (auto& kv : c->raw) names.push_back(kv.first);
+  for (auto& k : names) {
+    if (k.compare(0, 8, "encoder.") && k.compare(0, 8, "decoder.")) continue;
+    if (ends_with(k, ".conv.weight") && k.find(".conv_y.") == std::string::npos && k.find(".conv_b.") == std::string::npos) {
+      const std::string n = k.substr(0, k.size() - strlen(".conv.weight"));
+      Packed p; CHK(pack(c, {k}, {n + ".conv.bias"}, &p)); c->pc[n] = p;
+    } else if (ends_with(k, ".conv_shortcut.weight")) {
+      const std::string n = k.substr(0, k.size() - strlen(".weight"));
+      Packed p; CHK(pack(c, {k}, {n + ".bias"}, &p)); c->pc[n] = p;
+    } else if (ends_with(k, ".conv_y.conv.weight")) {
+      const std::string n = k.substr(0, k.size() - strlen(".conv_y.conv.weight"));
+      Packed p; CHK(pack(c, {k, n + ".conv_b.conv.weight"}, {n + ".conv_y.conv.bias", n + ".conv_b.conv.bias"}, &p)); c->pc[n + ".yb"] = p;
+      float *g, *b; CHK(to_f32(c, n + ".norm_layer.weight", &g)); CHK(to_f32(c, n + ".norm_layer.bias", &b)); c->aff[n] = {g, b};
+    } else if (ends_with(k, ".weight") && c->raw[k].shape.size() == 1 && k.find(".norm_layer.") == std::string::npos) {
+      const std::string n = k.substr(0, k.size() - strlen(".weight"));
+      float *g, *b; CHK(to_f32(c, k, &g)); CHK(to_f32(c, n + ".bias", &b)); c->aff[n] = {g, b};
+    }
+  }
+  DOVE_CHECK_ARG(c->pc.count("encoder.conv_in") && c->pc.count("decoder.conv_out"), "dove_finalize_weights: VAE weights missing");
+  // ---- DiT (dove_amd/transformer.py _pack) ----
+  const int D = cf.dit_heads * cf.dit_head_dim;
+  CHK(pack(c, {"patch_embed.proj.weight"}, {"patch_embed.proj.bias"}, &c->pe_proj));
+  CHK(pack(c, {"patch_embed.text_proj.weight"}, {"patch_embed.text_proj.bias"}, &c->pe_text));
+  CHK(to_bf16(c, "time_embedding.linear_1.weight", &c->te1_w)); CHK(to_f32(c, "time_embedding.linear_1.bias", &c->te1_b));
+  CHK(to_bf16(c, "time_embedding.linear_2.weight", &c->te2_w)); CHK(to_f32(c, "time_embedding.linear_2.bias", &c->te2_b));
+  c->blocks.resize(cf.dit_num_layers);
+  char b[96];
+  for (int i = 0; i < cf.dit_num_layers; ++i) {
+    DitBlock& k = c->blocks[i];
+    snprintf(b, sizeof b, "transformer_blocks.%d.", i);
+    const std::string p(b);
+    CHK(to_bf16(c, p + "norm1.linear.weight", &k.mod1_w)); CHK(to_f32(c, p + "norm1.linear.bias", &k.mod1_b, 6 * D));
+    CHK(to_bf16(c, p + "norm2.linear.weight", &k.mod2_w)); CHK(to_f32(c, p + "norm2.linear.bias", &k.mod2_b, 6 * D));
+    CHK(to_f32(c, p + "norm1.norm.weight", &k.ln1_g, D)); CHK(to_f32(c, p + "norm1.norm.bias", &k.ln1_b, D));
+    CHK(to_f32(c, p + "norm2.norm.weight", &k.ln2_g, D)); CHK(to_f32(c, p + "norm2.norm.bias", &k.ln2_b, D));
+    CHK(to_f32(c, p + "attn1.norm_q.weight", &k.nq_g, 64)); CHK(to_f32(c, p + "attn1.norm_q.bias", &k.nq_b, 64));
+    CHK(to_f32(c, p + "attn1.norm_k.weight", &k.nk_g, 64)); CHK(to_f32(c, p + "attn1.norm_k.bias", &k.nk_b, 64));
+    CHK(pack(c, {p + "attn1.to_q.weight", p + "attn1.to_k.weight", p + "attn1.to_v.weight"}, {p + "attn1.to_q.bias", p + "attn1.to_k.bias", p + "attn1.to_v.bias"}, &k.qkv));
+    CHK(pack(c, {p + "attn1.to_out.0.weight"}, {p + "attn1.to_out.0.bias"}, &k.out));
+    CHK(pack(c, {p + "ff.net.0.proj.weight"}, {p + "ff.net.0.proj.bias"}, &k.ff1));
+    CHK(pack(c, {p + "ff.net.2.weight"}, {p + "ff.net.2.bias"}, &k.ff2));
+    void* m;
+    CHK(dev_alloc(c, (size_t)4 * D * 4, &m)); k.m1 = (float*)m; CHK(dev_alloc(c, (size_t)2 * D * 4, &m)); k.g1 = (float*)m;
+    CHK(dev_alloc(c, (size_t)4 * D * 4, &m)); k.m2 = (float*)m; CHK(dev_alloc(c, (size_t)2 * D * 4, &m)); k.g2 = (float*)m;
+  }
+  CHK(to_f32(c, "norm_final.weight", &c->nf_g, D)); CHK(to_f32(c, "norm_final.bias", &c->nf_b, D));
+  CHK(to_bf16(c, "norm_out.linear.weight", &c->modout_w)); CHK(to_f32(c, "norm_out.linear.bias", &c->modout_b, 2 * D));
+  CHK(to_f32(c, "norm_out.norm.weight", &c->no_g, D)); CHK(to_f32(c, "norm_out.norm.bias", &c->no_b, D));
+  CHK(pack(c, {"proj_out.weight"}, {"proj_out.bias"}, &c->proj_out));
+  void* m;
+  CHK(dev_alloc(c, (size_t)4 * D * 4, &m)); c->final_mod = (float*)m;
+  CHK(dev_alloc(c, (size_t)cf.dit_time_embed_dim * 4, &m)); c->emb = (float*)m;
+  CHK(dev_alloc(c, (size_t)cf.dit_time_embed_dim * 4, &m)); c->e1 = (float*)m;
+  CHK(dev_alloc(c, (size_t)D * 4, &m)); c->temb = (float*)m;
+  CHK(dev_alloc(c, (size_t)6 * D * 4, &m)); c->vtmp = (float*)m;
+  CHK(dev_alloc(c, (size_t)2048 * 64 * 4, &m)); c->gn_ws = (float*)m;
+  HIPCHK(hipDeviceSynchronize());                             // the borrowed source tensors may be released by the caller now
+  c->raw.clear();
+  c->finalized = true;
+  return DOVE_OK;
+}
+
+// Upper bound of the arena a whole dove_sr_clip needs for a [3, F, H, W] clip: the live set of the widest VAE stage
+// (decoder up-block with C0 channels at full resolution: block input + normalised copy + conv output + shortcut, one frame-batch)
+// plus the DiT's token buffers.
+extern "C" size_t dove_workspace_bytes(dove_ctx* c, int F, int H, int W) {
+  if (!c) return 0;
+  const auto& cf = c->cfg;
+  const int T = 1 + (F - 1) / cf.vae_temporal_compression;
+  const long long fb = cf.vae_enc_batch + 1;                                      // frames of the largest frame-batch
+  const long long top = fb * H * W * (long long)cf.vae_block_out_channels[0] * 2;      // one full-resolution C0 tensor, bf16
+  // live set of the last up block (2*C0-channel input + its normalised copy + conv output) ~ 5 x top, every causal conv's 2-frame
+  // cache ~ 3 x top over the decoder, staging of one decoded frame-batch; x 1.5 for first-fit fragmentation
+  // plus, memory permitting, every causal conv's input of the previous frame-batch retained instead of copied (~ 20 x top)
+  long long vae = 22 * top;                                                       // measured high water at 33x720x1280: 17.4 x top
+  const int D = cf.dit_heads * cf.dit_head_dim;
+  const long long Td = T + (T % cf.dit_patch_t);
+  const long long N = cf.dit_max_text + (Td / cf.dit_patch_t) * (H / 8 / cf.dit_patch) * (W / 8 / cf.dit_patch);
+  long long dit = N * (long long)D * 2 * (1 + 1 + 3 + 4 + 1) + (1ll << 24);       // hs, n1, qkv, f1, slack
+  long long io = 4ll * F * H * W * 2 * 2 + (long long)T * (H / 8) * (W / 8) * 64 * 4 * 4;
+  return (size_t)((vae > dit ? vae : dit) + io + (64ll << 20));
+}
+extern "C" int dove_set_workspace(dove_ctx* c, void* dev_ptr, size_t bytes) {
+  DOVE_CHECK_ARG(c, "dove_set_workspace: null context");
+  if (c->arena.owned && c->arena.base) (void)hipFree(c->arena.base);
+  c->arena = Arena();
+  if (dev_ptr) { c->arena.base = (char*)dev_ptr; c->arena.cap = bytes; c->arena.owned = false; }
+  else { void* p; HIPCHK(hipMalloc(&p, bytes)); c->arena.base = (char*)p; c->arena.cap = bytes; c->arena.owned = true; }
+  c->arena.reset();
+  return DOVE_OK;
+}
+extern "C" size_t dove_workspace_high_water(dove_ctx* c) { return c ? c->arena.high : 0; }
+
+static int ensure_ws(dove_ctx* c, int F, int H, int W) {
+  DOVE_CHECK_ARG(c && c->finalized, "context is not finalized (dove_finalize_weights)");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t want = dove_workspace_bytes(c, F, H, W);
+  // no workspace yet, or a library-owned one that is too small and idle: (re)allocate.  A caller-provided workspace is used as is
+  // (allocation failures inside the stage then say how much was missing)
+  if (!c->arena.base || (c->arena.owned && c->arena.cap < want && c->arena.live.empty())) CHK(dove_set_workspace(c, nullptr, want));
+  return 0;
+}
+
+// moments [2L][T][h][w] (dtype) of x [3][F][H][W] (dtype), frame-batched like diffusers' _encode; conv caches are per call
+static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, int W, Tensor* moments, void* stream) {
+  const auto& cf = c->cfg;
+  Tensor xcl;
+  CHK(alloc_t(c, F, H, W, c->pc.at("encoder.conv_in").cin_pad, &xcl));
+  CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(F, cf.vae_enc_batch, &fb);
+  clear_caches(c);
+  const int T = 1 + (F - 1) / cf.vae_temporal_compression, h = H / 8, w = W / 8;
+  const int ld = c->pc.at("encoder.conv_out").cout_store();
+  CHK(alloc_t(c, T, h, w, ld, moments));
+  int t0 = 0;
+  for (auto& se : fb) {
+    Tensor xb = xcl; xb.p = xcl.p + (long long)se.first * H * W * xcl.C; xb.T = se.second - se.first;
+    Tensor o;
+    CHK(encoder(c, xb, &o, stream));
+    HIPCHK(hipMemcpyAsync(moments->p + (long long)t0 * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    t0 += o.T;
+    free_t(c, o);
+  }
+  free_t(c, xcl);
+  clear_caches(c);
+  return 0;
+}
+extern "C" int dove_vae_encode(dove_ctx* c, const void* x, int dtype, int F, int H, int W, void* moments_out, int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(x && moments_out, "dove_vae_encode: null pointer");
+  DOVE_CHECK_ARG(F >= 1 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8, "dove_vae_encode: H and W must be multiples of 8");
+  CHK(ensure_ws(c, F, H, W));
+  Tensor m;
+  CHK(vae_encode_cl(c, x, dtype, F, H, W, &m, stream));
+  CHK(dove_ncthw_from_cl(m.p, m.C, 2 * c->cfg.vae_latent_channels, (long long)m.T * m.H * m.W, 1.0f, 0.0f, -INFINITY, INFINITY, moments_out, out_dtype, stream));
+  free_t(c, m);
+  return DOVE_OK;
+}
+// frames the decoder returns for T latent frames: per latent frame-batch (diffusers' _decode batching) every temporal x2 stage maps
+// t frames to 2t - 1 (t odd, > 1: the first frame is not doubled), 2t (t even) or 1 (t == 1); 1 + 4(T - 1) for the odd T the
+// reference always has (clips are padded to 8N + 1 frames, ref :220-232)
+extern "C" int dove_vae_decode_num_frames(dove_ctx* c, int T) {
+  if (!c || T < 1) return 0;
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(T, c->cfg.vae_dec_batch, &fb);
+  int n_tdown = 0;
+  for (int r = c->cfg.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
+  int F = 0;
+  for (auto& se : fb) {
+    int t = se.second - se.first;
+    for (int i = 0; i < n_tdown && i < c->cfg.vae_num_blocks - 1; ++i) t = t > 1 ? (t % 2 ? 2 * t - 1 : 2 * t) : 1;
+    F += t;
+  }
+  return F;
+}
+// z [L][T][h][w] (dtype; multiplied by `prescale` on the way in) -> video [3][F][8h][8w], F = dove_vae_decode_num_frames(T);
+// range01: clamp(x*0.5+0.5, 0, 1)
+extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int h, int w, float prescale, int range01, void* video_out,
+                               int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(z && video_out && T >= 1 && h >= 1 && w >= 1, "dove_vae_decode: bad argument");
+  const auto& cf = c->cfg;
+  const int F = dove_vae_decode_num_frames(c, T), H = 8 * h, W = 8 * w;
+  CHK(ensure_ws(c, F, H, W));
+  Tensor zcl;
+  CHK(alloc_t(c, T, h, w, c->pc.at("decoder.conv_in").cin_pad, &zcl));
+  CHK(dove_cl_from_ncthw(z, dtype, cf.vae_latent_channels, (long long)T * h * w, zcl.C, prescale, 0.0f, zcl.p, stream));
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(T, cf.vae_dec_batch, &fb);
+  clear_caches(c);
+  const size_t esz = out_dtype == DOVE_F32 ? 4 : 2;
+  int f0 = 0;
+  for (auto& se : fb) {
+    Tensor zb = zcl; zb.p = zcl.p + (long long)se.first * h * w * zcl.C; zb.T = se.second - se.first;
+    Tensor o;
+    CHK(decoder(c, zb, &o, stream));
+    // [C][F][H][W] output: this batch's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
+    void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
+    DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
+    CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
+                           range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+    CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
+               cf.vae_out_channels, (hipStream_t)stream));
+    c->arena.release(tmp);
+    f0 += o.T;
+    free_t(c, o);
+  }
+  free_t(c, zcl);
+  clear_caches(c);
+  return DOVE_OK;
+}
+
+// CogVideoXTransformer3DModel.forward for one sample: hidden [T][C][h][w] (dtype), text [L][text_dim] bf16, timestep t ->
+// v_out [T][C][h][w] (dtype).  aux (optional, for bit-exact comparisons with a host that computes them itself): rope cos / sin
+// [Nv][64] fp32 and the bf16-rounded sinusoidal timestep projection [D] fp32, all device pointers.
+extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int T, int h, int w, const void* text, int L, int timestep,
+                                const dove_dit_aux* aux, void* v_out, int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(hidden && text && v_out, "dove_dit_forward: null pointer");
+  const auto& cf = c->cfg;
+  const int p = cf.dit_patch, pt = cf.dit_patch_t, Cc = cf.dit_in_channels, D = cf.dit_heads * cf.dit_head_dim, Hh = cf.dit_heads;
+  DOVE_CHECK_ARG(T % pt == 0 && h % p == 0 && w % p == 0 && L >= 1, "dove_dit_forward: T / h / w must be multiples of the patch sizes");
+  CHK(ensure_ws(c, 1 + 4 * (T - 1), 8 * h, 8 * w));
+  const long long nv = (long long)(T / pt) * (h / p) * (w / p), N = L + nv, npad = ru(N, 128);
+  const float *cosp, *sinp;
+  if (aux && aux->rope_cos && aux->rope_sin) { cosp = aux->rope_cos; sinp = aux->rope_sin; }
+  else CHK(rope_tables(c, T / pt, h / p, w / p, &cosp, &sinp, stream));
+  CHK(modulation(c, timestep, aux ? aux->timestep_proj : nullptr, stream));
+  if (c->attn_n != N) {
+    if (c->Qh) { (void)hipFree(c->Qh); (void)hipFree(c->Kh); (void)hipFree(c->Vt); }
+    const size_t b = (size_t)Hh * npad * 64 * 2;
+    HIPCHK(hipMalloc((void**)&c->Qh, b)); HIPCHK(hipMalloc((void**)&c->Kh, b)); HIPCHK(hipMalloc((void**)&c->Vt, b));
+    HIPCHK(hipMemsetAsync(c->Qh, 0, b, (hipStream_t)stream)); HIPCHK(hipMemsetAsync(c->Kh, 0, b, (hipStream_t)stream)); HIPCHK(hipMemsetAsync(c->Vt, 0, b, (hipStream_t)stream));
+    c->attn_n = N;
+  }
+  auto A = [&](size_t bytes) -> bf16_t* { return (bf16_t*)c->arena.alloc(bytes); };
+  bf16_t* hs = A((size_t)N * D * 2);
+  bf16_t* n1 = A((size_t)N * D * 2);
+  const int feat_pad = c->pe_proj.cin_pad;
+  bf16_t* tok = A((size_t)nv * feat_pad * 2);
+  DOVE_CHECK_ARG(hs && n1 && tok, "workspace exhausted (DiT token buffers)");
+  if (feat_pad > Cc * pt * p * p) HIPCHK(hipMemsetAsync(tok, 0, (size_t)nv * feat_pad * 2, (hipStream_t)stream));
+  CHK(dove_patchify(hidden, dtype, T, Cc, h, w, pt, p, tok, feat_pad, stream));
+  ConvOpt o; bf16_t* dummy;
+  o = ConvOpt(); o.out = hs; CHK(linear(c, (const bf16_t*)text, L, c->pe_text, o, &dummy, stream));
+  o = ConvOpt(); o.out = hs + (size_t)L * D; CHK(linear(c, tok, nv, c->pe_proj, o, &dummy, stream));
+  c->arena.release(tok);
+  const float qscale = (1.0f / sqrtf((float)cf.dit_head_dim)) * 1.4426950408889634f;
+  for (auto& b : c->blocks) {
+    CHK(dove_layernorm_modulate_bf16(hs, n1, N, D, cf.dit_norm_eps, b.ln1_g, b.ln1_b, b.m1, L, stream));
+    bf16_t* qkv;
+    CHK(linear(c, n1, N, b.qkv, ConvOpt(), &qkv, stream));
+    CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, stream));
+    c->arena.release(qkv);
+    CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, stream));      // attention output reuses n1
+    o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g1; o.gate_split = L; o.out = hs;
+    CHK(linear(c, n1, N, b.out, o, &dummy, stream));
+    CHK(dove_layernorm_modulate_bf16(hs, n1, N, D, cf.dit_norm_eps, b.ln2_g, b.ln2_b, b.m2, L, stream));
+    bf16_t* f1;
+    o = ConvOpt(); o.act = 1;
+    CHK(linear(c, n1, N, b.ff1, o, &f1, stream));
+    o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g2; o.gate_split = L; o.out = hs;
+    CHK(linear(c, f1, N, b.ff2, o, &dummy, stream));
+    c->arena.release(f1);
+  }
+  bf16_t* xv = hs + (size_t)L * D;
+  bf16_t* a1 = A((size_t)nv * D * 2);
+  DOVE_CHECK_ARG(a1, "workspace exhausted (DiT head)");
+  CHK(dove_layernorm_modulate_bf16(xv, a1, nv, D, cf.dit_norm_eps, c->nf_g, c->nf_b, nullptr, 0, stream));
+  CHK(dove_layernorm_modulate_bf16(a1, n1, nv, D, cf.dit_norm_eps, c->no_g, c->no_b, c->final_mod, 0, stream));
+  bf16_t* po;
+  CHK(linear(c, n1, nv, c->proj_out, ConvOpt(), &po, stream));
+  CHK(dove_unpatchify(po, c->proj_out.cout_store(), T, cf.dit_out_channels, h, w, pt, p, v_out, out_dtype, stream));
+  c->arena.release(po); c->arena.release(a1); c->arena.release(n1); c->arena.release(hs);
+  return DOVE_OK;
+}
+
+// process_video (ref :394-503) on device buffers: video_in [3][F][H][W] in [-1,1] (dtype), posterior noise [L][T][h][w] (noise_dtype),
+// text [Ltxt][text_dim] bf16, timestep t with sqrt(alpha_t), sqrt(1 - alpha_t) of the scheduler -> video_out [3][F][H][W] in [0,1].
+extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F, int H, int W, const void* noise, int noise_dtype,
+                            const void* text, int Ltxt, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux,
+                            void* video_out, int out_dtype, void* stream) {
+  DOVE_CHECK_ARG(video_in && noise && text && video_out, "dove_sr_clip: null pointer");
+  DOVE_CHECK_ARG(F >= 1 && H % 16 == 0 && W % 16 == 0, "dove_sr_clip: H and W must be multiples of 16 (8x VAE, 2x patch)");
+  CHK(ensure_ws(c, F, H, W));
+  const auto& cf = c->cfg;
+  const int Lc = cf.vae_latent_channels, h = H / 8, w = W / 8;
+  hipStream_t s = (hipStream_t)stream;
+  Tensor m;
+  CHK(vae_encode_cl(c, video_in, dtype, F, H, W, &m, stream));
+  const int T = m.T;
+  const long long fsz = (long long)h * w;                       // elements of one latent frame of one channel
+  // sample = mean + std * noise (bf16, [L][T][h][w]), then * scaling_factor and the first-frame pad, as [T'][L][h][w] for the DiT
+  bf16_t* samp = (bf16_t*)c->arena.alloc((size_t)Lc * T * fsz * 2);
+  DOVE_CHECK_ARG(samp, "workspace exhausted");
+  CHK(dove_posterior_sample(m.p, m.C, Lc, (long long)T * fsz, noise, noise_dtype, samp, DOVE_BF16, stream));
+  free_t(c, m);
+  const int ncopy = T % cf.dit_patch_t, Td = T + ncopy;
+  bf16_t* lat = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);     // [Td][L][h][w]
+  bf16_t* scaled = (bf16_t*)c->arena.alloc((size_t)Lc * T * fsz * 2);
+  DOVE_CHECK_ARG(lat && scaled, "workspace exhausted");
+  CHK(dove_axpby(samp, samp, scaled, DOVE_BF16, (long long)Lc * T * fsz, cf.vae_scaling_factor, 0.0f, stream));   // sample * scaling_factor
+  for (int t = 0; t < Td; ++t) {                                // permute(0,2,1,3,4) + prepend frame 0 `ncopy` times
+    const int ts = t < ncopy ? 0 : t - ncopy;
+    CHK(copy2d(lat + (long long)t * Lc * fsz, (size_t)fsz * 2, scaled + (long long)ts * fsz, (size_t)T * fsz * 2, (size_t)fsz * 2, Lc, s));
+  }
+  c->arena.release(samp); c->arena.release(scaled);
+  bf16_t* vel = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);
+  DOVE_CHECK_ARG(vel, "workspace exhausted");
+  CHK(dove_dit_forward(c, lat, DOVE_BF16, Td, h, w, text, Ltxt, timestep, aux, vel, DOVE_BF16, stream));
+  // get_velocity: x0 = sqrt(a) * latent - sqrt(1-a) * v
+  bf16_t* x0 = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);
+  DOVE_CHECK_ARG(x0, "workspace exhausted");
+  CHK(dove_axpby(lat, vel, x0, DOVE_BF16, (long long)Td * Lc * fsz, sqrt_alpha, -sqrt_one_minus_alpha, stream));
+  c->arena.release(lat); c->arena.release(vel);
+  // drop the padded frames, back to [L][T][h][w] for the decoder
+  bf16_t* z = (bf16_t*)c->arena.alloc((size_t)Lc * T * fsz * 2);
+  DOVE_CHECK_ARG(z, "workspace exhausted");
+  for (int t = 0; t < T; ++t)
+    CHK(copy2d(z + (long long)t * fsz, (size_t)T * fsz * 2, x0 + (long long)(t + ncopy) * Lc * fsz, (size_t)fsz * 2, (size_t)fsz * 2, Lc, s));
+  c->arena.release(x0);
+  CHK(dove_vae_decode(c, z, DOVE_BF16, T, h, w, 1.0f / cf.vae_scaling_factor, 1, video_out, out_dtype, stream));
+  c->arena.release(z);
+  return DOVE_OK;
+}

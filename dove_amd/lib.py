@@ -27,6 +27,21 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ModelConfig(C.Structure):
+    """dove_model_config (include/dove_hip.h): the fields of vae/config.json and transformer/config.json the graph needs."""
+    _fields_ = [(n, C.c_int) for n in ("vae_in_channels", "vae_out_channels", "vae_latent_channels", "vae_num_blocks")] + \
+               [("vae_block_out_channels", C.c_int * 8)] + \
+               [(n, C.c_int) for n in ("vae_layers_per_block", "vae_temporal_compression", "vae_enc_batch", "vae_dec_batch")] + \
+               [("vae_norm_eps", C.c_float), ("vae_scaling_factor", C.c_float)] + \
+               [(n, C.c_int) for n in ("dit_heads", "dit_head_dim", "dit_num_layers", "dit_in_channels", "dit_out_channels", "dit_patch",
+                                       "dit_patch_t", "dit_text_dim", "dit_time_embed_dim", "dit_max_text", "dit_flip_sin_to_cos")] + \
+               [("dit_norm_eps", C.c_float), ("dit_freq_shift", C.c_float)]
+
+
+class DitAux(C.Structure):
+    _fields_ = [("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("timestep_proj", C.c_void_p)]
+
+
 _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
 # name -> argtypes; the symbol list doubles as the export check in tests/test_abi.py
@@ -56,11 +71,23 @@ SIGNATURES = {
     "dove_gated_gelu_bf16": [_VP, _VP, _LL, _I, _VP],
     "dove_attention_bias_bf16": [_VP, _VP, _VP, _LL, _VP, _VP, _LL, _I, _I, _I, _VP],
     "dove_mx_quant_bf16": [_VP, _LL, _I, _VP, _VP, _VP],
+    "dove_create": [_I, C.POINTER(ModelConfig), C.POINTER(_VP)],
+    "dove_set_weight": [_VP, C.c_char_p, _VP, C.POINTER(C.c_longlong), _I, _I],
+    "dove_finalize_weights": [_VP],
+    "dove_set_workspace": [_VP, _VP, C.c_size_t],
+    "dove_vae_encode": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP],
+    "dove_dit_forward": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _I, C.POINTER(DitAux), _VP, _I, _VP],
+    "dove_vae_decode": [_VP, _VP, _I, _I, _I, _I, _F, _I, _VP, _I, _VP],
+    "dove_sr_clip": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _I, _I, _F, _F, C.POINTER(DitAux), _VP, _I, _VP],
     "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_conv_gn_partial_rows": (C.c_longlong, [C.POINTER(ConvDesc)]),
-         "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)])}
+         "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+         "dove_destroy": (None, [_VP]),
+         "dove_vae_decode_num_frames": (C.c_int, [_VP, _I]),
+         "dove_workspace_bytes": (C.c_size_t, [_VP, _I, _I, _I]),
+         "dove_workspace_high_water": (C.c_size_t, [_VP])}
 
 
 def use_timing_build():

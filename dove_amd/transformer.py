@@ -114,11 +114,9 @@ class CogVideoXTransformer3DModel:
         w.copy_((w.float() + scale * delta.to(w.device, torch.float32)).to(torch.bfloat16))
 
     # ---- timestep-dependent constants ----------------------------------------------------------------
-    def _modulation(self, t: int):
-        """emb = time_embedding(sinusoid(t)); per block the six AdaLN-Zero chunks (shift, scale, gate, enc_shift,
-        enc_scale, enc_gate) regrouped as mod[class][shift|scale][D] and gate[class][D], class 0 = text rows."""
-        if t in self._mod_cache:
-            return self._mod_cache[t]
+    def timestep_projection(self, t: int) -> torch.Tensor:
+        """diffusers' Timesteps(t): [cos | sin] (flip_sin_to_cos) of t * exp(-ln(1e4) i / (half - freq_shift)), cast to the model
+        dtype like the reference does before time_embedding.linear_1; fp32 [D] on the device."""
         D, c = self.D, self.config
         half = D // 2
         expo = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - c.get("freq_shift", 0))
@@ -126,8 +124,15 @@ class CogVideoXTransformer3DModel:
         temb = torch.cat([torch.sin(ang), torch.cos(ang)])
         if c.get("flip_sin_to_cos", True):
             temb = torch.cat([temb[half:], temb[:half]])
-        # the reference casts the sinusoid to the model dtype before linear_1
-        temb = temb.to(self.dtype).to(torch.float32).to(self.device)
+        return temb.to(self.dtype).to(torch.float32).to(self.device)
+
+    def _modulation(self, t: int):
+        """emb = time_embedding(sinusoid(t)); per block the six AdaLN-Zero chunks (shift, scale, gate, enc_shift,
+        enc_scale, enc_gate) regrouped as mod[class][shift|scale][D] and gate[class][D], class 0 = text rows."""
+        if t in self._mod_cache:
+            return self._mod_cache[t]
+        D = self.D
+        temb = self.timestep_projection(t)
         e1 = ops.gemv(self.te[0][0], self.te[0][1], temb, act_in=0)
         emb = ops.gemv(self.te[1][0], self.te[1][1], e1, act_in=1)
         out = []

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 3
+#define DOVE_ABI_VERSION 4
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -168,6 +168,52 @@ int dove_gated_gelu_bf16(const void* x, void* y, long long M, int F, void* strea
  * fp32 = relative_attention_bias gathered by bucket; N <= 1024 */
 int dove_attention_bias_bf16(const void* q, const void* k, const void* v, long long ld, const float* bias, void* out, long long ldo,
                              int N, int heads, int head_dim, void* stream);
+
+/* ---- graph-level entry points: a context owns packed weights + one workspace arena and runs whole stages ----
+ * One context per (process, device); NOT thread-safe; calls are asynchronous on the given stream except where a host-side
+ * table has to be uploaded (first call with a new shape / timestep).  Weight tensors passed to dove_set_weight are BORROWED until
+ * dove_finalize_weights returns (it repacks them into library-owned memory: implicit-GEMM layout for every conv / linear,
+ * fused QKV, SpatialNorm conv_y || conv_b, fp32 norm parameters).  Names are diffusers' state-dict names of
+ * AutoencoderKLCogVideoX (`encoder.*`, `decoder.*`) and CogVideoXTransformer3DModel (everything else); SURVEY.md App. E. */
+typedef struct dove_ctx dove_ctx;
+typedef struct dove_model_config {
+  /* vae/config.json */
+  int vae_in_channels, vae_out_channels, vae_latent_channels, vae_num_blocks, vae_block_out_channels[8], vae_layers_per_block,
+      vae_temporal_compression, vae_enc_batch /* num_sample_frames_batch_size */, vae_dec_batch /* num_latent_frames_batch_size */;
+  float vae_norm_eps, vae_scaling_factor;
+  /* transformer/config.json */
+  int dit_heads, dit_head_dim, dit_num_layers, dit_in_channels, dit_out_channels, dit_patch, dit_patch_t, dit_text_dim,
+      dit_time_embed_dim, dit_max_text, dit_flip_sin_to_cos;
+  float dit_norm_eps, dit_freq_shift;
+} dove_model_config;
+/* optional precomputed inputs of the DiT (all device pointers, may be NULL): RoPE tables [Nv][64] fp32 as
+ * `prepare_rotary_positional_embeddings` returns them (ref :364-392) and the bf16-rounded sinusoidal timestep projection [D] fp32;
+ * NULL = computed inside (host libm + upload, cached per shape / timestep) */
+typedef struct dove_dit_aux { const float* rope_cos; const float* rope_sin; const float* timestep_proj; } dove_dit_aux;
+int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
+void dove_destroy(dove_ctx* ctx);
+int dove_set_weight(dove_ctx* ctx, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype);
+int dove_finalize_weights(dove_ctx* ctx);
+/* arena bytes a [3,F,H,W] clip needs (upper bound); dove_set_workspace(ctx, NULL, n) lets the library allocate, a non-NULL pointer
+ * lends caller memory; with neither the first stage call allocates dove_workspace_bytes itself */
+size_t dove_workspace_bytes(dove_ctx* ctx, int F, int H, int W);
+int dove_set_workspace(dove_ctx* ctx, void* dev_ptr, size_t bytes);
+size_t dove_workspace_high_water(dove_ctx* ctx);
+/* pipe.vae.encode(x).latent_dist.parameters (ref :408): x [3][F][H][W] -> moments [2L][T][H/8][W/8] */
+int dove_vae_encode(dove_ctx* ctx, const void* x, int dtype, int F, int H, int W, void* moments_out, int out_dtype, void* stream);
+/* pipe.transformer(...)[0] for one sample (ref :483-489): hidden [T][C][h][w], text [L][text_dim] bf16 -> v [T][C][h][w] */
+int dove_dit_forward(dove_ctx* ctx, const void* hidden, int dtype, int T, int h, int w, const void* text, int L, int timestep,
+                     const dove_dit_aux* aux, void* v_out, int out_dtype, void* stream);
+/* pipe.vae.decode(z * prescale).sample (ref :500-501; range01 != 0 fuses (x*0.5+0.5).clamp(0,1)): z [L][T][h][w] -> [3][F][8h][8w],
+ * F = dove_vae_decode_num_frames(T) = 1 + 4(T-1) for the odd T of 8N+1-frame clips */
+int dove_vae_decode_num_frames(dove_ctx* ctx, int T);
+int dove_vae_decode(dove_ctx* ctx, const void* z, int dtype, int T, int h, int w, float prescale, int range01, void* video_out,
+                    int out_dtype, void* stream);
+/* process_video (ref :394-503) with the posterior noise injected and the scheduler's sqrt(alpha_t), sqrt(1 - alpha_t) (alpha cast
+ * to bf16 first, like diffusers): video_in [3][F][H][W] in [-1,1] -> video_out [3][F][H][W] in [0,1] */
+int dove_sr_clip(dove_ctx* ctx, const void* video_in, int dtype, int F, int H, int W, const void* noise, int noise_dtype, const void* text,
+                 int text_len, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux, void* video_out,
+                 int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

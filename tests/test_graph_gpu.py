@@ -1,0 +1,118 @@
+"""-m gpu: the graph-level C entry points (dove_create ... dove_sr_clip) against the Python facade.  Both drive the
+same operator kernels in the same order, so with the host-computed tables handed over (RoPE, timestep projection) every stage
+must agree BIT FOR BIT; with the tables computed inside the library (host libm) the result may differ in the last bf16 bit."""
+import time
+
+import pytest
+import torch
+
+from dove_amd import config, weights
+from dove_amd.graph import GraphContext
+from dove_amd.inference import process_video
+from dove_amd.pipeline import CogVideoXPipeline
+from dove_amd.rope import prepare_rotary_positional_embeddings
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def both():
+    v, t, s = config.small_configs(num_layers=2)
+    seed = 31
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), seed)
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=seed, device="cuda")
+    ctx = GraphContext(v, t, wv, wt, "cuda")
+    return pipe, ctx, (v, t, s)
+
+
+def rope_for(pipe, T, h, w):
+    return prepare_rotary_positional_embeddings(height=h * 8, width=w * 8, num_frames=T, transformer_config=pipe.transformer.config,
+                                                vae_scale_factor_spatial=8, device="cuda")
+
+
+@pytest.mark.parametrize("F,H,W", [(9, 64, 64), (17, 48, 80), (25, 32, 48)])
+def test_stages_bit_exact(both, F, H, W):
+    pipe, ctx, _ = both
+    g = torch.Generator().manual_seed(F)
+    video = (torch.rand(1, 3, F, H, W, generator=g) * 2 - 1).to(BF).cuda()
+    m_py = pipe.vae.encode(video).latent_dist.parameters[0]
+    m_c = ctx.vae_encode(video[0].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(m_c, m_py), f"encode differs: {float((m_c.float() - m_py.float()).abs().max())}"
+    T = m_py.shape[1]
+    Td = T + T % 2
+    hidden = torch.randn(Td, 16, H // 8, W // 8, generator=g).to(BF).cuda()
+    text = (torch.randn(226, 4096, generator=g) * 0.15).to(BF).cuda()
+    rope = rope_for(pipe, Td, H // 8, W // 8)
+    ts = torch.tensor([399], device="cuda")
+    v_py = pipe.transformer(hidden_states=hidden[None], encoder_hidden_states=text[None], timestep=ts, image_rotary_emb=rope, return_dict=False)[0][0]
+    v_c = ctx.dit_forward(hidden, text, 399, rope=rope, timestep_proj=pipe.transformer.timestep_projection(399))
+    torch.cuda.synchronize()
+    assert torch.equal(v_c, v_py), f"DiT differs: {float((v_c.float() - v_py.float()).abs().max())}"
+    v_own = ctx.dit_forward(hidden, text, 399)                  # tables from the library's own host math
+    rel = float((v_own.float() - v_py.float()).abs().max() / v_py.float().abs().max())
+    assert rel < 2e-2, rel
+    z = torch.randn(16, T, H // 8, W // 8, generator=g).to(BF).cuda()
+    d_py = pipe.vae.decode(z[None], _range01=True, _prescale=1 / 0.7).sample[0]
+    d_c = ctx.vae_decode(z, prescale=1 / 0.7, range01=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d_c, d_py), f"decode differs: {float((d_c.float() - d_py.float()).abs().max())}"
+    z2 = z[:, :2].contiguous()                                  # an even number of latent frames decodes to 8 frames, not 5
+    assert torch.equal(ctx.vae_decode(z2), pipe.vae.decode(z2[None]).sample[0])
+
+
+def test_sr_clip_equals_process_video(both):
+    pipe, ctx, _ = both
+    g = torch.Generator().manual_seed(77)
+    F, H, W = 9, 64, 96
+    video = (torch.rand(1, 3, F, H, W, generator=g) * 2 - 1).to(BF).cuda()
+    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=g).cuda()
+    text = (torch.randn(226, 4096, generator=g) * 0.15).to(BF).cuda()
+    want = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)[0]
+    sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+    rope = rope_for(pipe, 4, H // 8, W // 8)
+    got = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, rope=rope,
+                      timestep_proj=pipe.transformer.timestep_projection(399))
+    torch.cuda.synchronize()
+    assert got.shape == want.shape == (3, F, H, W)
+    assert torch.equal(got, want), f"sr_clip differs from process_video: {float((got.float() - want.float()).abs().max())}"
+    # the whole clip again with nothing precomputed by the host
+    own = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1)
+    d = (own.float() - want.float()).abs()                     # libm vs torch in the sinusoid / RoPE tables: a last-bit change of a few
+    assert float(d.max()) < 0.1 and float(d.mean()) < 5e-3, (float(d.max()), float(d.mean()))   # table entries, amplified by random weights
+
+
+def test_sr_clip_full_size_timing():
+    """Headline clip through ONE C call: same kernels, no Python between them, activations from the library's arena."""
+    v, t, s = config.default_configs()
+    seed = 1234
+    wv = weights.LazyStateDict(weights.vae_param_shapes(v), seed, "cuda")
+    wt = weights.LazyStateDict(weights.dit_param_shapes(t), seed, "cuda")     # fp32, like the facade reads them (22 GB until finalize)
+    ctx = GraphContext(v, t, wv, wt, "cuda")
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=seed, device="cuda", init_device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    F, H, W = 33, 720, 1280
+    video = (torch.rand(1, 3, F, H, W, device="cuda", generator=g) * 2 - 1).to(BF)
+    noise = torch.randn(1, 16, 9, H // 8, W // 8, device="cuda", generator=g)
+    text = (torch.randn(226, 4096, device="cuda", generator=g) * 0.15).to(BF)
+    sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+    rope = rope_for(pipe, 10, H // 8, W // 8)
+    tp = pipe.transformer.timestep_projection(399)
+    times = {}
+    for name, fn in (("python facade", lambda: process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)[0]),
+                     ("dove_sr_clip", lambda: ctx.sr_clip(video[0], noise[0], text, 399, sa, s1, rope=rope, timestep_proj=tp))):
+        out = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            out = fn()
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 2
+        assert bool(torch.isfinite(out.float()).all())
+    print(f"[graph] 33x720x1280: python facade {times['python facade'] * 1e3:.1f} ms, dove_sr_clip {times['dove_sr_clip'] * 1e3:.1f} ms; "
+          f"arena high water {ctx.workspace_high_water() / 2**30:.1f} GiB of {ctx.workspace_bytes(F, H, W) / 2**30:.1f} GiB requested")
+    a = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)[0]
+    b = ctx.sr_clip(video[0], noise[0], text, 399, sa, s1, rope=rope, timestep_proj=tp)
+    assert torch.equal(a, b), "full-size clip: the C graph and the Python facade disagree"
