@@ -485,230 +485,14 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// 3x3 (x kt) stride-1 convolution with an LDS HALO tile -- the kernel that carries the VAE resnets
-// (71 % of the clip's FLOPs).  Ablation of the fast path on MI355X: global->LDS staging + ds_reads alone
-// (no MFMA) already cost 76 % of the launch; the per-CU vector-memory path (~64 B/clk) is the limiter at
-// 64 FLOP per staged byte.  Here one workgroup owns 8 x 32 output pixels x 128 output channels and walks K as
-//   for dt (temporal tap) / for kc (32-channel chunk):   stage the (8+2) x (32+2) input halo ONCE
+// 3x3 (x kt) stride-1 convolutions with an LDS HALO tile.  History of the design (profiles/r01_*): ablation of the
+// igemm_fast path showed global->LDS staging + ds_reads alone (no MFMA) costing 76 % of the launch - the per-CU
+// vector-memory path (~64 B/clk) is the limiter at 64 FLOP per staged byte.  A halo kernel walks K as
+//   for dt (temporal tap) / for kc (32-channel chunk):   stage the (TH+2) x (TW+2) input halo ONCE
 //     for the 9 spatial taps:                              stage only the 128 x 32 weight tile
-// so the activations are fetched once per 9 taps (204 FLOP per staged byte, 3.2x better) and each wave's
-// 128 x 64 register tile needs 6 fragment reads per 8 MFMAs (was 8 per 8).
-// A fragments for tap (dh, dw) are the same halo rows shifted by dh*34 + dw: one tile row = 32 consecutive
-// halo rows, which keeps the XOR-swizzled ds_read_b128 conflict-free for ANY shift (16-lane groups always
-// see 16 distinct row indices mod 16).  Halo staging addresses are per-thread constants (image-border and
-// tail lanes use the descriptor's out-of-range -> 0 rule); the halo of the next (dt, kc) group trickles in
-// one 4 KB round per K-step behind the weight tiles.
-// ------------------------------------------------------------------------------------------------
-namespace halo {
-constexpr int TH = 8, TW = 32, HWID = TW + 2, HHGT = TH + 2, HPIX = HWID * HHGT;  // 340 halo pixels
-constexpr int BK = 32, ROWB = BK * 2;                                                 // 64-byte LDS rows
-constexpr int A_ROUNDS = (HPIX * 4 + 255) / 256;                                      // 6 rounds of 256 x 16 B
-constexpr int A_BYTES = A_ROUNDS * 256 * 16;                                          // 24576 (padded tail)
-constexpr int BN = 128, B_BYTES = BN * ROWB;                                          // 8192
-constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;                                  // 73728: 2 halo + 3 weight buffers
-}  // namespace halo
-
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const IgemmArgs a) {
-  using namespace halo;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 4);
-  const int wm = wave >> 1, wn = wave & 1;      // wave tile: tile rows [4wm, 4wm+4) x couts [64wn, 64wn+64)
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
-  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
-  const int thi = rest % a.tiles_h;
-  const int t = rest / a.tiles_h;
-  const int n0 = tn * BN;
-  const int oh0 = thi * TH, ow0 = twi * TW;
-
-  // ---- per-thread constant staging offsets ----
-  unsigned voffA[A_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < A_ROUNDS; ++r) {
-    const int s = r * 256 + tid;
-    const int px = s >> 2, cs = s & 3;
-    const int c = cs ^ ((px >> 2) & 3);
-    const int hh = px / HWID, hw = px - hh * HWID;
-    const int ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
-    const bool ok = (px < HPIX) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
-    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
-  }
-  unsigned voffB[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int row = j * 64 + (tid >> 2);
-    const int c = (tid & 3) ^ ((row >> 2) & 3);
-    voffB[j] = (unsigned)((row * a.Cin + c * 8) * 2);
-  }
-  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
-  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
-  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
-  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
-  const int kcn = a.Cin / BK;
-  const int ngroups = a.kt * kcn;          // (dt, kc) groups, 9 spatial taps each
-  const int nk = ngroups * 9;
-
-  auto frame_ptr = [&](int dt) -> const bf16_t* {
-    if (a.kt > 1) {
-      const int fv = t + dt - (a.kt - 1);
-      if (fv >= 0) return a.x + fv * frame_elems;
-      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
-      return a.x;
-    }
-    return a.x + (long long)t * frame_elems;
-  };
-
-  // staging cursors (SGPR state)
-  int h_dt = 0, h_kc = 0;                  // group whose halo is being staged
-  auto stage_halo_round = [&](auto rc, int buf) {   // one 4 KB round of group (h_dt, h_kc) into A[buf]
-    constexpr int r = decltype(rc)::value;
-    if (DOVE_DBG(a) & 1) return;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 256 + wave * 64) * 16), 16, voffA[r],
-                                             h_kc * ROWB, 0, 0);
-  };
-  int b_tap = 0, b_dt = 0, b_kc = 0;       // weight tile cursor: spatial tap, temporal tap, channel chunk
-  auto stage_b = [&](auto bc) {
-    constexpr int buf = decltype(bc)::value;
-    const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
-    if (!(DOVE_DBG(a) & 2)) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + (j * 256 + wave * 64) * 16), 16,
-                                               voffB[j], b_kc * ROWB, 0, 0);
-    }
-    if (++b_tap == 9) {
-      b_tap = 0;
-      if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
-    }
-  };
-
-  // per-lane constant B fragment offsets (buffer 0); buffers 1, 2 are +B_BYTES immediates
-  int boff[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wn * 64 + i * 32 + l31;
-      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
-    }
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-
-  // ---- prologue: whole halo of group 0 + weights of step 0 ----
-  stage_halo_round(std::integral_constant<int, 0>{}, 0);
-  stage_halo_round(std::integral_constant<int, 1>{}, 0);
-  stage_halo_round(std::integral_constant<int, 2>{}, 0);
-  stage_halo_round(std::integral_constant<int, 3>{}, 0);
-  stage_halo_round(std::integral_constant<int, 4>{}, 0);
-  stage_halo_round(std::integral_constant<int, 5>{}, 0);
-  static_assert(A_ROUNDS == 6, "prologue is written for 6 halo rounds");
-  if (++h_kc == kcn) { h_kc = 0; ++h_dt; }   // cursor -> group 1
-  stage_b(std::integral_constant<int, 0>{});
-
-  const int R0 = 4 * wm * HWID + l31;      // halo row of (tile row 4wm, column l31) before the tap shift
-  const int hi4 = hi << 2;
-
-  auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
-    constexpr int tap = decltype(tapc)::value;
-    constexpr int dh = tap / 3, dw = tap % 3;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // stage the next step's weight tile (3-deep ring indexed by tap % 3) and one round of the next halo
-    if (tap < 8 || more_groups) stage_b(std::integral_constant<int, (tap + 1) % 3>{});
-    if constexpr (tap < A_ROUNDS) {
-      if (more_groups) stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1);
-    }
-    int aaddr[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int R = R0g + (p + dh) * HWID + dw;
-      aaddr[p] = (R << 6) + (((R ^ hi4) & 0xC) << 2);       // R*64 + ((hi ^ (R>>2)) & 3) * 16
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 xf[4], wf[2];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + (aaddr[p] ^ (kk << 5)));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[i] = *(const bf16x8*)(smem + (tap % 3) * B_BYTES + boff[i][kk]);
-      if (DOVE_DBG(a) & 4) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(wf[i]), "v"(xf[p])); }
-        continue;
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
-    }
-  };
-
-  for (int g = 0; g < ngroups; ++g) {
-    const int R0g = R0 + (g & 1) * (A_BYTES / ROWB);   // A buffer select folded into the row index (384 rows, keeps R>>2 & 3)
-    const bool more = g + 1 < ngroups;
-    step(std::integral_constant<int, 0>{}, g, R0g, more);
-    step(std::integral_constant<int, 1>{}, g, R0g, more);
-    step(std::integral_constant<int, 2>{}, g, R0g, more);
-    step(std::integral_constant<int, 3>{}, g, R0g, more);
-    step(std::integral_constant<int, 4>{}, g, R0g, more);
-    step(std::integral_constant<int, 5>{}, g, R0g, more);
-    step(std::integral_constant<int, 6>{}, g, R0g, more);
-    step(std::integral_constant<int, 7>{}, g, R0g, more);
-    step(std::integral_constant<int, 8>{}, g, R0g, more);
-    if (++h_kc == kcn) { h_kc = 0; ++h_dt; }            // halo cursor -> group g + 2
-  }
-
-  // ---- epilogue: tile row p -> output row oh0 + 4wm + p, column ow0 + l31 ----
-  const int ow = ow0 + l31;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int oh = oh0 + 4 * wm + p;
-    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
-    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int cb = n0 + wn * 64 + i * 32 + 8 * gq + 4 * hi;
-        if (cb >= a.Cout_st) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][gq * 4 + e];
-        if (a.bias) {
-          const f32x4 b = *(const f32x4*)(a.bias + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-        if (a.resid) {
-          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(a.out + pix * a.ldo + cb) = o;
-      }
-    }
-  }
-}
-
-
+// so the activations are fetched once per 9 taps (204 FLOP per staged byte).  Fragments for tap (dh, dw) are the same
+// halo rows shifted by dh*(TW+2) + dw.  The first (4-wave, 8 x 32 pixel) kernel of that family is gone; its shapes
+// (H < 16) run on igemm_fast.
 // ------------------------------------------------------------------------------------------------
 // 8-wave ping-pong variant of the halo kernel.  PMC on the 4-wave kernel: MFMA busy 56 % of cycles, waves
 // parked/stalled 70 % -- each wave interleaves staging, 12 ds_reads, ~30 VALU and 16 MFMAs per K-step and the
@@ -2037,10 +1821,55 @@ static const bf16_t* zero_page() {
   return g_zero_page[dev];
 }
 
-static int g_force_generic = -1;
+// ------------------------------------------------------------------------------------------------
+// Dispatch.  ONE selection rule (used by the launch, by dove_conv_gn_partial_rows and by dove_conv_kernel_name); no
+// environment switches.  Which shapes of the 33x720x1280 clip reach which kernel:
+//   conv3x3_halo4x  3x3(x3) stride-1 convs with Cin % 64 == 0, Cout % 128 == 0, H, W >= 16 (every VAE resnet conv) and the
+//                   upsample-fused 3x3 convs (Upsample3D)                                       268 + 12 launches, 55 % of the step
+//   conv3x3_halo8   the same convs with Cin_pad == 32: encoder.conv_in (3 -> 128), decoder.conv_in (16 -> 512)        8 launches
+//   gemm4x          plain GEMMs with M >= 4096, Cout % 256 == 0, Cin % 128 == 0, Cin >= 256 (DiT qkv / out / ff)    168 launches
+//   gemm8           other plain GEMMs with M >= 4096, Cout % 128 == 0: SpatialNorm conv_y||conv_b (Cin 32), 1x1x1 shortcuts  158
+//   igemm_fast      everything else without upsampling: stride-2 downsample convs, decoder.conv_out (128 -> 3),
+//                   encoder.conv_out, patch / text embedding, proj_out, 3x3 convs of small clips (H or W < 16)            33
+//   igemm (v1)      upsample-fused convs too small for the halo tile, frames above the 31-bit buffer range                0
+// ------------------------------------------------------------------------------------------------
+enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO8, K_HALO8_UP, K_HALO4X, K_HALO4X_UP, K_GEMM8, K_GEMM4X };
+static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo8_kernel", "conv3x3_halo8_kernel",
+                                           "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel", "gemm4x_kernel"};
+
+static ConvKernel select_kernel(const dove_conv_desc* d) {
+  const long long M = (long long)d->t_out * d->h_out * d->w_out;
+  const bool frame_fits = (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31);
+  const bool plain_gemm = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
+                          d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 && M >= 4096 &&
+                          (long long)512 * d->cin * 2 < (1ll << 31);
+  if (plain_gemm) {
+    if (d->cout_pad % 256 == 0 && d->cout_store % 256 == 0 && d->cin % 128 == 0 && d->cin >= 256 && (long long)256 * d->cin * 2 < (1ll << 31) &&
+        d->ldo < (1 << 20) && d->ldr < (1 << 20) && (d->act == 0 || d->act == 1))
+      return K_GEMM4X;
+    // few, very deep tiles (K > 4096 with < 1024 tiles) run better on the 2-blocks-per-CU igemm_fast
+    const long long g8_tiles = ((M + 511) / 512) * (d->cout_pad / 128);
+    if (g8_tiles >= 1024 || d->cin <= 4096) return K_GEMM8;
+  }
+  const bool conv3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
+                     d->cout_pad % 128 == 0 && frame_fits;
+  if (conv3) {
+    const bool same = d->up == 0 && d->tmode == 0 && d->h_out == d->h_in && d->w_out == d->w_in && d->w_out >= 16 && d->h_out >= 16;
+    const bool ups = d->up == 1 && d->kt == 1 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in && d->h_out >= 16 && d->w_out >= 32;
+    const bool h4 = d->cout_store % 128 == 0 && d->cin % 64 == 0 && d->ldo < (1 << 20) && (!d->resid || d->ldr < (1 << 20));
+    if (same) return h4 ? K_HALO4X : K_HALO8;
+    if (ups) return h4 ? K_HALO4X_UP : K_HALO8_UP;
+  }
+  const int BN = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
+  const bool fits = frame_fits && (long long)BN * d->cin * 2 < (1ll << 31);
+  return (d->up == 0 && fits) ? K_IGEMM_FAST : K_IGEMM;
+}
+
+/* name of the kernel a call would dispatch to (reporting: bench.py's per-kernel roofline; tests pin the production shapes) */
+extern "C" const char* dove_conv_kernel_name(const dove_conv_desc* d) { return d ? kKernelNames[select_kernel(d)] : ""; }
 
 template <int BN, int BK>
-static int launch_igemm(const IgemmArgs& a, unsigned grid, hipStream_t s) {
+static int launch_igemm(const IgemmArgs& a, unsigned grid, bool fast, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -2048,47 +1877,29 @@ static int launch_igemm(const IgemmArgs& a, unsigned grid, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  if (g_force_generic < 0) {
-    const char* e = getenv("DOVE_IGEMM_GENERIC");   // debugging aid: route everything through the v1 kernel
-    g_force_generic = (e && e[0] == '1') ? 1 : 0;
-  }
-  // frame / weight-tap byte ranges must fit the 31-bit buffer offsets of the fast path
-  const bool fits = (long long)a.H_in * a.W_in * a.Cin * 2 < (1ll << 31) && (long long)BN * a.Cin * 2 < (1ll << 31);
-  if (a.up == 0 && fits && !g_force_generic) {
-    hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
-    DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(fast)");
-    return DOVE_OK;
-  }
-  hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
+  if (fast) hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16");
   return DOVE_OK;
 }
 
-// does this call dispatch to conv3x3_halo4x?  (one rule for the launch and for dove_conv_gn_partial_rows)
-static bool halo4x_applies(const dove_conv_desc* d) {
-  static int enabled = -1, no_halo = -1, ablate = 0;
-  if (enabled < 0) {
-    const char* e = getenv("DOVE_CONV_HALO4X");
-    enabled = (e && e[0] == '0') ? 0 : 1;                      // default on; 0 falls back to conv3x3_halo8
-    const char* n = getenv("DOVE_IGEMM_NOHALO");
-    no_halo = (n && n[0] == '1') ? 1 : 0;
-#ifdef DOVE_TIMING_BUILD
-    const char* ab = getenv("DOVE_IGEMM_ABLATE");
-    ablate = ab ? atoi(ab) : 0;
-#endif
+static int cu_count() {
+  static int cus[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) dev = 0;
+  if (!cus[dev]) {
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus[dev] = n;
   }
-  if (!enabled || no_halo) return false;
-  const bool common = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
-                      d->cout_pad % 128 == 0 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
-                      d->cout_store % 128 == 0 && d->cin % 64 == 0 && d->ldo < (1 << 20) && (!d->resid || d->ldr < (1 << 20));
-  if (!common) return false;
-  if (d->up == 0)
-    return d->tmode == 0 && d->h_out == d->h_in && d->w_out == d->w_in && d->w_out >= 16 && d->h_out >= 16;
-  return d->kt == 1 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in && d->h_out >= 16 && d->w_out >= 32 && !(ablate & 7);
+  return cus[dev];
 }
 
 extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
-  if (!d || !halo4x_applies(d)) return 0;
+  if (!d) return 0;
+  const ConvKernel k = select_kernel(d);
+  if (k != K_HALO4X && k != K_HALO4X_UP) return 0;
   if (d->cout_store != 128 && d->cout_store != 256 && d->cout_store != 512) return 0;   // 4 / 8 / 16 channels per group
   if (d->cout_store != d->cout_pad) return 0;
   const long long th = (d->h_out + halo8::TH - 1) / halo8::TH, tw = (d->w_out + halo8::TW - 1) / halo8::TW;
@@ -2127,7 +1938,121 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     a.debug = ablate;
   }
 #endif
-  // tile shape: 8x16 pixels for images, 1x128 for token-major (H == 1) tensors
+  hipStream_t s = (hipStream_t)stream;
+  const ConvKernel kern = select_kernel(d);
+  DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
+                 "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
+  const long long M = (long long)d->t_out * d->h_out * d->w_out;
+  switch (kern) {
+    case K_GEMM4X: {
+      static bool attr4g = false;
+      if (!attr4g) {
+        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+        attr4g = true;
+      }
+      a.tiles_n = d->cout_pad / 256;
+      const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
+      DOVE_CHECK_ARG(nt > 0 && nt < (1ll << 31), "conv_igemm: grid too large");
+      const int cus = cu_count();
+      const unsigned grid4 = nt > cus ? (unsigned)cus : (unsigned)nt;
+#ifdef DOVE_TIMING_BUILD
+      if (d->debug_buf && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
+        static bool attrt = false;
+        if (!attrt) {
+          (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+          attrt = true;
+        }
+        a.zero = (const bf16_t*)d->debug_buf;
+        hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+      } else
+#endif
+      if (d->gate) {
+        DOVE_CHECK_ARG(d->act == 0, "conv_igemm: gate with activation is not a path of the reference");
+        hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+      } else if (d->act == 1) {
+        hipLaunchKernelGGL((gemm4x_kernel<true, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+      } else {
+        hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+      }
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
+      return DOVE_OK;
+    }
+    case K_GEMM8: {
+      static bool attrg = false;
+      if (!attrg) {
+        (void)hipFuncSetAttribute((const void*)gemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
+        attrg = true;
+      }
+      a.tiles_n = d->cout_pad / 128;
+      const long long gridg = ((M + gemm8::BM - 1) / gemm8::BM) * a.tiles_n;
+      DOVE_CHECK_ARG(gridg > 0 && gridg < (1ll << 31), "conv_igemm: grid too large");
+      hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)gridg), dim3(512), gemm8::LDS_BYTES, s, a, M);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8)");
+      return DOVE_OK;
+    }
+    case K_HALO4X:
+    case K_HALO4X_UP: {
+      a.gn_partial = d->gn_partial;
+      a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
+      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
+      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
+      static bool attr4 = false;
+      if (!attr4) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+#ifdef DOVE_TIMING_BUILD
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+#endif
+        attr4 = true;
+      }
+      const int cus = cu_count();                              // persistent: one workgroup per CU walks its share of the tiles
+      const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
+#ifdef DOVE_TIMING_BUILD
+      if (d->debug_buf && kern == K_HALO4X) {                   // tools/halo4x_timing.py
+        a.gate = (const float*)d->debug_buf;
+        hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      } else
+#endif
+      if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
+      return DOVE_OK;
+    }
+    case K_HALO8:
+    case K_HALO8_UP: {
+      static bool attr8 = false;
+      if (!attr8) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+#ifdef DOVE_TIMING_BUILD
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
+#endif
+        attr8 = true;
+      }
+      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
+      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = d->cout_pad / 128;
+      const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
+#ifdef DOVE_TIMING_BUILD
+      if (d->debug_buf && kern == K_HALO8) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
+        a.gate = (const float*)d->debug_buf;
+        hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      } else
+#endif
+      if (kern == K_HALO8_UP) hipLaunchKernelGGL((conv3x3_halo8_kernel<false, true>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv3x3_halo8_kernel<false, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
+      return DOVE_OK;
+    }
+    default: break;
+  }
+  // generic tiles: 8x16 pixels for images, 1x128 for token-major (H == 1) tensors
   int twl = 7;
   if (d->h_out > 1) {
     twl = 4;
@@ -2142,199 +2067,9 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   a.tiles_n = d->cout_pad / BN;
   const long long grid = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
   DOVE_CHECK_ARG(grid > 0 && grid < (1ll << 31), "conv_igemm: grid too large");
-  hipStream_t s = (hipStream_t)stream;
-  {
-    static int no_halo = -1;
-    if (no_halo < 0) { const char* e = getenv("DOVE_IGEMM_NOHALO"); no_halo = (e && e[0] == '1') ? 1 : 0; }
-    const bool halo_ok = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 0 && d->pad_h == 1 && d->pad_w == 1 &&
-                         d->tmode == 0 && d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == d->h_in &&
-                         d->w_out == d->w_in && d->w_out >= 16 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) &&
-                         !no_halo;
-    // plain GEMM (linear / 1x1x1 conv over a contiguous channels-last tensor): ping-pong gemm8 for large M
-    {
-      static int use_g8 = -1;
-      if (use_g8 < 0) { const char* e = getenv("DOVE_GEMM8"); use_g8 = (e && e[0] == '0') ? 0 : 1; }
-      const long long M = (long long)d->t_out * d->h_out * d->w_out;
-      const bool g8_ok = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
-                         d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 &&
-                         M >= 4096 && (long long)512 * d->cin * 2 < (1ll << 31) && use_g8 && !(DOVE_DBG(a) & 127);
-      // gemm4x: 256 x 256 tiles, one wave per SIMD, persistent (DOVE_GEMM4X=0 falls back to gemm8 / igemm_fast)
-      static int use_g4 = -1;
-      if (use_g4 < 0) { const char* e = getenv("DOVE_GEMM4X"); use_g4 = (e && e[0] == '0') ? 0 : 1; }
-      if (g8_ok && use_g4 && d->cout_pad % 256 == 0 && d->cout_store % 256 == 0 && d->cin % 128 == 0 && d->cin >= 256 &&
-          (long long)256 * d->cin * 2 < (1ll << 31) && d->ldo < (1 << 20) && d->ldr < (1 << 20) && (!d->gate || d->resid) &&
-          (d->act == 0 || d->act == 1)) {
-        static bool attr4g = false;
-        if (!attr4g) {
-          (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          attr4g = true;
-        }
-        static int pgrid4 = -1;
-        if (pgrid4 < 0) {
-          int dev = 0, cus = 256;
-          (void)hipGetDevice(&dev);
-          (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-          pgrid4 = cus;
-        }
-        a.tiles_n = d->cout_pad / 256;
-        const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
-        DOVE_CHECK_ARG(nt > 0 && nt < (1ll << 31), "conv_igemm: grid too large");
-        const unsigned grid4 = nt > pgrid4 ? (unsigned)pgrid4 : (unsigned)nt;
-#ifdef DOVE_TIMING_BUILD
-        if (d->debug_buf && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
-          static bool attrt = false;
-          if (!attrt) {
-            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-            attrt = true;
-          }
-          a.zero = (const bf16_t*)d->debug_buf;
-          hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-        } else
-#endif
-        if (d->gate) {
-          DOVE_CHECK_ARG(d->act == 0, "conv_igemm: gate with activation is not a path of the reference");
-          hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-        } else if (d->act == 1) {
-          hipLaunchKernelGGL((gemm4x_kernel<true, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-        } else {
-          hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-        }
-        DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
-        return DOVE_OK;
-      }
-      // few, very deep tiles (e.g. ff2: K = 12288, 864 tiles) run slightly better on the 2-blocks-per-CU fast kernel
-      const long long g8_tiles = ((M + gemm8::BM - 1) / gemm8::BM) * (d->cout_pad / 128);
-      if (g8_ok && (g8_tiles >= 1024 || d->cin <= 4096)) {
-        static bool attrg = false;
-        if (!attrg) {
-          (void)hipFuncSetAttribute((const void*)gemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-          attrg = true;
-        }
-        a.tiles_n = d->cout_pad / 128;
-        const long long gridg = ((M + gemm8::BM - 1) / gemm8::BM) * a.tiles_n;
-        DOVE_CHECK_ARG(gridg > 0 && gridg < (1ll << 31), "conv_igemm: grid too large");
-        hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)gridg), dim3(512), gemm8::LDS_BYTES, s, a, M);
-        DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8)");
-        return DOVE_OK;
-      }
-    }
-    static int halo8 = -1;
-    if (halo8 < 0) { const char* e = getenv("DOVE_CONV_HALO8"); halo8 = (e && e[0] == '0') ? 0 : 1; }
-    const bool halo_up_ok = d->kt == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->up == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-                            d->act == 0 && !d->gate && d->cout_pad % 128 == 0 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in &&
-                            d->h_out >= 16 && d->w_out >= 32 && (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31) && !no_halo &&
-                            !(DOVE_DBG(a) & 7);
-    static int halo4x = -1, h4cfg = 0;
-    if (halo4x < 0) {
-      const char* e = getenv("DOVE_CONV_HALO4X");
-      halo4x = (e && e[0] == '0') ? 0 : 1;   // default on; DOVE_CONV_HALO4X=0 falls back to conv3x3_halo8
-      const char* c = getenv("DOVE_HALO4X_CFG");
-      h4cfg = c ? atoi(c) : 0;
-    }
-    DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
-                   "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
-    (void)halo4x; (void)h4cfg;
-    if (halo4x_applies(d)) {
-      a.gn_partial = d->gn_partial;
-      a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
-      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
-      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
-      a.tiles_n = d->cout_pad / 128;
-      const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-      DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
-#ifdef DOVE_TIMING_BUILD
-      const bool timing = h4cfg == 9 && d->debug_buf;
-      if (timing) a.gate = (const float*)d->debug_buf;
-#endif
-      static bool attr4 = false;
-      if (!attr4) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-#ifdef DOVE_TIMING_BUILD
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-#endif
-        attr4 = true;
-      }
-      // persistent: one workgroup per CU walks its share of the tiles (DOVE_HALO4X_GRID=0: one workgroup per tile)
-      static int pgrid = -1;
-      if (pgrid < 0) {
-        int dev = 0, cus = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const char* ge = getenv("DOVE_HALO4X_GRID");
-        pgrid = ge ? atoi(ge) : cus;
-      }
-      const unsigned grid = (pgrid > 0 && g4 > pgrid) ? (unsigned)pgrid : (unsigned)g4;
-#ifdef DOVE_TIMING_BUILD
-      if (timing && !d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      else
-#endif
-      if (d->up) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
-      return DOVE_OK;
-    }
-    if (halo_up_ok && halo8) {
-      static bool attru = false;
-      if (!attru) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-        attru = true;
-      }
-      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
-      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
-      a.tiles_n = d->cout_pad / 128;
-      const long long gu = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-      DOVE_CHECK_ARG(gu > 0 && gu < (1ll << 31), "conv_igemm: grid too large");
-      hipLaunchKernelGGL((conv3x3_halo8_kernel<false, true>), dim3((unsigned)gu), dim3(512), halo8::LDS_BYTES, s, a);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8 up)");
-      return DOVE_OK;
-    }
-    if (halo_ok && halo8 && d->h_out >= 16) {
-      static bool attr8 = false;
-      if (!attr8) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-#ifdef DOVE_TIMING_BUILD
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-#endif
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-        attr8 = true;
-      }
-      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
-      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
-      a.tiles_n = d->cout_pad / 128;
-      const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-      DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
-#ifdef DOVE_TIMING_BUILD
-      if (d->debug_buf) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
-        a.gate = (const float*)d->debug_buf;
-        hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
-        a.gate = nullptr;
-      } else
-#endif
-      hipLaunchKernelGGL((conv3x3_halo8_kernel<false, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
-      return DOVE_OK;
-    }
-    if (halo_ok) {
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, halo::LDS_BYTES);
-        attr = true;
-      }
-      a.tiles_w = (d->w_out + halo::TW - 1) / halo::TW;
-      a.tiles_h = (d->h_out + halo::TH - 1) / halo::TH;
-      a.tiles_n = d->cout_pad / 128;
-      const long long g2 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-      DOVE_CHECK_ARG(g2 > 0 && g2 < (1ll << 31), "conv_igemm: grid too large");
-      hipLaunchKernelGGL(conv3x3_halo_kernel, dim3((unsigned)g2), dim3(256), halo::LDS_BYTES, s, a);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo)");
-      return DOVE_OK;
-    }
-  }
+  const bool fast = kern == K_IGEMM_FAST;
   const bool bk64 = (d->cin % 64 == 0);
-  if (BN == 128) return bk64 ? launch_igemm<128, 64>(a, (unsigned)grid, s) : launch_igemm<128, 32>(a, (unsigned)grid, s);
-  if (BN == 64) return bk64 ? launch_igemm<64, 64>(a, (unsigned)grid, s) : launch_igemm<64, 32>(a, (unsigned)grid, s);
-  return bk64 ? launch_igemm<32, 64>(a, (unsigned)grid, s) : launch_igemm<32, 32>(a, (unsigned)grid, s);
+  if (BN == 128) return bk64 ? launch_igemm<128, 64>(a, (unsigned)grid, fast, s) : launch_igemm<128, 32>(a, (unsigned)grid, fast, s);
+  if (BN == 64) return bk64 ? launch_igemm<64, 64>(a, (unsigned)grid, fast, s) : launch_igemm<64, 32>(a, (unsigned)grid, fast, s);
+  return bk64 ? launch_igemm<32, 64>(a, (unsigned)grid, fast, s) : launch_igemm<32, 32>(a, (unsigned)grid, fast, s);
 }

@@ -6,8 +6,6 @@ import ctypes as C
 import math
 from dataclasses import dataclass
 
-import os
-
 import torch
 
 from . import lib as L
@@ -55,7 +53,6 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
 
 
 _profiler = None
-_GN_FUSE = os.environ.get("DOVE_CONV_GN_FUSE", "1") != "0"     # 0: always run the separate GroupNorm statistics pass
 
 
 def set_profiler(records: list | None):
@@ -65,28 +62,26 @@ def set_profiler(records: list | None):
     _profiler = records
 
 
-def kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, in_thw) -> str:
-    """Which kernel dove_conv_igemm_bf16 dispatches to (mirror of the host rule in csrc/igemm.hip; reporting only)."""
-    T, H, W = in_thw
-    m = t_out * hw_out[0] * hw_out[1]
-    if (pc.kt == pc.kh == pc.kw == 1 and stride == 1 and up == 0 and tmode == 0 and pc.cout_pad % 128 == 0 and m >= 4096
-            and (T, H, W) == (t_out, hw_out[0], hw_out[1])):
-        if (os.environ.get("DOVE_GEMM4X", "1") != "0" and pc.cout_pad % 256 == 0 and pc.cout_store % 256 == 0
-                and pc.cin_pad % 128 == 0 and pc.cin_pad >= 256 and act in (0, 1)):
-            return "gemm4x_kernel"
-        tiles = -(-m // 512) * (pc.cout_pad // 128)
-        if tiles >= 1024 or pc.cin_pad <= 4096:
-            return "gemm8_kernel"
-    big = "conv3x3_halo8_kernel"
-    if os.environ.get("DOVE_CONV_HALO4X", "1") != "0" and pc.cout_store % 128 == 0 and pc.cin_pad % 64 == 0:
-        big = "conv3x3_halo4x_kernel"
-    if (pc.kh == 3 and pc.kw == 3 and stride == 1 and up == 0 and ph == 1 and pw == 1 and tmode == 0 and act == 0 and gate is None
-            and pc.cout_pad % 128 == 0 and hw_out == (H, W) and W >= 16):
-        return big if H >= 16 else "conv3x3_halo_kernel"
-    if (pc.kt == 1 and pc.kh == 3 and pc.kw == 3 and stride == 1 and up == 1 and ph == 1 and pw == 1 and act == 0 and gate is None
-            and pc.cout_pad % 128 == 0 and hw_out == (2 * H, 2 * W) and hw_out[0] >= 16 and hw_out[1] >= 32):
-        return big
-    return "igemm_fast_kernel" if up == 0 else "igemm_kernel"
+def conv_kernel_name(x_shape, pc: PackedConv, *, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, act=0, gated=False,
+                     resid=False) -> str:
+    """Kernel a conv / linear of this shape dispatches to (dove_conv_kernel_name; pure function of the descriptor, no GPU needed)."""
+    T, H, W, Cx = x_shape
+    d = L.ConvDesc()
+    ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
+    pw = (pc.kw - 1) // 2 if pad[1] is None else pad[1]
+    t_out = T if t_out is None else t_out
+    if hw_out is None:
+        hw_out = (H << up, W << up) if stride == 1 else ((H + 1 - pc.kh) // stride + 1, (W + 1 - pc.kw) // stride + 1)
+    d.t_in, d.h_in, d.w_in, d.cin = T, H, W, Cx
+    d.t_out, d.h_out, d.w_out = t_out, hw_out[0], hw_out[1]
+    d.cout_pad, d.cout_store = pc.cout_pad, pc.cout_store
+    d.kt, d.kh, d.kw, d.stride, d.pad_h, d.pad_w = pc.kt, pc.kh, pc.kw, stride, ph, pw
+    d.up, d.tmode, d.act = up, tmode, act
+    d.ldo = pc.cout_store
+    d.ldr = pc.cout_store if resid else 0
+    d.resid = 1 if (resid or gated) else None                  # only tested for NULL-ness by the selection rule
+    d.gate = 1 if gated else None
+    return L.load().dove_conv_kernel_name(C.byref(d)).decode()
 
 
 def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, stride: int = 1, pad=(None, None),
@@ -139,7 +134,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if gate is not None:
         assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
     partial = None
-    if gn_eps is not None and ldo == pc.cout_store and _GN_FUSE:
+    if gn_eps is not None and ldo == pc.cout_store:
         rows = int(L.load().dove_conv_gn_partial_rows(C.byref(d)))
         if rows > 0:
             partial = torch.empty(rows, 64, dtype=torch.float32, device=x.device)
@@ -151,8 +146,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if _profiler is not None:
         e1.record()
         flops = 2.0 * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
-        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1,
-                          kernel_variant(pc, stride, up, ph, pw, tmode, act, gate, t_out, hw_out, (T, H, W))))
+        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1, L.load().dove_conv_kernel_name(C.byref(d)).decode()))
     if partial is None:
         if getattr(out, "gn_stats", None) is not None:      # a re-used `out` tensor must not keep statistics of old contents
             out.gn_stats = None

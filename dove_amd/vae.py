@@ -98,11 +98,10 @@ class AutoencoderKLCogVideoX:
         self.dec_batch = c.get("num_latent_frames_batch_size", 2)
         if c.get("norm_num_groups", 32) != 32:
             raise NotImplementedError("HIP GroupNorm kernels are built for 32 groups")
-        import os as _os
-        # 2 = alternate frame-batches on two HIP streams.  Worth +2 % with the 8-wave conv kernel, +1.4 % with the persistent
-        # conv3x3_halo4x (whose workgroups own a whole CU each, so two convs mostly serialise) - and it makes per-kernel
-        # durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
-        self.n_streams = int(_os.environ.get("DOVE_VAE_STREAMS", "1"))
+        # n_streams = 2 alternates frame-batches on two HIP streams (bit-identical; tests/test_e2e_gpu.py).  Worth +1.4 % with the
+        # persistent conv3x3_halo4x (whose workgroups own a whole CU each, so two convs mostly serialise) - and it makes
+        # per-kernel durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
+        self.n_streams = 1
         self._streams = None
         self._pack(state_dict)
 

@@ -43,8 +43,8 @@ def test_version_and_error_channel(lib):
 
 def test_dispatch_rule_mirror(lib):
     """`dove_conv_gn_partial_rows` is pure host logic (no HIP call): it answers "does this conv dispatch to the kernel that
-    fuses the GroupNorm statistics, and how many partial rows will it write".  The Python mirror of the dispatch rule
-    (dove_amd.ops.kernel_variant, used for reporting in bench.py) must agree with it on every shape class of the VAE."""
+    fuses the GroupNorm statistics, and how many partial rows will it write" - from the same selection rule that
+    `dove_conv_kernel_name` reports, on every shape class of the VAE."""
     import ctypes as C
 
     import torch
@@ -82,7 +82,7 @@ def test_dispatch_rule_mirror(lib):
         pc, d = desc(cin, cout, k, T, H, W, up, stride)
         rows = int(lib.dove_conv_gn_partial_rows(C.byref(d)))
         ph = pw = 1 if stride == 1 and pc.kh == 3 else 0
-        var = ops.kernel_variant(pc, stride, up, ph, pw, 0, 0, None, d.t_out, (d.h_out, d.w_out), (T, H, W))
+        var = lib.dove_conv_kernel_name(C.byref(d)).decode()
         assert (rows > 0) == fused, (cin, cout, k, H, W, rows)
         assert (var == "conv3x3_halo4x_kernel") == fused, (cin, cout, k, H, W, var)
         if fused:
@@ -110,3 +110,48 @@ def test_product_library_has_no_work_skipping_switches():
     blob = open(L.LIB_PATH, "rb").read()
     assert b"DOVE_IGEMM_ABLATE" not in blob
     assert not os.path.basename(L.LIB_PATH).endswith("_timing.so")
+
+
+def test_kernel_dispatch_table():
+    """dove_conv_kernel_name is the library's ONE selection rule (no environment switches).  Pinned here: (i) the production
+    shapes of the 33x720x1280 clip run on the kernels DESIGN.md names for them; (ii) every kernel of the library is reached by
+    at least one GPU parity case of tests/test_ops_gpu.py (so no kernel depends on a fallback re-run for its coverage)."""
+    import math
+
+    import torch
+
+    import test_ops_gpu as T
+    from dove_amd import ops
+
+    def pc(cout, cin, k):
+        return ops.pack_conv(torch.zeros(cout, cin, *k), None, "cpu")
+
+    def name(x_shape, cout, cin, k, **kw):
+        p = pc(cout, cin, k)
+        return ops.conv_kernel_name(x_shape[:3] + (p.cin_pad,), p, **kw)
+
+    prod = {
+        "resnet conv 128->128 @ 9x720x1280": (name((9, 720, 1280), 128, 128, (3, 3, 3), resid=True), "conv3x3_halo4x_kernel"),
+        "resnet conv 512->512 @ 3x90x160": (name((3, 90, 160), 512, 512, (3, 3, 3)), "conv3x3_halo4x_kernel"),
+        "upsample conv 256->256 @ 360x640 -> 720x1280": (name((8, 360, 640), 256, 256, (3, 3), up=1, pad=(1, 1)), "conv3x3_halo4x_kernel"),
+        "encoder.conv_in 3->128": (name((9, 720, 1280), 128, 3, (3, 3, 3)), "conv3x3_halo8_kernel"),
+        "decoder.conv_in 16->512": (name((3, 90, 160), 512, 16, (3, 3, 3)), "conv3x3_halo8_kernel"),
+        "decoder.conv_out 128->3": (name((9, 720, 1280), 3, 128, (3, 3, 3)), "igemm_fast_kernel"),
+        "downsample conv stride 2": (name((9, 720, 1280), 128, 128, (3, 3), stride=2, pad=(0, 0)), "igemm_fast_kernel"),
+        "DiT qkv 3072->9216": (name((1, 1, 18226), 9216, 3072, ()), "gemm4x_kernel"),
+        "DiT ff2 12288->3072 gated": (name((1, 1, 18226), 3072, 12288, (), gated=True), "gemm4x_kernel"),
+        "SpatialNorm conv_y||conv_b 16->256": (name((3, 90, 160), 256, 16, (1, 1, 1)), "gemm8_kernel"),
+        "resnet shortcut 256->128 @ 720p": (name((9, 720, 1280), 128, 256, (1, 1, 1)), "gemm8_kernel"),
+        "text embedding 4096->3072 (226 rows)": (name((1, 1, 226), 3072, 4096, ()), "igemm_fast_kernel"),
+    }
+    for what, (got, want) in prod.items():
+        assert got == want, (what, got, want)
+    covered = set()
+    for cname, cin, cout, k, Tt, H, W, kw in T.CONV_CASES:
+        kw = {a: b for a, b in kw.items() if a not in ("cache",)}
+        resid = kw.pop("resid", False)
+        covered.add(name((Tt, H, W), cout, cin, k, resid=resid, **kw))
+    for cname, N, cin, cout, kw in T.LIN_CASES:
+        covered.add(name((1, 1, N), cout, cin, (), act=kw.get("act", 0), gated=kw.get("gate", False), resid=kw.get("resid_only", False)))
+    assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo8_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel",
+                       "gemm4x_kernel"}, covered

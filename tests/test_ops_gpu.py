@@ -78,6 +78,9 @@ CONV_CASES = [
     # so the staging streams cross a tile boundary every 18 steps) with more tiles than workgroups, and a kt = 1 conv
     ("c2d_halo4x_k64_many", 64, 128, (3, 3), 20, 64, 128, {}),
     ("c2d_halo4x_kt1_resid", 128, 256, (3, 3), 2, 24, 40, {"resid": True}),
+    # conv3x3_halo8 at its production roles: Cin_pad == 32 convs with H, W >= 16 (encoder.conv_in 3 -> 128, decoder.conv_in 16 -> 512)
+    ("c3d_halo8_conv_in_enc", 3, 128, (3, 3, 3), 3, 40, 48, {"cache": True}),
+    ("c3d_halo8_conv_in_dec", 16, 512, (3, 3, 3), 2, 18, 34, {}),
 ]
 
 
@@ -412,23 +415,6 @@ def test_invalid_arguments_raise():
         ops.conv(torch.zeros(1, 4, 4, 32, dtype=BF, device="cuda"), pc_g)
     with pytest.raises(RuntimeError, match="power of two"):
         ops.groupnorm_stats(torch.zeros(1, 4, 4, 96, dtype=BF, device="cuda"), 1e-6)
-
-
-def test_fallback_kernels_in_subprocess():
-    """conv3x3_halo4x / gemm4x are the default dispatch; the kernels they replaced stay in the library as fallbacks for
-    shapes outside their rules and behind DOVE_CONV_HALO4X=0 / DOVE_GEMM4X=0 (read once per process).  Re-run the conv
-    and linear parity cases with both switched off so the fallbacks (conv3x3_halo8, gemm8, igemm_fast) keep their coverage."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("DOVE_CONV_HALO4X") == "0" and os.environ.get("DOVE_GEMM4X") == "0":
-        pytest.skip("already running with the fallbacks selected")
-    env = dict(os.environ, DOVE_CONV_HALO4X="0", DOVE_GEMM4X="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "(test_conv or test_linear) and not fused and not fullsize"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
 
 
 # ---- MXFP8 linears (BASELINE configs[4]) -------------------------------------------------------------------------------------
