@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--dit-linear", choices=["bf16", "mxfp8"], default="bf16",
                     help="BASELINE configs[4] variant: the DiT's big linears in MXFP8 (block-scaled fp8 MFMA).  A SEPARATE line, "
                          "never the headline: the line says so in `dtype` and `config.variant`")
+    ap.add_argument("--dit-attention", choices=["bf16", "mxfp8"], default="bf16",
+                    help="same configs[4] variant: attention products on the block-scaled fp8 MFMA; never the headline")
     ap.add_argument("--single-clip", action="store_true",
                     help="strong scaling: ONE clip sharded over all ranks (halo-exact VAE + Ulysses DiT, dove_amd.dist."
                          "process_video_sharded) instead of one clip per rank; not the driver's default")
@@ -143,7 +145,8 @@ def main():
     if args.layers is not None:
         t["num_layers"] = args.layers
     t_build = time.time()
-    pipe = CogVideoXPipeline.from_config(v, t, s, seed=1234, device=dev, init_device=dev, dit_linear_precision=args.dit_linear)
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=1234, device=dev, init_device=dev, dit_linear_precision=args.dit_linear,
+                                         dit_attention_precision=args.dit_attention)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
 
@@ -235,16 +238,18 @@ def main():
                 pmc_busy = {"whole_step": pj.get("whole_step_mfma_busy_frac"), "per_kernel": pj.get("mfma_busy_frac_per_kernel"),
                             "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc pass, not this run)"}
                 pmc_src = "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, not this run)"
+        fp8_parts = (["qkv/out/ff linears"] if args.dit_linear == "mxfp8" else []) + (["attention"] if args.dit_attention == "mxfp8" else [])
+        headline = not fp8_parts
         res = {
             "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": observed_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dit_linear == "bf16" else "mxfp8 (DiT qkv/out/ff linears: e4m3 + E8M0 block scales) + bf16 (everything else)",
+            "dtype": "bf16" if headline else "mxfp8 (DiT " + " + ".join(fp8_parts) + ": e4m3 + E8M0 block scales) + bf16 (everything else)",
             "data": "synthetic",
             "config": {"workload": f"synthetic {args.frames}x{args.height}x{args.width} HR clip (LR {args.height//up}x{args.width//up}, 4x), "
                                    f"one-step t=399, CogVideoX1.5-5B VAE + {t['num_layers']}-layer DiT random-init, " + ("ONE clip sharded over all GPUs (BASELINE configs[2])" if strong else "1 clip per GPU (BASELINE configs[1])"),
                        "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15,
-                       "variant": "headline (bf16)" if args.dit_linear == "bf16" else "BASELINE configs[4]: fp8 DiT linears, NOT the headline dtype"},
+                       "variant": "headline (bf16)" if headline else "BASELINE configs[4]: fp8 DiT " + " + ".join(fp8_parts) + ", NOT the headline dtype"},
             "frames_per_s_per_gpu": value / world,
             "ranks": {"world_size_observed": observed_world, "gpus": gpu_ids,
                       "busy_s_per_rank": per_rank, "slowest_over_fastest": max(per_rank) / min(per_rank)},

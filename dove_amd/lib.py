@@ -56,6 +56,8 @@ SIGNATURES = {
     "dove_layernorm_modulate_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP, _VP, _LL, _VP],
     "dove_qkv_post_bf16": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP],
     "dove_attention_fwd_bf16": [_VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP],
+    "dove_qkv_post_mxfp8": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP, _VP],
+    "dove_attention_fwd_mxfp8": [_VP, _VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP],
     "dove_cl_from_ncthw": [_VP, _I, _I, _LL, _I, _F, _F, _VP, _VP],
     "dove_ncthw_from_cl": [_VP, _LL, _I, _LL, _F, _F, _F, _F, _VP, _I, _VP],
     "dove_avgpool_time_bf16": [_VP, _I, _LL, _VP, _VP],

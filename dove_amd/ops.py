@@ -280,6 +280,21 @@ def attention(Qh, Kh, Vt, N, Npad, heads, out):
     return out
 
 
+def qkv_post_mx(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Q8, K8, V8t, Vs):
+    """dove_qkv_post_mxfp8: e4m3 attention operands (Q8, K8 [heads][Npad][64], V8t [heads][64][Npad] u8; Vs [heads][Npad/64][64][2] u8)."""
+    L.require_cuda(qkv, gq, bq, gk, bk, cos, sin, Q8, K8, V8t, Vs)
+    L.check(L.load().dove_qkv_post_mxfp8(L.ptr(qkv), N, Npad, heads, 64, text_len, L.ptr(gq), L.ptr(bq), L.ptr(gk), L.ptr(bk),
+                                         L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Q8), L.ptr(K8), L.ptr(V8t), L.ptr(Vs),
+                                         L.stream_ptr()), "dove_qkv_post_mxfp8")
+
+
+def attention_mx(Q8, K8, V8t, Vs, N, Npad, heads, out):
+    L.require_cuda(Q8, K8, V8t, Vs, out)
+    L.check(L.load().dove_attention_fwd_mxfp8(L.ptr(Q8), L.ptr(K8), L.ptr(V8t), L.ptr(Vs), L.ptr(out), N, Npad, heads, 64,
+                                              out.shape[1], L.stream_ptr()), "dove_attention_fwd_mxfp8")
+    return out
+
+
 def cl_from_ncthw(x: torch.Tensor, cp: int, scale=1.0, shift=0.0) -> torch.Tensor:
     """[C,T,H,W] fp32/bf16 -> [T,H,W,cp] bf16 (zero-padded channels)."""
     L.require_cuda(x)

@@ -37,7 +37,7 @@ class CogVideoXPipeline:
 
     # ---- constructors ---------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, device="cuda", dit_linear_precision="bf16", **kw):
+    def from_pretrained(cls, model_path, torch_dtype=torch.bfloat16, device="cuda", dit_linear_precision="bf16", dit_attention_precision="bf16", **kw):
         """Read a CogVideoX1.5 / DOVE checkpoint directory (vae/, transformer/, scheduler/ with config.json +
         safetensors shards; /root/reference/finetune/scripts/prepare_sft_ckpt.py:43-69)."""
         cls._check_dtype(torch_dtype)
@@ -54,12 +54,13 @@ class CogVideoXPipeline:
             from transformers import AutoTokenizer
             tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "tokenizer"))
         return cls(AutoencoderKLCogVideoX(vcfg, vsd, device, torch_dtype),
-                   CogVideoXTransformer3DModel(tcfg, tsd, device, torch_dtype, dit_linear_precision), CogVideoXDPMScheduler(**scfg),
+                   CogVideoXTransformer3DModel(tcfg, tsd, device, torch_dtype, dit_linear_precision, dit_attention_precision), CogVideoXDPMScheduler(**scfg),
                    text_encoder, tokenizer)
 
     @classmethod
     def from_config(cls, vae_config=None, transformer_config=None, scheduler_config=None, seed: int = 1234,
-                    torch_dtype=torch.bfloat16, device="cuda", init_device="cpu", dit_linear_precision="bf16"):
+                    torch_dtype=torch.bfloat16, device="cuda", init_device="cpu", dit_linear_precision="bf16",
+                    dit_attention_precision="bf16"):
         """Deterministic random-init pipeline for synthetic benchmarks / parity tests (no weights offline)."""
         cls._check_dtype(torch_dtype)
         dv, dt, ds = default_configs()
@@ -67,7 +68,7 @@ class CogVideoXPipeline:
         # tensors are generated one at a time while they are packed (the 42-layer DiT is 22 GB in fp32)
         vae = AutoencoderKLCogVideoX(vcfg, W.LazyStateDict(W.vae_param_shapes(vcfg), seed, init_device), device, torch_dtype)
         tr = CogVideoXTransformer3DModel(tcfg, W.LazyStateDict(W.dit_param_shapes(tcfg), seed, init_device), device, torch_dtype,
-                                         dit_linear_precision)
+                                         dit_linear_precision, dit_attention_precision)
         return cls(vae, tr, CogVideoXDPMScheduler(**scfg))
 
     @staticmethod

@@ -26,12 +26,16 @@ def _ru(x, m):
 
 
 class CogVideoXTransformer3DModel:
-    def __init__(self, config: dict, state_dict: dict, device="cuda", dtype=torch.bfloat16, linear_precision: str = "bf16"):
+    def __init__(self, config: dict, state_dict: dict, device="cuda", dtype=torch.bfloat16, linear_precision: str = "bf16",
+                 attention_precision: str = "bf16"):
         """``linear_precision="mxfp8"`` (BASELINE configs[4], not a reference option): the four big linears of every block
         (fused QKV, attn1.to_out.0, ff.net.0.proj, ff.net.2 = 99.9 % of the DiT's linear MACs) run in OCP MXFP8 - e4m3
         elements with a power-of-two scale per 32 K-elements, weights quantised once at load, activations per call, both
-        scales applied inside the block-scaled MFMA (csrc/mxfp8.hip).  Everything else (norms, attention, embeddings,
-        residual stream, final projection) stays bf16 / fp32 exactly as in the default path."""
+        scales applied inside the block-scaled MFMA (csrc/mxfp8.hip).  ``attention_precision="mxfp8"`` (same variant): both
+        products of the attention on the block-scaled MFMA (csrc/attention_mx.hip) - q, k in e4m3 with fixed scales, V in MXFP8
+        along the keys, probabilities quantised per (query, 64-key tile) in registers; softmax statistics and the output
+        accumulator stay fp32.  Everything else (norms, embeddings, residual stream, final projection) stays bf16 / fp32
+        exactly as in the default path."""
         self.config = AttrDict(config)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -49,7 +53,10 @@ class CogVideoXTransformer3DModel:
         self.eps = c.get("norm_eps", 1e-5)
         if linear_precision not in ("bf16", "mxfp8"):
             raise ValueError(f"linear_precision must be 'bf16' or 'mxfp8', got {linear_precision!r}")
+        if attention_precision not in ("bf16", "mxfp8"):
+            raise ValueError(f"attention_precision must be 'bf16' or 'mxfp8', got {attention_precision!r}")
         self.linear_precision = linear_precision
+        self.attention_precision = attention_precision
         self._mod_cache = {}
         self._bufs = {}
         self._pack(state_dict)
@@ -155,8 +162,13 @@ class CogVideoXTransformer3DModel:
         npad = _ru(N, 128)
         key = (N,)
         if key not in self._bufs:
-            z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)   # noqa: E731
-            self._bufs = {key: (npad, z(self.heads, npad, 64), z(self.heads, npad, 64), z(self.heads, 64, npad))}
+            if self.attention_precision == "mxfp8":
+                z = lambda *s: torch.zeros(*s, dtype=torch.uint8, device=self.device)   # noqa: E731
+                self._bufs = {key: (npad, z(self.heads, npad, 64), z(self.heads, npad, 64), z(self.heads, 64, npad),
+                                    z(self.heads, npad // 64, 64, 2))}
+            else:
+                z = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=self.device)   # noqa: E731
+                self._bufs = {key: (npad, z(self.heads, npad, 64), z(self.heads, npad, 64), z(self.heads, 64, npad), None)}
         return self._bufs[key]
 
     # ---- forward -----------------------------------------------------------------------------------
@@ -194,7 +206,7 @@ class CogVideoXTransformer3DModel:
         assert cos.shape == (nv, self.hd), (cos.shape, nv)
         N = Lt + nv
         blocks_mod, final_mod = self._modulation(t)
-        npad, Qh, Kh, Vt = self._buffers(N)
+        npad, Qh, Kh, Vt, Vs = self._buffers(N)
 
         hs = torch.empty(N, D, dtype=torch.bfloat16, device=self.device)
         tok = ops.patchify(hidden, pt, p, self.pe_proj.cin_pad)
@@ -210,9 +222,14 @@ class CogVideoXTransformer3DModel:
         for bi, (blk, md) in enumerate(zip(self.blocks, blocks_mod)):
             n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], self.eps, md["m1"], Lt)
             qkv = big(n1, blk["qkv"])
-            ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
-                         1e-6, Qh, Kh, Vt)
-            att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1)          # reuse n1's storage for the attention output
+            if Vs is not None:
+                ops.qkv_post_mx(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
+                                1e-6, Qh, Kh, Vt, Vs)
+                att = ops.attention_mx(Qh, Kh, Vt, Vs, N, npad, Lh, n1)
+            else:
+                ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
+                             1e-6, Qh, Kh, Vt)
+                att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1)      # reuse n1's storage for the attention output
             big(att, blk["out"], resid=hs, gate=md["gate1"], gate_split=Lt, out=hs)
             n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
             f1 = big(n2, blk["ff1"], act=1)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 4
+#define DOVE_ABI_VERSION 5
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -160,6 +160,19 @@ int dove_mx_quant_bf16(const void* x, long long rows, int K, void* q, void* scal
 int dove_linear_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, const void* resid,
                       const float* gate, void* out, long long M, int N, int K, long long ldo, long long ldr, long long gate_split,
                       int act, void* stream);
+
+/* MXFP8 attention (csrc/attention_mx.hip; same configs[4] variant): dove_qkv_post_bf16's pre-processing with e4m3 outputs -
+ * Q8 [heads][Npad][64] = e4m3(q * qscale * 8) (fixed block scale 2^-3), K8 [heads][Npad][64] = e4m3(k) (scale 2^0),
+ * V8t [heads][64][Npad] e4m3 with one E8M0 scale per (d, 32 consecutive keys): Vs u8 [heads][Npad/64][64][2].
+ * Every row of the padded buffers is written (pad = zeros); Npad % 128 == 0.
+ * dove_attention_fwd_mxfp8: softmax(Q K^T) V on those operands, probabilities quantised per (query, 64-key tile) in
+ * registers; O as dove_attention_fwd_bf16. */
+int dove_qkv_post_mxfp8(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
+                        const float* gq, const float* bq, const float* gk, const float* bk, const float* cosT,
+                        const float* sinT, float qscale, float eps, void* Q8, void* K8, void* V8t, void* Vs,
+                        void* stream);
+int dove_attention_fwd_mxfp8(const void* Q8, const void* K8, const void* V8t, const void* Vs, void* O, long long N,
+                             long long Npad, int heads, int head_dim, long long ldo, void* stream);
 
 /* ---- T5 text encoder operators (non-empty prompts only: `pipe.text_encoder(ids)[0]`, /root/reference/inference_script.py:429-444;
  * transformers' T5EncoderModel of CogVideoX1.5: T5-v1.1-XXL, 24 blocks, d_model 4096, 64 heads x 64, gated-GELU d_ff 10240) ----

@@ -213,6 +213,69 @@ def attention(Qh, Kh, Vt, N, Npad, heads, out):
     return out
 
 
+def qkv_post_mx(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Q8, K8, V8t, Vs):
+    """dove_qkv_post_mxfp8: same pre-processing, e4m3 outputs (uint8 views); V in MXFP8 along the keys (32-key blocks per d row)."""
+    Qf = torch.zeros(heads, Npad, 64)
+    Kf = torch.zeros(heads, Npad, 64)
+    Vf = torch.zeros(heads, 64, Npad)
+    D = heads * 64
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64) for i in range(3))
+    q = F.layer_norm(q, (64,), gq.float(), bq.float(), eps)
+    k = F.layer_norm(k, (64,), gk.float(), bk.float(), eps)
+
+    def rope(t):
+        tv = t[text_len:]
+        xr, xi = tv.reshape(tv.shape[0], heads, 32, 2).unbind(-1)
+        rot = torch.stack([-xi, xr], dim=-1).flatten(2)
+        return torch.cat([t[:text_len], tv * cos.float()[:, None] + rot * sin.float()[:, None]], dim=0)
+
+    if cos is not None:
+        q, k = rope(q), rope(k)
+    Qf[:, :N] = (q * (qscale * 8.0)).permute(1, 0, 2)
+    Kf[:, :N] = k.permute(1, 0, 2)
+    Vf[:, :, :N] = v.permute(1, 2, 0)
+    Q8.copy_(Qf.to(torch.float8_e4m3fn).view(torch.uint8))
+    K8.copy_(Kf.to(torch.float8_e4m3fn).view(torch.uint8))
+    vq, ve = mx_quant_ref(Vf.reshape(heads * 64, Npad))                  # blocks of 32 consecutive keys
+    V8t.copy_(vq.view(torch.uint8).reshape(heads, 64, Npad))
+    Vs.copy_(ve.reshape(heads, 64, Npad // 64, 2).permute(0, 2, 1, 3))
+
+
+def attention_mx(Q8, K8, V8t, Vs, N, Npad, heads, out, thr=6.0):
+    """dove_attention_fwd_mxfp8 restated tile by tile.  Running max m as in the kernel: set by the first tile, afterwards moved
+    (for all 32 queries of a wave) only when one of them sees a score above m + thr.  The probabilities of each (query, 64-key
+    tile) are e4m3 values of 2^(s - m - e), e = ceil(max_tile(s) - m) - 8; the row sum uses the unquantised values."""
+    q = torch.zeros(heads, Npad, 64)
+    q[:, :N] = Q8.view(torch.float8_e4m3fn).float()[:, :N] * 0.125
+    k = K8.view(torch.float8_e4m3fn).float()
+    ve = Vs.permute(0, 2, 1, 3).reshape(heads * 64, Npad // 32)
+    v = mx_dequant(V8t.view(torch.float8_e4m3fn).reshape(heads * 64, Npad), ve).reshape(heads, 64, Npad)
+    m = torch.zeros(heads, Npad)
+    l = torch.zeros(heads, Npad)
+    o = torch.zeros(heads, Npad, 64)
+    for t0 in range(0, N, 64):
+        t1 = min(t0 + 64, N)
+        s = torch.einsum("hqd,hkd->hqk", q, k[:, t0:t1]) - m[..., None]
+        mt = s.amax(dim=2)
+        if t0 == 0:
+            delta, alpha = mt, torch.ones_like(mt)
+        else:
+            fire = (mt > thr).reshape(heads, Npad // 32, 32).any(dim=2, keepdim=True).expand(-1, -1, 32).reshape(heads, Npad)
+            delta = torch.where(fire, mt.clamp_min(0.0), torch.zeros_like(mt))
+            alpha = torch.exp2(-delta)
+        m = m + delta
+        s = s - delta[..., None]
+        mt = mt - delta
+        e = torch.ceil(mt).clamp_min(-100.0) - 8.0
+        p = torch.exp2(s)
+        l = l * alpha + p.sum(dim=2)
+        pq = (p * torch.exp2(-e)[..., None]).to(torch.float8_e4m3fn).float()
+        o = o * alpha[..., None] + torch.einsum("hqk,hdk->hqd", pq, v[:, :, t0:t1]) * torch.exp2(e)[..., None]
+    o = (o / l[..., None])[:, :N]
+    out[:N, : heads * 64] = o.permute(1, 0, 2).reshape(N, heads * 64).to(BF)
+    return out
+
+
 def cl_from_ncthw(x, cp, scale=1.0, shift=0.0):
     Cc, T, H, W = x.shape
     y = torch.zeros(T, H, W, cp, dtype=BF)
@@ -349,7 +412,7 @@ def attention_bias(qkv, bias, heads):
     return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
 
 
-ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention",
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "qkv_post_mx", "attention_mx",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

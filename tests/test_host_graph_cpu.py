@@ -273,12 +273,15 @@ def test_dit_mxfp8_host_path(monkeypatch):
     rope = odit.rope_3d(64, 2, 4, 6)
     ts = torch.tensor([399])
     outs = {}
-    for prec in ("bf16", "mxfp8"):
-        tr = CogVideoXTransformer3DModel(t, wt, "cpu", linear_precision=prec)
+    for prec in ("bf16", "mxfp8", "mxfp8+attn"):
+        tr = CogVideoXTransformer3DModel(t, wt, "cpu", linear_precision=prec.split("+")[0],
+                                         attention_precision="mxfp8" if prec.endswith("attn") else "bf16")
         outs[prec] = tr(hidden_states=hidden, encoder_hidden_states=text, timestep=ts, image_rotary_emb=rope, return_dict=False)[0].float()
     want = odit.OracleDiT(t, wt).forward(hidden.float(), text.float(), ts, rope)
-    e_bf, e_mx = rel(outs["bf16"], want), rel(outs["mxfp8"], want)
-    print(f"tiny DiT rel-max-err vs fp32 oracle: bf16 graph {e_bf:.4f}, mxfp8 graph {e_mx:.4f}")
-    assert e_bf < 0.03 and e_mx < 0.15
+    e_bf, e_mx, e_mxa = rel(outs["bf16"], want), rel(outs["mxfp8"], want), rel(outs["mxfp8+attn"], want)
+    print(f"tiny DiT rel-max-err vs fp32 oracle: bf16 graph {e_bf:.4f}, mxfp8 linears {e_mx:.4f}, + mxfp8 attention {e_mxa:.4f}")
+    assert e_bf < 0.03 and e_mx < 0.15 and e_mxa < 0.2
     with pytest.raises(ValueError):
         CogVideoXTransformer3DModel(t, wt, "cpu", linear_precision="fp4")
+    with pytest.raises(ValueError):
+        CogVideoXTransformer3DModel(t, wt, "cpu", attention_precision="fp4")

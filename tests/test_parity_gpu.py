@@ -162,11 +162,13 @@ def test_dit_42_layers_per_block(full):
     assert ev <= 1.5 * evb + 2e-3, (ev, evb)
 
 
-def test_mxfp8_dit_linears_psnr_gate(full):
-    """BASELINE configs[4]: the DiT's big linears in MXFP8 (block-scaled e4m3 MFMA), 42 layers, gated against the bf16 HIP path
-    and the fp32 oracle on the configs[0]-size clip.  Reported: per-block residual-stream error, velocity error, PSNR."""
+@pytest.mark.parametrize("attn", ["bf16", "mxfp8"])
+def test_mxfp8_dit_psnr_gate(full, attn):
+    """BASELINE configs[4]: the DiT's big linears (and, second case, the attention products) in MXFP8 (block-scaled e4m3 MFMA),
+    42 layers, gated against the bf16 HIP path and the fp32 oracle on the configs[0]-size clip.  Reported: per-block
+    residual-stream error, velocity error, PSNR."""
     pipe, (v, t, s), text, video, noise, ref, tr32 = (full[k] for k in ("pipe", "cfg", "text", "video", "noise", "ref", "tr32"))
-    tr8 = CogVideoXTransformer3DModel(t, full["wt"], "cuda", linear_precision="mxfp8")
+    tr8 = CogVideoXTransformer3DModel(t, full["wt"], "cuda", linear_precision="mxfp8", attention_precision=attn)
     pipe8 = CogVideoXPipeline(pipe.vae, tr8, pipe.scheduler)
     latent = tr32["latent"]
     B, T, C, h, w = latent.shape
@@ -178,7 +180,7 @@ def test_mxfp8_dit_linears_psnr_gate(full):
     v8 = tr8(**kw, _trace=b8)[0]
     v16 = pipe.transformer(**kw, _trace=b16)[0]
     rows = [(n, rms_rel(b8[n], tr32[n][0]), rms_rel(b16[n], tr32[n][0])) for n in ["embed"] + [f"block{i}" for i in range(42)]]
-    print("[mxfp8] residual stream rms-rel vs fp32 oracle (mxfp8 | bf16): " +
+    print(f"[mxfp8 attention={attn}] residual stream rms-rel vs fp32 oracle (mxfp8 | bf16): " +
           "  ".join(f"{n}:{a:.1e}|{b:.1e}" for n, a, b in rows[::6] + rows[-1:]))
     e8, e16 = rms_rel(v8, tr32["v"]), rms_rel(v16, tr32["v"])
     print(f"[mxfp8] velocity rms-rel vs fp32 oracle: mxfp8 {e8:.3e}  bf16 {e16:.3e}")
