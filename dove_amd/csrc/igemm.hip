@@ -1833,9 +1833,70 @@ static const bf16_t* zero_page() {
 //                   encoder.conv_out, patch / text embedding, proj_out, 3x3 convs of small clips (H or W < 16)            33
 //   igemm (v1)      upsample-fused convs too small for the halo tile, frames above the 31-bit buffer range                0
 // ------------------------------------------------------------------------------------------------
-enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO8, K_HALO8_UP, K_HALO4X, K_HALO4X_UP, K_GEMM8, K_GEMM4X };
+// ------------------------------------------------------------------------------------------------------------------
+// smallk: out [M][ldo] = x [M][32] w^T [Cout][32] + bias for the 1x1x1 convs with (padded) Cin = 32 - CogVideoXSpatialNorm3D's
+// conv_y || conv_b on the 16-channel latent, 158 launches per clip.  64 FLOP per output byte: HBM-write-bound, the MFMA tile
+// pipelines (gemm8: 68 us per launch, 1.3 TB/s) only add latency.  A lane keeps 4 output channels x 32 K of weights as packed
+// bf16 pairs (64 registers), a wave covers 256 consecutive channels of one row per pass: x is the same address for all
+// lanes (staged per block in LDS, read as a broadcast), the products run on v_dot2c_f32_bf16, stores are 8 B per lane = 512
+// contiguous bytes per wave.
+// ------------------------------------------------------------------------------------------------------------------
+namespace smallk { constexpr int ROWS = 32; }
+__global__ __launch_bounds__(256) void smallk_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                     bf16_t* __restrict__ out, long long M, int cout_store, long long ldo) {
+  typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+  __shared__ uint4 xs[4 * smallk::ROWS][4];                      // the block's 128 rows of x, one coalesced load
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long rb = (long long)blockIdx.x * 4 * smallk::ROWS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const long long m = rb + (idx >> 2);
+    xs[idx >> 2][idx & 3] = m < M ? *(const uint4*)(x + m * 32 + (idx & 3) * 8) : uint4{0u, 0u, 0u, 0u};
+  }
+  const int n0 = (blockIdx.y * 64 + lane) * 4;
+  const bool live = n0 < cout_store;                             // Cout_store % 4 == 0: a lane's four channels are all in or all out
+  uint32_t wr[4][16];
+  float b[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = *(const uint4*)(w + (long long)(n0 + j) * 32 + q * 8);
+        wr[j][q * 4 + 0] = v.x; wr[j][q * 4 + 1] = v.y; wr[j][q * 4 + 2] = v.z; wr[j][q * 4 + 3] = v.w;
+      }
+    if (bias) { b[0] = bias[n0]; b[1] = bias[n0 + 1]; b[2] = bias[n0 + 2]; b[3] = bias[n0 + 3]; }
+  }
+  __syncthreads();
+  if (!live) return;
+  const long long r0 = rb + wave * smallk::ROWS;
+#pragma unroll 4
+  for (int r = 0; r < smallk::ROWS; ++r) {
+    const long long m = r0 + r;
+    if (m >= M) break;
+    uint32_t xr[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = xs[wave * smallk::ROWS + r][q];           // same address in every lane: LDS broadcast
+      xr[q * 4 + 0] = v.x; xr[q * 4 + 1] = v.y; xr[q * 4 + 2] = v.z; xr[q * 4 + 3] = v.w;
+    }
+    float acc[4] = {b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[j] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, wr[j][k]), __builtin_bit_cast(v2bf, xr[k]), acc[j], false);
+    uint2 o;
+    o.x = pack_bf2(acc[0], acc[1]);
+    o.y = pack_bf2(acc[2], acc[3]);
+    *(uint2*)(out + m * ldo + n0) = o;
+  }
+}
+
+enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO8, K_HALO8_UP, K_HALO4X, K_HALO4X_UP, K_GEMM8, K_GEMM4X, K_SMALLK };
 static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo8_kernel", "conv3x3_halo8_kernel",
-                                           "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel", "gemm4x_kernel"};
+                                           "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel", "gemm4x_kernel", "smallk_kernel"};
 
 static ConvKernel select_kernel(const dove_conv_desc* d) {
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
@@ -1843,6 +1904,9 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
   const bool plain_gemm = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
                           d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 && M >= 4096 &&
                           (long long)512 * d->cin * 2 < (1ll << 31);
+  const bool pointwise = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 && d->t_in == d->t_out &&
+                         d->h_in == d->h_out && d->w_in == d->w_out;
+  if (pointwise && d->cin == 32 && d->act == 0 && !d->resid && !d->gate && d->cout_store >= 128) return K_SMALLK;
   if (plain_gemm) {
     if (d->cout_pad % 256 == 0 && d->cout_store % 256 == 0 && d->cin % 128 == 0 && d->cin >= 256 && (long long)256 * d->cin * 2 < (1ll << 31) &&
         d->ldo < (1 << 20) && d->ldr < (1 << 20) && (d->act == 0 || d->act == 1))
@@ -1977,6 +2041,12 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
         hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
       }
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
+      return DOVE_OK;
+    }
+    case K_SMALLK: {
+      dim3 grid((unsigned)((M + 4 * smallk::ROWS - 1) / (4 * smallk::ROWS)), (unsigned)((d->cout_store + 255) / 256));
+      hipLaunchKernelGGL(smallk_kernel, grid, dim3(256), 0, s, a.x, a.w, a.bias, a.out, M, d->cout_store, d->ldo);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(smallk)");
       return DOVE_OK;
     }
     case K_GEMM8: {

@@ -386,17 +386,45 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ sinT, float qscale, float eps,
                                                        bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh,
                                                        bf16_t* __restrict__ Vt) {
+  __shared__ float vt[4][64][65];   // V transpose staging, one slice per wave (row stride 65: conflict-free both ways)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y;
   const int which = blockIdx.z;  // 0 q, 1 k, 2 v
-  const long long n = ((long long)blockIdx.x * 4 + wave) * 64 + lane;
-  if (n >= N) return;
+  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  const long long n = n0 + lane;
+  if (n0 >= N) return;
   const int D = heads * 64;
-  const bf16_t* src = qkv + n * (3LL * D) + (long long)which * D + h * 64;
   float f[64];
+  if (which == 2 && (Npad & 7) == 0) {
+    // the wave's 64 tokens x 64 dims go through LDS so that lane d owns row d of V^T: 128 contiguous bytes per lane instead of
+    // 64 two-byte stores Npad apart (2.5 -> 3.4 TB/s for the whole kernel)
+    if (n < N) {
+      const bf16_t* src = qkv + n * (3LL * D) + 2LL * D + h * 64;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) unpack8(*(const uint4*)(src + i * 8), f + i * 8);
+    } else {
+#pragma unroll
+      for (int d = 0; d < 64; ++d) f[d] = 0.f;                          // keys past N inside the pad stay zero
+    }
+#pragma unroll
+    for (int d = 0; d < 64; ++d) vt[wave][lane][d] = f[d];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16_t* dst = Vt + ((long long)h * 64 + lane) * Npad + n0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = vt[wave][j * 8 + e][lane];
+      if (n0 + j * 8 + 8 <= Npad) *(uint4*)(dst + j * 8) = pack8(o);
+    }
+    return;
+  }
+  if (n >= N) return;
+  const bf16_t* src = qkv + n * (3LL * D) + (long long)which * D + h * 64;
 #pragma unroll
   for (int i = 0; i < 8; ++i) unpack8(*(const uint4*)(src + i * 8), f + i * 8);
-  if (which == 2) {
+  if (which == 2) {                                                     // row stride not 16-byte aligned (rank-local packing)
     bf16_t* dst = Vt + ((long long)h * 64) * Npad + n;
 #pragma unroll
     for (int d = 0; d < 64; ++d) dst[(long long)d * Npad] = f2bf(f[d]);

@@ -55,6 +55,8 @@ CONV_CASES = [
     ("c111_128_256", 128, 256, (1, 1, 1), 3, 9, 11, {}),
     ("c111_16_1024", 16, 1024, (1, 1, 1), 3, 4, 6, {}),
     ("c111_gemm8", 128, 256, (1, 1, 1), 2, 48, 64, {}),
+    # smallk_kernel: CogVideoXSpatialNorm3D's conv_y || conv_b on the 16-channel latent (Cin_pad 32), ragged last row block
+    ("c111_smallk_spatialnorm", 16, 512, (1, 1, 1), 2, 45, 81, {}),
     ("c2d_down_even", 128, 128, (3, 3), 3, 16, 20, {"stride": 2, "pad": (0, 0)}),
     ("c2d_down_odd", 64, 64, (3, 3), 2, 15, 9, {"stride": 2, "pad": (0, 0)}),
     ("c2d_up", 128, 128, (3, 3), 3, 6, 9, {"up": 1, "pad": (1, 1)}),
