@@ -50,7 +50,8 @@ __device__ __forceinline__ f32x16 mfma_c_in(bf16x8 a, bf16x8 b, const f32x16& c)
   return d;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+template <int NW>   // waves per workgroup: NW x 32 queries share every K / V^T tile (waves 0-3 stage them)
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                           long long N, long long Npad, long long ldo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y;
-  const long long q0 = (long long)blockIdx.x * 128 + wave * 32;
+  const long long q0 = (long long)blockIdx.x * (NW * 32) + wave * 32;
 
   bf16x8 qf[4];
   {
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
   auto stage = [&](auto bufc, int tile) {
     constexpr int BUF = decltype(bufc)::value;
+    if (NW > 4 && wave >= 4) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(smem + BUF * STAGE + (j * 256 + wave * 64) * 16), 16, vk[j],
@@ -236,14 +238,37 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_ARG(Npad * 128 < (1ll << 31), "attention_fwd: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
   constexpr int LDS = 4 * 16384;
+  constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 (3 waves per SIMD) -13 %
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  dim3 grid((unsigned)(Npad / 128), heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
+  dim3 grid((unsigned)((Npad + NW * 32 - 1) / (NW * 32)), heads);
+  hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
                      (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
 }
+
+#ifdef DOVE_TIMING_BUILD
+// tools/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS), within one run
+extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads,
+                                          long long ldo, int nw, void* stream) {
+  constexpr int LDS = 4 * 16384;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((Npad + nw * 32 - 1) / (nw * 32)), heads);
+  if (nw == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  else if (nw == 6) hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, dim3(384), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  else if (nw == 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(512), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  else return -1;
+  DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16_nw");
+  return DOVE_OK;
+}
+#endif

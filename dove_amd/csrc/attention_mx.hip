@@ -174,7 +174,8 @@ extern "C" int dove_qkv_post_mxfp8(const void* qkv, long long N, long long Npad,
 // attention: 4 waves x 32 queries; K and V^T tiles of 64 keys = 4 KB each, one LDS-DMA instruction per thread and tile; two tiles
 // per barrier (4 stages of 8 KB)
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_mx_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ K8,
+template <int NW>   // waves per workgroup sharing each K / V^T tile (waves 0-3 stage)
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mx_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ K8,
                                                              const unsigned char* __restrict__ V8t, const unsigned char* __restrict__ Vs,
                                                              bf16_t* __restrict__ O, long long N, long long Npad, long long ldo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mx_kernel(const unsigned char
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
   const int h = blockIdx.y;
-  const long long q0 = (long long)blockIdx.x * 128 + wave * 32;
+  const long long q0 = (long long)blockIdx.x * (NW * 32) + wave * 32;
 
   v8i qf;
   {
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mx_kernel(const unsigned char
   const unsigned vv = (unsigned)((long long)srow * Npad + sc_ld * 16);
   auto stage = [&](auto bufc, int tile) {
     constexpr int BUF = decltype(bufc)::value;
+    if (NW > 4 && wave >= 4) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)(smem + BUF * STAGE + wave * 1024), 16, vk, tile * 4096, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(smem + BUF * STAGE + VOFF + wave * 1024), 16, vv, tile * 64, 0, 0);
   };
@@ -361,9 +363,23 @@ extern "C" int dove_attention_fwd_mxfp8(const void* Q8, const void* K8, const vo
   DOVE_CHECK_ARG(Npad * 64 < (1ll << 31), "attention_fwd_mxfp8: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd_mxfp8: bad ldo");
   constexpr int LDS = 4 * 8192;
-  dim3 grid((unsigned)(Npad / 128), heads);
-  hipLaunchKernelGGL(attn_fwd_mx_kernel, grid, dim3(256), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8,
+  constexpr int NW = 4;
+  dim3 grid((unsigned)((Npad + NW * 32 - 1) / (NW * 32)), heads);
+  hipLaunchKernelGGL(attn_fwd_mx_kernel<NW>, grid, dim3(NW * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8,
                      (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_mxfp8");
   return DOVE_OK;
 }
+
+#ifdef DOVE_TIMING_BUILD
+extern "C" int dove_attention_fwd_mxfp8_nw(const void* Q8, const void* K8, const void* V8t, const void* Vs, void* O, long long N, long long Npad,
+                                           int heads, long long ldo, int nw, void* stream) {
+  constexpr int LDS = 4 * 8192;
+  dim3 grid((unsigned)((Npad + nw * 32 - 1) / (nw * 32)), heads);
+#define MXL(W) hipLaunchKernelGGL(attn_fwd_mx_kernel<W>, grid, dim3(W * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8, \
+                                  (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo)
+  if (nw == 4) MXL(4); else if (nw == 6) MXL(6); else if (nw == 8) MXL(8); else return -1;
+  DOVE_CHECK_LAUNCH("dove_attention_fwd_mxfp8_nw");
+  return DOVE_OK;
+}
+#endif

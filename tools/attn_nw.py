@@ -1,0 +1,69 @@
+"""attn_fwd_kernel<NW>: 4 / 6 / 8 waves per workgroup sharing each K / V^T tile (TIMING build only), interleaved within one run."""
+import ctypes as C
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dove_amd import lib as L  # noqa: E402
+
+L.use_timing_build()
+lib = L.load()
+lib.dove_attention_fwd_bf16_nw.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_int, C.c_void_p]
+N, H = 18226, 48
+npad = (N + 127) // 128 * 128
+g = torch.Generator(device="cuda").manual_seed(0)
+Q = torch.zeros(H, npad, 64, dtype=torch.bfloat16, device="cuda")
+K = torch.zeros(H, npad, 64, dtype=torch.bfloat16, device="cuda")
+V = torch.zeros(H, 64, npad, dtype=torch.bfloat16, device="cuda")
+Q[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 0.18 * 1.6).to(torch.bfloat16)
+K[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 1.6).to(torch.bfloat16)
+V[:, :, :N] = torch.randn(H, 64, N, device="cuda", generator=g).to(torch.bfloat16)
+outs = {nw: torch.zeros(N, H * 64, dtype=torch.bfloat16, device="cuda") for nw in (4, 6, 8)}
+t = {nw: [] for nw in outs}
+for rnd in range(5):
+    for nw, o in outs.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            assert lib.dove_attention_fwd_bf16_nw(Q.data_ptr(), K.data_ptr(), V.data_ptr(), o.data_ptr(), N, npad, H, H * 64, nw,
+                                                  torch.cuda.current_stream().cuda_stream) == 0
+        e1.record()
+        torch.cuda.synchronize()
+        if rnd:
+            t[nw].append(e0.elapsed_time(e1) / 5)
+fl = 4.0 * N * N * 64 * H
+for nw in outs:
+    ms = statistics.median(t[nw])
+    print(f"NW={nw}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s   equal to NW=4: {bool(torch.equal(outs[nw], outs[4]))}", flush=True)
+
+# ---- MXFP8 attention, same question ----
+from dove_amd import ops  # noqa: E402
+import math  # noqa: E402
+lib.dove_attention_fwd_mxfp8_nw.argtypes = [C.c_void_p] * 5 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_int, C.c_void_p]
+D = H * 64
+qkv = torch.randn(N, 3 * D, device="cuda", generator=g).to(torch.bfloat16)
+one, zero = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+zu = lambda *s: torch.zeros(*s, dtype=torch.uint8, device="cuda")      # noqa: E731
+Q8, K8, V8, Vs = zu(H, npad, 64), zu(H, npad, 64), zu(H, 64, npad), zu(H, npad // 64, 64, 2)
+ops_lib = L.load()
+assert ops_lib.dove_qkv_post_mxfp8(qkv.data_ptr(), N, npad, H, 64, 0, one.data_ptr(), zero.data_ptr(), one.data_ptr(), zero.data_ptr(), None, None,
+                                   0.125 * math.log2(math.e), 1e-6, Q8.data_ptr(), K8.data_ptr(), V8.data_ptr(), Vs.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream) == 0
+t = {nw: [] for nw in outs}
+for rnd in range(5):
+    for nw, o in outs.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            assert lib.dove_attention_fwd_mxfp8_nw(Q8.data_ptr(), K8.data_ptr(), V8.data_ptr(), Vs.data_ptr(), o.data_ptr(), N, npad, H, H * 64, nw,
+                                                   torch.cuda.current_stream().cuda_stream) == 0
+        e1.record()
+        torch.cuda.synchronize()
+        if rnd:
+            t[nw].append(e0.elapsed_time(e1) / 5)
+for nw in outs:
+    ms = statistics.median(t[nw])
+    print(f"mxfp8 NW={nw}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s   equal to NW=4: {bool(torch.equal(outs[nw], outs[4]))}", flush=True)
