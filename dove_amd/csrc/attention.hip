@@ -238,7 +238,7 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_ARG(Npad * 128 < (1ll << 31), "attention_fwd: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
   constexpr int LDS = 4 * 16384;
-  constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 (3 waves per SIMD) -13 %
+  constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
