@@ -1970,6 +1970,29 @@ extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
   return (long long)d->t_out * th * tw * 4;
 }
 
+static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern);
+
+// gemm4x tail: ntiles 256x256 tiles on G persistent workgroups take ceil(ntiles / G) rounds, and the last round of the DiT's
+// N = 3072 GEMMs (864 tiles on 256 CUs) keeps 96 CUs busy for a whole tile time.  When the rows behind the last FULL round fit
+// one resident wave of igemm_fast's 128x128 tiles (2 workgroups per CU), those rows go to igemm_fast instead: they then cost
+// about 0.6 of a gemm4x round spread over every CU.  Rows are disjoint, both launches are ordered on the stream, the epilogue
+// (bias / GELU / gated residual; gate_split shifted by the row offset) is the same code path as for any igemm_fast GEMM.
+static bool gemm4x_tail_split(const dove_conv_desc* d, long long* rows_main) {
+  const long long M = (long long)d->t_out * d->h_out * d->w_out;
+  if (d->t_out != 1 || d->h_out != 1) return false;                                  // token-major [1, 1, N] linears only
+  const int cus = cu_count(), tiles_n = d->cout_pad / 256;
+  const long long row_tiles = (M + gemm4x::BM - 1) / gemm4x::BM, ntiles = row_tiles * tiles_n;
+  if (ntiles <= cus || ntiles % cus == 0) return false;
+  const long long main_rt = (ntiles / cus) * cus / tiles_n;                           // row-tiles that fill whole rounds
+  if (main_rt < 1 || main_rt >= row_tiles) return false;
+  const long long tail_rows = M - main_rt * gemm4x::BM;
+  const long long tail_blocks = ((tail_rows + 127) / 128) * (d->cout_pad / 128);
+  if (tail_blocks > 2ll * cus) return false;                                          // more than one resident wave: no gain
+  if ((long long)128 * d->cin * 2 >= (1ll << 31)) return false;
+  *rows_main = main_rt * gemm4x::BM;
+  return true;
+}
+
 extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d && d->x && d->w && d->out, "conv_igemm: null pointer");
   DOVE_CHECK_ARG(d->cin % 32 == 0 && d->cin > 0, "conv_igemm: Cin (%d) must be a positive multiple of 32 (pad on pack)", d->cin);
@@ -1983,6 +2006,26 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d->up == 0 || d->up == 1, "conv_igemm: up must be 0/1");
   DOVE_CHECK_ARG(d->kt == 1 || (d->tmode == 0 && d->t_in == d->t_out), "conv_igemm: causal temporal taps need t_in == t_out and tmode 0");
   DOVE_CHECK_ARG(d->t_out > 0 && d->h_out > 0 && d->w_out > 0 && d->t_in > 0 && d->h_in > 0 && d->w_in > 0, "conv_igemm: empty tensor");
+  DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
+                 "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
+  const ConvKernel kern0 = select_kernel(d);
+  long long rows_main = 0;
+  if (kern0 == K_GEMM4X && !d->debug_buf && gemm4x_tail_split(d, &rows_main)) {
+    dove_conv_desc m = *d, t = *d;
+    m.w_in = m.w_out = (int)rows_main;
+    const long long tail = (long long)d->w_out - rows_main;
+    t.w_in = t.w_out = (int)tail;
+    t.x = (const char*)d->x + rows_main * d->cin * 2;
+    t.out = (char*)d->out + rows_main * d->ldo * 2;
+    if (d->resid) t.resid = (const char*)d->resid + rows_main * d->ldr * 2;
+    t.gate_split = d->gate_split > rows_main ? d->gate_split - rows_main : 0;
+    const int rc = conv_dispatch(&m, stream, K_GEMM4X);
+    return rc ? rc : conv_dispatch(&t, stream, K_IGEMM_FAST);
+  }
+  return conv_dispatch(d, stream, kern0);
+}
+
+static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern) {
   const bf16_t* zp = zero_page();
   DOVE_CHECK_ARG(zp, "conv_igemm: could not allocate the zero page");
   IgemmArgs a;
@@ -2003,9 +2046,6 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   }
 #endif
   hipStream_t s = (hipStream_t)stream;
-  const ConvKernel kern = select_kernel(d);
-  DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
-                 "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
   switch (kern) {
     case K_GEMM4X: {

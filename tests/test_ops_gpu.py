@@ -130,6 +130,12 @@ LIN_CASES = [
     ("lin4x_ragged", 4099, 256, 256, {}),
     ("lin4x_many_tiles", 20011, 256, 1024, {}),
     ("lin4x_many_tiles_gate", 20011, 384, 768, {"gate": True, "inplace": True}),
+    # gemm4x + igemm_fast tail split (rows behind the last full round of 256 tiles): 316 tiles -> 16384 rows + 3627 rows; the
+    # gate's row-class boundary before / inside the tail; GELU; the DiT's own N = 3072 shape (864 tiles -> 16384 + 1842 rows)
+    ("lin4x_tail_gate", 20011, 256, 1024, {"gate": True, "inplace": True}),
+    ("lin4x_tail_gate_late", 20011, 256, 1024, {"gate": True, "gate_split": 18000}),
+    ("lin4x_tail_gelu", 20011, 128, 1024, {"act": 1}),
+    ("lin4x_tail_dit_out", 18226, 256, 3072, {"gate": True, "gate_split": 226, "inplace": True}),
     ("lin4x_gelu_deep", 4500, 1536, 512, {"act": 1}),
     ("lin4x_resid", 4300, 512, 256, {"resid_only": True}),
 ]
@@ -149,7 +155,7 @@ def test_linear(case):
         g = torch.Generator().manual_seed(6)
         gate = torch.randn(2, pc_c.cout_pad, generator=g)
         resid = rnd(N, cout, seed=7)
-        kw.update(gate_split=N // 3)
+        kw.setdefault("gate_split", N // 3)
     ref = E.linear(x, pc_c, resid=resid, gate=gate, **kw)
     rg = None if resid is None else resid.cuda()
     got = ops.linear(x.cuda(), pc_g, resid=rg, gate=None if gate is None else gate.cuda(), out=rg if inplace else None, **kw)
