@@ -390,6 +390,9 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     from . import ops
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     D, heads = tr.D, tr.heads
+    if getattr(tr, "linear_precision", "bf16") != "bf16" or getattr(tr, "attention_precision", "bf16") != "bf16":
+        raise NotImplementedError("the sequence/head-parallel DiT runs the bf16 operators only (the MXFP8 variant of BASELINE "
+                                  "configs[4] is single-GPU / one clip per GPU)")
     if heads % world:
         raise ValueError(f"{heads} attention heads do not split over {world} ranks")
     hloc = heads // world
