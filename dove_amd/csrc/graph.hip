@@ -11,6 +11,7 @@
 // Memory: activations come from ONE arena (first-fit free list, stream-ordered reuse: a block is released as soon as the
 // last kernel reading it has been enqueued); causal-conv caches (diffusers' conv_cache: the last two input frames of every
 // k_t = 3 convolution) are copied out of the batch's activations into per-conv buffers, so nothing outlives its frame-batch.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -173,6 +174,11 @@ struct dove_ctx {
   float* gn_ws = nullptr;
   Arena arena;
   std::string err;
+  // multi-GPU (dove_comm_init*): this rank's frame-batches of a clip; halos travel rank -> rank + 1 in layer order
+  int rank = 0, nranks = 1;
+  dove_xfer_fn send_fn = nullptr, recv_fn = nullptr; void* xfer_user = nullptr;
+  void* rccl_lib = nullptr; void* rccl_comm = nullptr;
+  bool halo_recv = false, halo_send = false;            // set by the batch loop around the rank's first / last batch
 };
 
 namespace {
@@ -342,6 +348,15 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   }
   const int k = pc.kt - 1;
   auto it = c->cache.find(name);
+  if (c->halo_recv && it == c->cache.end()) {
+    // first batch of a rank > 0: the conv_cache the previous batch would have left arrives from rank - 1 (same layer order there)
+    Tensor h; h.T = k; h.H = x.H; h.W = x.W; h.C = x.C;
+    h.p = (bf16_t*)c->arena.alloc(h.bytes(), true);
+    if (!h.p) { dove_set_error("workspace exhausted (halo of %s: %zu bytes)", name.c_str(), h.bytes()); return DOVE_EINVAL; }
+    CHK(c->recv_fn(c->xfer_user, c->rank - 1, h.p, h.bytes(), stream));
+    c->cache[name] = h; c->cache_owner[name] = h.p;
+    it = c->cache.find(name);
+  }
   Tensor prev;
   const bool have = it != c->cache.end();
   if (have) prev = it->second;
@@ -356,6 +371,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     c->cache[name] = nc; c->cache_owner[name] = x.p;
     c->arena.release(old_owner);                              // the conv that read the old entry is already enqueued
     x.p = nullptr;
+    if (c->halo_send) CHK(c->send_fn(c->xfer_user, c->rank + 1, nc.p, nc.bytes(), stream));
     return 0;
   }
   nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
@@ -372,7 +388,29 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   c->cache[name] = nc; c->cache_owner[name] = nc.p;
   c->arena.release(old_owner);
   if (x_owned) free_t(c, x);
+  if (c->halo_send) CHK(c->send_fn(c->xfer_user, c->rank + 1, nc.p, nc.bytes(), stream));
   return 0;
+}
+// frames one frame-batch of t input frames leaves behind the encoder's / decoder's temporal stages (diffusers' Downsample3D
+// avg_pool1d with the first frame kept for odd t; Upsample3D: t -> 2t - 1 (t odd, > 1), 2t (t even), 1)
+int n_temporal_stages(const dove_ctx* c) {
+  int n = 0;
+  for (int r = c->cfg.vae_temporal_compression; r > 1; r >>= 1) ++n;
+  return n < c->cfg.vae_num_blocks - 1 ? n : c->cfg.vae_num_blocks - 1;
+}
+int enc_batch_frames(const dove_ctx* c, int t) {
+  for (int i = 0; i < n_temporal_stages(c); ++i) t = t > 1 ? (t % 2 ? 1 + (t - 1) / 2 : t / 2) : 1;
+  return t;
+}
+int dec_batch_frames(const dove_ctx* c, int t) {
+  for (int i = 0; i < n_temporal_stages(c); ++i) t = t > 1 ? (t % 2 ? 2 * t - 1 : 2 * t) : 1;
+  return t;
+}
+// contiguous groups of frame-batches, one per rank, earlier ranks take the extras (dove_amd.dist.split_batches)
+void rank_batches(const dove_ctx* c, int nb, int* b0, int* b1) {
+  const int base = nb / c->nranks, extra = nb % c->nranks, r = c->rank;
+  *b0 = r * base + (r < extra ? r : extra);
+  *b1 = *b0 + base + (r < extra ? 1 : 0);
 }
 int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::string& name, const Tensor* zq, Tensor* out, void* stream) {
   const float eps = c->cfg.vae_norm_eps;
@@ -576,8 +614,10 @@ extern "C" int dove_create(int device, const dove_model_config* cfg, dove_ctx** 
   *out = c;
   return DOVE_OK;
 }
+extern "C" void dove_comm_destroy(dove_ctx* c);
 extern "C" void dove_destroy(dove_ctx* c) {
   if (!c) return;
+  dove_comm_destroy(c);
   clear_caches(c);
   for (void* p : c->owned) (void)hipFree(p);
   if (c->rope_dev) (void)hipFree(c->rope_dev);
@@ -585,6 +625,105 @@ extern "C" void dove_destroy(dove_ctx* c) {
   if (c->arena.owned && c->arena.base) (void)hipFree(c->arena.base);
   delete c;
 }
+// ---- multi-GPU: halo exchange between the ranks of one clip (SURVEY.md 8(b) dove_comm_init, 8(e)) ---------------------------------
+// The transport is two function pointers; dove_comm_init binds them to RCCL (ncclSend / ncclRecv on the caller's stream, library
+// opened with dlopen so that libdove_hip.so itself does not depend on it), dove_comm_init_custom to anything else (tests: an
+// in-process mailbox between contexts on one GPU).
+namespace {
+struct Rccl {
+  void* lib; void* comm;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t);
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t);
+  int (*CommDestroy)(void*);
+};
+struct UniqueId { char b[128]; };   // ncclUniqueId: a 128-byte struct, passed BY VALUE to ncclCommInitRank
+int rccl_send(void* user, int peer, void* p, size_t bytes, void* stream) {
+  Rccl* r = (Rccl*)user;
+  const int rc = r->Send(p, bytes, /*ncclChar*/ 0, peer, r->comm, (hipStream_t)stream);
+  if (rc) { dove_set_error("ncclSend to rank %d failed (%d)", peer, rc); return DOVE_ELAUNCH; }
+  return 0;
+}
+int rccl_recv(void* user, int peer, void* p, size_t bytes, void* stream) {
+  Rccl* r = (Rccl*)user;
+  const int rc = r->Recv(p, bytes, /*ncclChar*/ 0, peer, r->comm, (hipStream_t)stream);
+  if (rc) { dove_set_error("ncclRecv from rank %d failed (%d)", peer, rc); return DOVE_ELAUNCH; }
+  return 0;
+}
+void* open_rccl() {
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  return h;
+}
+}  // namespace
+
+extern "C" int dove_comm_unique_id(void* out128) {
+  DOVE_CHECK_ARG(out128, "dove_comm_unique_id: null pointer");
+  void* h = open_rccl();
+  DOVE_CHECK_ARG(h, "dove_comm_unique_id: librccl.so not found (%s)", dlerror());
+  auto get = (int (*)(UniqueId*))dlsym(h, "ncclGetUniqueId");
+  DOVE_CHECK_ARG(get, "dove_comm_unique_id: ncclGetUniqueId not found");
+  const int rc = get((UniqueId*)out128);
+  DOVE_CHECK_ARG(rc == 0, "ncclGetUniqueId failed (%d)", rc);
+  return DOVE_OK;
+}
+extern "C" void dove_comm_destroy(dove_ctx* c) {
+  if (!c) return;
+  if (c->rccl_comm) {
+    Rccl* r = (Rccl*)c->rccl_comm;
+    if (r->comm) (void)r->CommDestroy(r->comm);
+    delete r;
+    c->rccl_comm = nullptr;
+  }
+  c->rank = 0; c->nranks = 1; c->send_fn = c->recv_fn = nullptr; c->xfer_user = nullptr;
+}
+extern "C" int dove_comm_init_custom(dove_ctx* c, int rank, int nranks, dove_xfer_fn send, dove_xfer_fn recv, void* user) {
+  DOVE_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks, "dove_comm_init_custom: bad rank %d of %d", rank, nranks);
+  DOVE_CHECK_ARG(nranks == 1 || (send && recv), "dove_comm_init_custom: send / recv callbacks are required");
+  dove_comm_destroy(c);
+  c->rank = rank; c->nranks = nranks; c->send_fn = send; c->recv_fn = recv; c->xfer_user = user;
+  return DOVE_OK;
+}
+extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank, int nranks) {
+  DOVE_CHECK_ARG(c && nccl_unique_id && nranks >= 1 && rank >= 0 && rank < nranks, "dove_comm_init: bad argument");
+  void* h = open_rccl();
+  DOVE_CHECK_ARG(h, "dove_comm_init: librccl.so not found (%s)", dlerror());
+  Rccl* r = new Rccl();
+  r->lib = h; r->comm = nullptr;
+  auto init = (int (*)(void**, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
+  r->Send = (decltype(r->Send))dlsym(h, "ncclSend");
+  r->Recv = (decltype(r->Recv))dlsym(h, "ncclRecv");
+  r->CommDestroy = (decltype(r->CommDestroy))dlsym(h, "ncclCommDestroy");
+  if (!init || !r->Send || !r->Recv || !r->CommDestroy) { delete r; dove_set_error("dove_comm_init: RCCL symbols not found"); return DOVE_EINVAL; }
+  HIPCHK(hipSetDevice(c->device));
+  UniqueId id;
+  memcpy(&id, nccl_unique_id, sizeof id);
+  const int rc = init(&r->comm, nranks, id, rank);
+  if (rc) { delete r; dove_set_error("ncclCommInitRank failed (%d)", rc); return DOVE_ELAUNCH; }
+  dove_comm_destroy(c);
+  c->rccl_comm = r;
+  c->rank = rank; c->nranks = nranks; c->send_fn = rccl_send; c->recv_fn = rccl_recv; c->xfer_user = r;
+  return DOVE_OK;
+}
+// frames [first, first + count) of a stage's output that THIS rank produces (stage 0: dove_vae_encode, n = F pixel frames ->
+// latent frames; stage 1: dove_vae_decode, n = T latent frames -> pixel frames); the other frames of the output buffer are
+// left untouched and are the other ranks' to deliver
+extern "C" int dove_shard_frames(dove_ctx* c, int stage, int n, int* first, int* count) {
+  DOVE_CHECK_ARG(c && first && count && n >= 1 && (stage == 0 || stage == 1), "dove_shard_frames: bad argument");
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(n, stage == 0 ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch, &fb);
+  int b0 = 0, b1 = (int)fb.size();
+  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
+  int f = 0;
+  *first = 0; *count = 0;
+  for (int b = 0; b < (int)fb.size(); ++b) {
+    const int k = stage == 0 ? enc_batch_frames(c, fb[b].second - fb[b].first) : dec_batch_frames(c, fb[b].second - fb[b].first);
+    if (b == b0) *first = f;
+    if (b >= b0 && b < b1) *count += k;
+    f += k;
+  }
+  return DOVE_OK;
+}
+
 extern "C" int dove_set_weight(dove_ctx* c, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype) {
   DOVE_CHECK_ARG(c && name && dev_ptr && shape && ndim >= 1 && ndim <= 5, "dove_set_weight: bad argument");
   DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "dove_set_weight: dtype must be DOVE_F32 or DOVE_BF16");
@@ -714,14 +853,24 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   const int T = 1 + (F - 1) / cf.vae_temporal_compression, h = H / 8, w = W / 8;
   const int ld = c->pc.at("encoder.conv_out").cout_store();
   CHK(alloc_t(c, T, h, w, ld, moments));
+  int b0 = 0, b1 = (int)fb.size();
+  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
   int t0 = 0;
-  for (auto& se : fb) {
-    Tensor xb = xcl; xb.p = xcl.p + (long long)se.first * H * W * xcl.C; xb.T = se.second - se.first;
-    Tensor o;
-    CHK(encoder(c, xb, &o, stream));
-    HIPCHK(hipMemcpyAsync(moments->p + (long long)t0 * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    t0 += o.T;
-    free_t(c, o);
+  for (int b = 0; b < (int)fb.size(); ++b) {
+    const auto& se = fb[b];
+    const int tb = enc_batch_frames(c, se.second - se.first);                          // latent frames of this batch
+    if (b >= b0 && b < b1) {
+      c->halo_recv = c->nranks > 1 && b == b0 && b > 0;
+      c->halo_send = c->nranks > 1 && b == b1 - 1 && b + 1 < (int)fb.size();
+      Tensor xb = xcl; xb.p = xcl.p + (long long)se.first * H * W * xcl.C; xb.T = se.second - se.first;
+      Tensor o;
+      const int rc = encoder(c, xb, &o, stream);
+      c->halo_recv = c->halo_send = false;
+      CHK(rc);
+      HIPCHK(hipMemcpyAsync(moments->p + (long long)t0 * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+      free_t(c, o);
+    }
+    t0 += tb;
   }
   free_t(c, xcl);
   clear_caches(c);
@@ -733,7 +882,24 @@ extern "C" int dove_vae_encode(dove_ctx* c, const void* x, int dtype, int F, int
   CHK(ensure_ws(c, F, H, W));
   Tensor m;
   CHK(vae_encode_cl(c, x, dtype, F, H, W, &m, stream));
-  CHK(dove_ncthw_from_cl(m.p, m.C, 2 * c->cfg.vae_latent_channels, (long long)m.T * m.H * m.W, 1.0f, 0.0f, -INFINITY, INFINITY, moments_out, out_dtype, stream));
+  if (c->nranks == 1) {
+    CHK(dove_ncthw_from_cl(m.p, m.C, 2 * c->cfg.vae_latent_channels, (long long)m.T * m.H * m.W, 1.0f, 0.0f, -INFINITY, INFINITY, moments_out, out_dtype, stream));
+  } else {
+    // only this rank's latent frames exist: convert them into a staging block and place them at their frame offset of [2L][T][h][w]
+    int first = 0, count = 0;
+    CHK(dove_shard_frames(c, 0, F, &first, &count));
+    if (count > 0) {
+      const size_t esz = out_dtype == DOVE_F32 ? 4 : 2;
+      const int C2 = 2 * c->cfg.vae_latent_channels;
+      const long long hw = (long long)m.H * m.W;
+      void* tmp = c->arena.alloc((size_t)C2 * count * hw * esz);
+      DOVE_CHECK_ARG(tmp, "workspace exhausted (encoder output staging)");
+      CHK(dove_ncthw_from_cl(m.p + (long long)first * hw * m.C, m.C, C2, (long long)count * hw, 1.0f, 0.0f, -INFINITY, INFINITY, tmp, out_dtype, stream));
+      CHK(copy2d((char*)moments_out + (size_t)first * hw * esz, (size_t)m.T * hw * esz, tmp, (size_t)count * hw * esz, (size_t)count * hw * esz, C2,
+                 (hipStream_t)stream));
+      c->arena.release(tmp);
+    }
+  }
   free_t(c, m);
   return DOVE_OK;
 }
@@ -769,21 +935,31 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   frame_batches(T, cf.vae_dec_batch, &fb);
   clear_caches(c);
   const size_t esz = out_dtype == DOVE_F32 ? 4 : 2;
+  int b0 = 0, b1 = (int)fb.size();
+  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
   int f0 = 0;
-  for (auto& se : fb) {
-    Tensor zb = zcl; zb.p = zcl.p + (long long)se.first * h * w * zcl.C; zb.T = se.second - se.first;
-    Tensor o;
-    CHK(decoder(c, zb, &o, stream));
-    // [C][F][H][W] output: this batch's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
-    void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
-    DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
-    CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
-                           range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
-    CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
-               cf.vae_out_channels, (hipStream_t)stream));
-    c->arena.release(tmp);
-    f0 += o.T;
-    free_t(c, o);
+  for (int b = 0; b < (int)fb.size(); ++b) {
+    const auto& se = fb[b];
+    const int fb_frames = dec_batch_frames(c, se.second - se.first);
+    if (b >= b0 && b < b1) {
+      c->halo_recv = c->nranks > 1 && b == b0 && b > 0;
+      c->halo_send = c->nranks > 1 && b == b1 - 1 && b + 1 < (int)fb.size();
+      Tensor zb = zcl; zb.p = zcl.p + (long long)se.first * h * w * zcl.C; zb.T = se.second - se.first;
+      Tensor o;
+      const int rc = decoder(c, zb, &o, stream);
+      c->halo_recv = c->halo_send = false;
+      CHK(rc);
+      // [C][F][H][W] output: this batch's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
+      void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
+      DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
+      CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
+                             range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+      CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
+                 cf.vae_out_channels, (hipStream_t)stream));
+      c->arena.release(tmp);
+      free_t(c, o);
+    }
+    f0 += fb_frames;
   }
   free_t(c, zcl);
   clear_caches(c);
@@ -860,6 +1036,7 @@ extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F,
                             const void* text, int Ltxt, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux,
                             void* video_out, int out_dtype, void* stream) {
   DOVE_CHECK_ARG(video_in && noise && text && video_out, "dove_sr_clip: null pointer");
+  DOVE_CHECK_ARG(c->nranks == 1, "dove_sr_clip: a multi-rank context runs the VAE stages only (dove_vae_encode / dove_vae_decode + the caller's gather)");
   DOVE_CHECK_ARG(F >= 1 && H % 16 == 0 && W % 16 == 0, "dove_sr_clip: H and W must be multiples of 16 (8x VAE, 2x patch)");
   CHK(ensure_ws(c, F, H, W));
   const auto& cf = c->cfg;

@@ -60,6 +60,32 @@ class GraphContext:
         except Exception:
             pass
 
+    # ---- one clip on several ranks (halo-exact VAE; include/dove_hip.h "one clip on several GPUs") ----
+    def comm_init_rccl(self, unique_id: bytes, rank: int, nranks: int):
+        L.check(L.load().dove_comm_init(self._h, unique_id, rank, nranks), "dove_comm_init")
+        self._rank, self._nranks = rank, nranks
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(L.load().dove_comm_unique_id(buf), "dove_comm_unique_id")
+        return buf.raw
+
+    def comm_init_custom(self, rank: int, nranks: int, send, recv):
+        """``send(peer, dev_ptr, nbytes, stream)`` / ``recv(...)`` -> 0 on success: any transport (tests: an in-process mailbox)."""
+        self._xfer = (L.XFER_FN(lambda user, peer, p, n, st: send(peer, p, n, st)), L.XFER_FN(lambda user, peer, p, n, st: recv(peer, p, n, st)))
+        L.check(L.load().dove_comm_init_custom(self._h, rank, nranks, self._xfer[0], self._xfer[1], None), "dove_comm_init_custom")
+        self._rank, self._nranks = rank, nranks
+
+    def comm_destroy(self):
+        L.load().dove_comm_destroy(self._h)
+
+    def shard_frames(self, stage: int, n: int):
+        """(first, count) of the output frames this rank produces: stage 0 = vae_encode (n pixel frames), 1 = vae_decode (n latent)."""
+        first, count = C.c_int(), C.c_int()
+        L.check(L.load().dove_shard_frames(self._h, stage, n, C.byref(first), C.byref(count)), "dove_shard_frames")
+        return first.value, count.value
+
     def workspace_bytes(self, F, H, W) -> int:
         return int(L.load().dove_workspace_bytes(self._h, F, H, W))
 
@@ -85,12 +111,12 @@ class GraphContext:
             keep.append(tp)
         return a, keep
 
-    def vae_encode(self, x: torch.Tensor) -> torch.Tensor:
-        """x [3,F,H,W] -> moments [2L, T, H/8, W/8] bf16."""
+    def vae_encode(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """x [3,F,H,W] -> moments [2L, T, H/8, W/8] bf16 (with a multi-rank communicator only this rank's frames are written)."""
         L.require_cuda(x)
         _, F, H, W = x.shape
         lat = self.vae_cfg["latent_channels"]
-        out = torch.empty(2 * lat, 1 + (F - 1) // self.vae_cfg.get("temporal_compression_ratio", 4), H // 8, W // 8, dtype=torch.bfloat16, device=x.device)
+        out = out if out is not None else torch.empty(2 * lat, 1 + (F - 1) // self.vae_cfg.get("temporal_compression_ratio", 4), H // 8, W // 8, dtype=torch.bfloat16, device=x.device)
         L.check(L.load().dove_vae_encode(self._h, L.ptr(x), L.dt_code(x), F, H, W, L.ptr(out), L.BF16, L.stream_ptr()), "dove_vae_encode")
         return out
 
@@ -106,11 +132,11 @@ class GraphContext:
                 "dove_dit_forward")
         return out
 
-    def vae_decode(self, z: torch.Tensor, prescale: float = 1.0, range01: bool = False) -> torch.Tensor:
-        """z [L,T,h,w] -> video [3, 1+4(T-1), 8h, 8w] bf16."""
+    def vae_decode(self, z: torch.Tensor, prescale: float = 1.0, range01: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+        """z [L,T,h,w] -> video [3, 1+4(T-1), 8h, 8w] bf16 (with a multi-rank communicator only this rank's frames are written)."""
         L.require_cuda(z)
         _, T, h, w = z.shape
-        out = torch.empty(self.vae_cfg["out_channels"], int(L.load().dove_vae_decode_num_frames(self._h, T)), 8 * h, 8 * w,
+        out = out if out is not None else torch.empty(self.vae_cfg["out_channels"], int(L.load().dove_vae_decode_num_frames(self._h, T)), 8 * h, 8 * w,
                           dtype=torch.bfloat16, device=z.device)
         L.check(L.load().dove_vae_decode(self._h, L.ptr(z), L.dt_code(z), T, h, w, prescale, int(range01), L.ptr(out), L.BF16, L.stream_ptr()),
                 "dove_vae_decode")

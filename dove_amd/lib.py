@@ -43,6 +43,7 @@ class DitAux(C.Structure):
 
 
 _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)   # dove_xfer_fn
 
 # name -> argtypes; the symbol list doubles as the export check in tests/test_abi.py
 SIGNATURES = {
@@ -81,9 +82,13 @@ SIGNATURES = {
     "dove_dit_forward": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _I, C.POINTER(DitAux), _VP, _I, _VP],
     "dove_vae_decode": [_VP, _VP, _I, _I, _I, _I, _F, _I, _VP, _I, _VP],
     "dove_sr_clip": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _I, _I, _F, _F, C.POINTER(DitAux), _VP, _I, _VP],
+    "dove_comm_unique_id": [_VP],
+    "dove_comm_init": [_VP, _VP, _I, _I],
+    "dove_comm_init_custom": [_VP, _I, _I, XFER_FN, XFER_FN, _VP],
+    "dove_shard_frames": [_VP, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }
-PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
+PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []), "dove_comm_destroy": (None, [C.c_void_p]),
          "dove_conv_gn_partial_rows": (C.c_longlong, [C.POINTER(ConvDesc)]),
          "dove_conv_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 5
+#define DOVE_ABI_VERSION 6
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -208,6 +208,24 @@ typedef struct dove_model_config {
  * NULL = computed inside (host libm + upload, cached per shape / timestep) */
 typedef struct dove_dit_aux { const float* rope_cos; const float* rope_sin; const float* timestep_proj; } dove_dit_aux;
 int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
+/* ---- one clip on several GPUs: halo-exact VAE ----
+ * One context per rank (process or thread, one GPU each).  With a communicator set, dove_vae_encode / dove_vae_decode run only
+ * THIS rank's contiguous group of frame-batches (diffusers' num_sample_frames_batch_size / num_latent_frames_batch_size batching;
+ * at most as many ranks as batches do work): every CogVideoXCausalConv3d of the rank's first batch receives its conv_cache (the
+ * last kt-1 input frames the previous batch would have left) from rank-1, and sends its own to rank+1 after the rank's last
+ * batch - point-to-point, in layer order, on the caller's stream.  Results are bit-identical to the single-GPU call.  Only the
+ * frames dove_shard_frames reports are written to the output buffer; gathering them is the caller's (an all-gather of
+ * [channels][own frames][H][W] pieces).  dove_dit_forward is not sharded at this level and dove_sr_clip refuses a multi-rank
+ * context (the Python host shards the DiT by sequence / heads, dove_amd.dist).
+ * dove_comm_init: RCCL transport (librccl opened at run time; the 128-byte id from dove_comm_unique_id on rank 0, distributed by
+ * the host).  dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`, ordered on `stream`. */
+typedef int (*dove_xfer_fn)(void* user, int peer, void* dev_ptr, size_t bytes, void* stream);
+int dove_comm_unique_id(void* out128);
+int dove_comm_init(dove_ctx* ctx, const void* nccl_unique_id, int rank, int nranks);
+int dove_comm_init_custom(dove_ctx* ctx, int rank, int nranks, dove_xfer_fn send, dove_xfer_fn recv, void* user);
+void dove_comm_destroy(dove_ctx* ctx);
+/* stage 0 = dove_vae_encode (n = pixel frames F -> latent frames), stage 1 = dove_vae_decode (n = latent frames T -> pixel frames) */
+int dove_shard_frames(dove_ctx* ctx, int stage, int n, int* first, int* count);
 void dove_destroy(dove_ctx* ctx);
 int dove_set_weight(dove_ctx* ctx, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype);
 int dove_finalize_weights(dove_ctx* ctx);

@@ -116,3 +116,94 @@ def test_sr_clip_full_size_timing():
     a = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)[0]
     b = ctx.sr_clip(video[0], noise[0], text, 399, sa, s1, rope=rope, timestep_proj=tp)
     assert torch.equal(a, b), "full-size clip: the C graph and the Python facade disagree"
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+def test_vae_sharded_halo_exchange_c_level(both, R):
+    """dove_comm_init_custom: R contexts on ONE GPU play the ranks of one clip, the transport is an in-process mailbox (send = copy
+    into a queued buffer, recv = copy out of it).  Halos only flow rank -> rank + 1, so running the ranks one after the other
+    satisfies every receive.  Gathered frames must equal the single-context result bit for bit (encode: 33 frames = 4 batches,
+    decode: 9 latent frames = 4 batches; with R = 3 one rank owns two batches)."""
+    import ctypes as C
+    pipe, ctx0, (v, t, s) = both
+    seed = 31
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
+    wt = weights.random_state_dict(weights.dit_param_shapes(t), seed)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    box = {}                                                   # (src, dst) -> list of uint8 tensors in send order
+    log = []
+
+    def make(rank):
+        def send(peer, p, n, st):
+            buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+            assert hip.hipMemcpyAsync(buf.data_ptr(), p, n, 3, st) == 0
+            box.setdefault((rank, peer), []).append(buf)
+            log.append((rank, peer, n))
+            return 0
+
+        def recv(peer, p, n, st):
+            q = box.get((peer, rank))
+            if not q:
+                return -1                                       # nothing was sent: the layer orders of the two ranks diverged
+            buf = q.pop(0)
+            if buf.numel() != n:
+                return -2
+            assert hip.hipMemcpyAsync(p, buf.data_ptr(), n, 3, st) == 0
+            return 0
+        return send, recv
+
+    g = torch.Generator().manual_seed(100 + R)
+    F, H, W = 33, 48, 64
+    video = (torch.rand(3, F, H, W, generator=g) * 2 - 1).to(BF).cuda()
+    z = torch.randn(16, 9, H // 8, W // 8, generator=g).to(BF).cuda()
+    m_ref = ctx0.vae_encode(video)
+    d_ref = ctx0.vae_decode(z, prescale=1 / 0.7, range01=True)
+    torch.cuda.synchronize()
+    ranks = []
+    for r in range(R):
+        c = GraphContext(v, t, wv, wt, "cuda")
+        c.comm_init_custom(r, R, *make(r))
+        ranks.append(c)
+    m = torch.full_like(m_ref, float("nan"))
+    d = torch.full_like(d_ref, float("nan"))
+    covered_m, covered_d = 0, 0
+    for r, c in enumerate(ranks):                               # rank order = dependency order
+        first, count = c.shard_frames(0, F)
+        out = c.vae_encode(video, out=torch.full_like(m_ref, float("nan")))
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(out[:, :first].float()).all()) and bool(torch.isnan(out[:, first + count:].float()).all())   # other ranks' frames untouched
+        m[:, first:first + count] = out[:, first:first + count]
+        covered_m += count
+    assert covered_m == m_ref.shape[1] and torch.equal(m, m_ref), "sharded encode differs"
+    n_enc_msgs = len(log)
+    for r, c in enumerate(ranks):
+        first, count = c.shard_frames(1, 9)
+        out = c.vae_decode(z, prescale=1 / 0.7, range01=True, out=torch.full_like(d_ref, float("nan")))
+        torch.cuda.synchronize()
+        d[:, first:first + count] = out[:, first:first + count]
+        covered_d += count
+    assert covered_d == d_ref.shape[1] and torch.equal(d, d_ref), "sharded decode differs"
+    assert all(not q for q in box.values()), "unconsumed halo messages"
+    assert n_enc_msgs > 0 and len(log) > n_enc_msgs and all(dst == src + 1 for src, dst, _ in log)
+    with pytest.raises(RuntimeError):                           # the fused call is single-rank only
+        ranks[0].sr_clip(video, torch.zeros(16, 9, H // 8, W // 8, device="cuda"), torch.zeros(226, 4096, dtype=BF, device="cuda"), 399, 0.6, 0.8)
+    for c in ranks:
+        c.comm_destroy()
+
+
+def test_comm_init_rccl_single_rank(both):
+    """The RCCL transport binding (librccl opened at run time, ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy) on the one GPU a
+    test box has: a 1-rank communicator must come up, leave the stages unchanged and go away again."""
+    pipe, ctx0, (v, t, s) = both
+    g = torch.Generator().manual_seed(5)
+    video = (torch.rand(3, 17, 32, 48, generator=g) * 2 - 1).to(BF).cuda()
+    ref = ctx0.vae_encode(video)
+    uid = GraphContext.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx0.comm_init_rccl(uid, 0, 1)
+    assert ctx0.shard_frames(0, 17) == (0, 5)
+    got = ctx0.vae_encode(video)
+    torch.cuda.synchronize()
+    ctx0.comm_destroy()
+    assert torch.equal(got, ref)
