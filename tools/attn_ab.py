@@ -15,13 +15,15 @@ from dove_amd import lib as L, ops  # noqa: E402
 exp = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn_exp.so"))
 exp.attn_exp.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p]
 exp.attn_exp2.argtypes = exp.attn_exp.argtypes
+pipe = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn_pipe_exp.so"))      # variants 30+: software-pipelined kernel
+pipe.attn_exp3.argtypes = exp.attn_exp.argtypes
 BF = torch.bfloat16
 
 
 def run(variant, Q, K, V, N, npad, heads, out):
     if variant < 0:
         return ops.attention(Q, K, V, N, npad, heads, out)
-    fn = exp.attn_exp2 if variant >= 20 else exp.attn_exp
+    fn = pipe.attn_exp3 if variant >= 30 else (exp.attn_exp2 if variant >= 20 else exp.attn_exp)
     rc = fn(variant, Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
     assert rc == 0, rc
     return out
