@@ -174,9 +174,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         const uint32_t a1 = pack_bf2(st[kb][b + 2], st[kb][b + 3]);
         const uint32_t b0 = pack_bf2(st[kb][b + 4], st[kb][b + 5]);
         const uint32_t b1 = pack_bf2(st[kb][b + 6], st[kb][b + 7]);
-        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        pf[kb][k2] = make_frag(r0[0], r1[0], r0[1], r1[1]);
+        // The QK^T MFMA leaves lane half hi with keys {0-3, 8-11} + 4 hi of these 16; the PV contraction runs over the keys, so
+        // their order is free as long as V^T uses the same one: dove_qkv_post_bf16 (v_order 1) stores every 16 keys as
+        // [0-3, 8-11, 4-7, 12-15] and the lane's own eight probabilities ARE its half of the B operand - no exchange between the
+        // lane halves (was: 2 v_permlane32_swap per fragment, 72 issue cycles per tile).
+        pf[kb][k2] = make_frag(a0, a1, b0, b1);
       }
     // ---- O^T[d][q] += V^T P^T ----
 #pragma unroll

@@ -1005,7 +1005,7 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
     CHK(dove_layernorm_modulate_bf16(hs, n1, N, D, cf.dit_norm_eps, b.ln1_g, b.ln1_b, b.m1, L, stream));
     bf16_t* qkv;
     CHK(linear(c, n1, N, b.qkv, ConvOpt(), &qkv, stream));
-    CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, stream));
+    CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, /*v_order=*/1, stream));
     c->arena.release(qkv);
     CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, stream));      // attention output reuses n1
     o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g1; o.gate_split = L; o.out = hs;

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ bk, const float* __restrict__ cosT,
                                                        const float* __restrict__ sinT, float qscale, float eps,
                                                        bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh,
-                                                       bf16_t* __restrict__ Vt) {
+                                                       bf16_t* __restrict__ Vt, int v_swap) {
   __shared__ float vt[4][64][65];   // V transpose staging, one slice per wave (row stride 65: conflict-free both ways)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = blockIdx.y;
@@ -433,8 +433,11 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float o[8];
+      // natural: slots 8j .. 8j+7 hold keys 8j .. 8j+7; quad-swapped (what dove_attention_fwd_bf16 reads): every 16 keys are stored
+      // [0-3, 8-11, 4-7, 12-15] so that a 16-byte V^T fragment holds the keys the QK^T MFMA left in the same lane half
+      const int g16 = (j >> 1) * 16, odd = (j & 1) * 4;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = vt[wave][j * 8 + e][lane];
+      for (int e = 0; e < 8; ++e) o[e] = v_swap ? vt[wave][g16 + odd + (e & 3) + (e >> 2) * 8][lane] : vt[wave][j * 8 + e][lane];
       if (n0 + j * 8 + 8 <= Npad) *(uint4*)(dst + j * 8) = pack8(o);
     }
     return;
@@ -486,16 +489,33 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict_
 extern "C" int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
                                    const float* gq, const float* bq, const float* gk, const float* bk,
                                    const float* cosT, const float* sinT, float qscale, float eps, void* Qh, void* Kh,
-                                   void* Vt, void* stream) {
+                                   void* Vt, int v_order, void* stream) {
   DOVE_CHECK_ARG(qkv && Qh && Kh && Vt && gq && bq && gk && bk, "qkv_post: null pointer");
   DOVE_CHECK_ARG(head_dim == 64, "qkv_post: head_dim must be 64 (got %d)", head_dim);
   // Npad is only the row stride of the head-major outputs here (the attention kernel is what wants a multiple of 128);
   // dove_amd.dist packs rank-local rows with Npad == N so a head group is one contiguous all-to-all chunk
   DOVE_CHECK_ARG(N > 0 && Npad >= N, "qkv_post: Npad must be >= N");
   DOVE_CHECK_ARG((cosT == nullptr) == (sinT == nullptr), "qkv_post: cos/sin must both be given or both be null");
+  DOVE_CHECK_ARG(v_order == 0 || (v_order == 1 && Npad % 16 == 0), "qkv_post: v_order 1 (quad-swapped V^T) needs Npad %% 16 == 0");
   dim3 grid((unsigned)((N + 255) / 256), heads, 3);
   hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
-                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh, (bf16_t*)Vt);
+                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh, (bf16_t*)Vt, v_order);
   DOVE_CHECK_LAUNCH("dove_qkv_post_bf16");
+  return DOVE_OK;
+}
+
+// natural <-> quad-swapped key order of V^T rows, in place (an involution): every 32-byte group [q0 q1 q2 q3] -> [q0 q2 q1 q3]
+__global__ __launch_bounds__(256) void vt_quad_swap_kernel(uint4* __restrict__ vt, long long ngroups) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const uint4 a = vt[2 * g], b = vt[2 * g + 1];
+  vt[2 * g] = uint4{a.x, a.y, b.x, b.y};
+  vt[2 * g + 1] = uint4{a.z, a.w, b.z, b.w};
+}
+extern "C" int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, void* stream) {
+  DOVE_CHECK_ARG(Vt && rows > 0 && Npad > 0 && Npad % 16 == 0, "vt_quad_swap: Npad must be a positive multiple of 16");
+  const long long ng = rows * (Npad / 16);
+  hipLaunchKernelGGL(vt_quad_swap_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)Vt, ng);
+  DOVE_CHECK_LAUNCH("dove_vt_quad_swap_bf16");
   return DOVE_OK;
 }

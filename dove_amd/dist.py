@@ -460,13 +460,16 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
         n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], tr.eps, md["m1"], lt_loc)
         qkv = ops.linear(n1, blk["qkv"])
         ops.qkv_post(qkv, nloc, nloc, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
-                     qscale, 1e-6, Ql, Kl, Vl)
+                     qscale, 1e-6, Ql, Kl, Vl, v_order=0)        # natural key order: the pieces are assembled below
         a2a(rq, Ql.view(-1), blk_in, blk_out)
         a2a(rk, Kl.view(-1), blk_in, blk_out)
         a2a(rv, Vl.view(-1), blk_in, blk_out)
         place(Qh, rq, False)
         place(Kh, rk, False)
         place(Vt, rv, True)
+        if npad > N:
+            Vt[:, :, N:].zero_()                                   # the previous layer's swap left tail keys in the pad
+        ops.vt_quad_swap(Vt)                                       # the key order the attention kernel reads
         ops.attention(Qh, Kh, Vt, N, npad, hloc, att)
         # heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
         a2a(back, att.view(-1), blk_out, blk_in)

@@ -266,11 +266,21 @@ def layernorm_modulate(x, gamma, beta, eps, mod=None, split=0, out=None):
     return out
 
 
-def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt):
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1):
+    """``v_order=1``: V^T rows in the quad-swapped key order ``attention`` reads (include/dove_hip.h); 0 = natural (pieces that
+    are assembled later and converted with ``vt_quad_swap``)."""
     L.require_cuda(qkv, gq, bq, gk, bk, cos, sin, Qh, Kh, Vt)
     L.check(L.load().dove_qkv_post_bf16(L.ptr(qkv), N, Npad, heads, 64, text_len, L.ptr(gq), L.ptr(bq), L.ptr(gk), L.ptr(bk),
-                                        L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt),
+                                        L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), v_order,
                                         L.stream_ptr()), "dove_qkv_post_bf16")
+
+
+def vt_quad_swap(Vt):
+    """[..., 64, Npad] V^T rows: natural <-> quad-swapped key order, in place."""
+    L.require_cuda(Vt)
+    assert Vt.is_contiguous()
+    L.check(L.load().dove_vt_quad_swap_bf16(L.ptr(Vt), Vt.numel() // Vt.shape[-1], Vt.shape[-1], L.stream_ptr()), "dove_vt_quad_swap_bf16")
+    return Vt
 
 
 def attention(Qh, Kh, Vt, N, Npad, heads, out):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 6
+#define DOVE_ABI_VERSION 7
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -104,13 +104,18 @@ int dove_layernorm_modulate_bf16(const void* x, void* y, long long rows, int D, 
 
 /* Attention pre-processing of the fused QKV projection [N, 3*heads*64]: per-head LayerNorm(64) on q,k
  * (attn1.norm_q / norm_k), interleaved-pair RoPE on rows >= text_len (apply_rotary_emb), q *= qscale,
- * head-major outputs Qh,Kh [heads][Npad][64] and Vt [heads][64][Npad] (pad must be pre-zeroed). */
+ * head-major outputs Qh,Kh [heads][Npad][64] and Vt [heads][64][Npad] (pad must be pre-zeroed).
+ * v_order: key order of the Vt rows.  0 = natural.  1 = quad-swapped, what dove_attention_fwd_bf16 reads (Npad % 16 == 0): every
+ * 16 consecutive keys are stored [0-3, 8-11, 4-7, 12-15] - the order in which the QK^T MFMA leaves the probabilities in a lane,
+ * so that P needs no cross-lane exchange before the PV MFMA.  dove_vt_quad_swap_bf16 converts rows [rows][Npad] between the two
+ * orders in place (an involution; for hosts that assemble Vt from natural-order pieces, e.g. after an all-to-all). */
 int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
                        const float* gq, const float* bq, const float* gk, const float* bk, const float* cosT,
-                       const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, void* stream);
+                       const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, int v_order, void* stream);
+int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, void* stream);
 
-/* F.scaled_dot_product_attention (no mask, non-causal) on the operands above; Qh carries scale*log2(e).
- * O [N][ldo] token-major, head h at columns [64h, 64h+64). */
+/* F.scaled_dot_product_attention (no mask, non-causal) on the operands above, Vt in QUAD-SWAPPED key order; Qh carries
+ * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64). */
 int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
                             int heads, int head_dim, long long ldo, void* stream);
 

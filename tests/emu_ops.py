@@ -185,7 +185,19 @@ def layernorm_modulate(x, gamma, beta, eps, mod=None, split=0, out=None):
     return y
 
 
-def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt):
+def _quad_swap_index(npad):
+    """position s of a V^T row holds key _quad_swap_index[s]: every 16 keys stored [0-3, 8-11, 4-7, 12-15] (an involution)."""
+    idx = torch.arange(npad)
+    q = (idx >> 2) & 3
+    return idx + 4 * (q == 1).long() - 4 * (q == 2).long()
+
+
+def vt_quad_swap(Vt):
+    Vt.copy_(Vt[..., _quad_swap_index(Vt.shape[-1])])
+    return Vt
+
+
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1):
     D = heads * 64
     q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64) for i in range(3))
     q = F.layer_norm(q, (64,), gq.float(), bq.float(), eps)
@@ -202,10 +214,15 @@ def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, ep
     Qh[:, :N] = (q * qscale).permute(1, 0, 2).to(BF)
     Kh[:, :N] = k.permute(1, 0, 2).to(BF)
     Vt[:, :, :N] = v.permute(1, 2, 0).to(BF)
+    if v_order == 1:
+        assert Vt.shape[-1] % 16 == 0
+        Vt[:, :, N:] = 0                                                # the swap moves tail keys into [N, Npad): keep the pad defined
+        vt_quad_swap(Vt)
 
 
 def attention(Qh, Kh, Vt, N, Npad, heads, out):
-    q, k, v = Qh.float()[:, :N], Kh.float()[:, :N], Vt.float()[:, :, :N]
+    """Vt in the quad-swapped key order (dove_attention_fwd_bf16's contract)."""
+    q, k, v = Qh.float()[:, :N], Kh.float()[:, :N], Vt.float()[:, :, _quad_swap_index(Vt.shape[-1])][:, :, :N]
     s = torch.einsum("hqd,hkd->hqk", q, k) * math.log(2.0)       # Qh carries scale*log2(e)
     p = torch.softmax(s, dim=-1)
     o = torch.einsum("hqk,hdk->hqd", p, v)                        # [H, N, 64]
@@ -412,7 +429,7 @@ def attention_bias(qkv, bias, heads):
     return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
 
 
-ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "qkv_post_mx", "attention_mx",
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "qkv_post_mx", "attention_mx",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

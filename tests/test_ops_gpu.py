@@ -361,6 +361,7 @@ def test_attention_spiked_rows():
     V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
     K[:, 400] = (Q[:, 7].float() * 40).to(BF)      # huge score for query 7 at key 400 (7th KV tile)
     K[:, 3] = (Q[:, 300].float() * 30).to(BF)      # and an early spike for query 300
+    E.vt_quad_swap(V)                              # the attention contract: V^T rows in the quad-swapped key order
     ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
     torch.cuda.synchronize()
@@ -442,14 +443,17 @@ def test_attention_fullsize_properties():
     out = lambda: torch.zeros(N, heads * 64, dtype=BF, device="cuda")   # noqa: E731
     ones = torch.zeros_like(Vt)
     ones[:, :, :N] = 1.0
+    ops.vt_quad_swap(ones)                         # natural -> the quad-swapped key order the kernel reads
+    ops.vt_quad_swap(Vt)
     o1 = ops.attention(Qh, Kh, ones, N, npad, heads, out())
     assert float((o1.float() - 1.0).abs().max()) <= 2 ** -7
     a = ops.attention(Qh, Kh, Vt, N, npad, heads, out())
     b = ops.attention(Qh, Kh, (Vt.float() * 2).to(BF), N, npad, heads, out())
     assert torch.equal((a.float() * 2).to(BF), b)
-    Kp, Vp = Kh.clone(), Vt.clone()
+    Kp, Vp = Kh.clone(), ops.vt_quad_swap(Vt.clone())          # Vp back in natural order
     Kp[:, N:] = 7.0
-    Vp[:, :, N:] = 1e4
+    Vp[:, :, N:] = 1e4                                          # poison every key >= N ...
+    ops.vt_quad_swap(Vp)                                        # ... wherever the swapped order puts it
     c = ops.attention(Qh, Kp, Vp, N, npad, heads, out())
     torch.cuda.synchronize()
     assert torch.equal(a, c)

@@ -21,8 +21,8 @@ BF = torch.bfloat16
 
 
 def run(variant, Q, K, V, N, npad, heads, out):
-    if variant < 0:
-        return ops.attention(Q, K, V, N, npad, heads, out)
+    if variant < 0:                                # the product kernel reads V^T in the quad-swapped key order
+        return ops.attention(Q, K, ops.vt_quad_swap(V.clone()), N, npad, heads, out)
     fn = pipe.attn_exp3 if variant >= 30 else (exp.attn_exp2 if variant >= 20 else exp.attn_exp)
     rc = fn(variant, Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
     assert rc == 0, rc
