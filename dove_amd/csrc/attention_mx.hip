@@ -7,7 +7,8 @@
 //   Q8 [H][Npad][64] e4m3 of q * qscale * 8, fixed block scale 2^-3;  K8 [H][Npad][64] e4m3 of k, fixed scale 2^0
 //     (q and k are LayerNorm(64) outputs: their dynamic range is a few binades by construction, e4m3's relative precision does
 //      not need a data-dependent scale there - and constant scales cost no loads in the kernel);
-//   V8t [H][64][Npad] e4m3 with ONE E8M0 scale per (d row, 32 consecutive keys) - OCP MX along the contraction dimension -
+//   V8t [H][64][Npad] e4m3 with ONE E8M0 scale per (d row, 32 consecutive keys) - OCP MX along the contraction dimension; inside a
+//     32-key block the keys are stored quad-wise as [0,2,4,6,1,3,5,7] (the order the QK^T MFMA leaves P in, so P needs no permute) -
 //     Vs [H][Npad/64][64][2] bytes (tile, d, 32-key block);
 //   P is quantised in registers per (query, 64-key tile): p' = 2^(s - m - e), e = ceil(max_tile(s - m)) - 8, so the tile's
 //     largest probability lands in (128, 256] and the E8M0 scale 2^e restores it inside the MFMA.  A scale per tile (not one
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(256) void qkv_post_mx_kernel(const bf16_t* __restri
       u32x4 o[2];
 #pragma unroll
       for (int q4 = 0; q4 < 8; ++q4) {
-        const float* p = v + b * 32 + q4 * 4;
+        // stored quad q4 of the 32-key block holds key quad (q4 & 3) * 2 + (q4 >> 2): the order in which the QK^T MFMA leaves the
+        // probabilities in a lane (keys 8i + 4h + j in register i of lane half h), so that P needs no cross-lane exchange
+        const float* p = v + b * 32 + ((q4 & 3) * 2 + (q4 >> 2)) * 4;
         o[q4 >> 2][q4 & 3] = pack4_fp8(p[0] * inv, p[1] * inv, p[2] * inv, p[3] * inv);
       }
       *(u32x4*)(dst + b * 32) = o[0];
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mx_kernel(const unsigned 
         ps += p;
       }
     lsum += ps;
-    // P^T as the B operand: keys 16h..16h+15 of each 32-key block, i.e. this lane's rows plus its half-partner's (see header)
+    // P^T as the B operand: slot 16h + 4i + j of each 32-key block = this lane's register i = key 8i + 4h + j; V8t stores its keys in
+    // that order (qkv_post_mx), the contraction does not care
     v8i pf;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -300,9 +304,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mx_kernel(const unsigned 
       unsigned w1 = pack4_fp8_scaled(st[kb][4], st[kb][5], st[kb][6], st[kb][7], pscale);
       unsigned w2 = pack4_fp8_scaled(st[kb][8], st[kb][9], st[kb][10], st[kb][11], pscale);
       unsigned w3 = pack4_fp8_scaled(st[kb][12], st[kb][13], st[kb][14], st[kb][15], pscale);
-      const auto a = __builtin_amdgcn_permlane32_swap(w0, w2, false, false);      // (w0', w2')
-      const auto b = __builtin_amdgcn_permlane32_swap(w1, w3, false, false);      // (w1', w3')
-      pf[kb * 4 + 0] = (int)a[0]; pf[kb * 4 + 1] = (int)a[1]; pf[kb * 4 + 2] = (int)b[0]; pf[kb * 4 + 3] = (int)b[1];
+      pf[kb * 4 + 0] = (int)w0; pf[kb * 4 + 1] = (int)w1; pf[kb * 4 + 2] = (int)w2; pf[kb * 4 + 3] = (int)w3;
     }
     // ---- O^T[d][q] += V^T P^T : one MX MFMA per 32-row block of d covers the 64 keys ----
 #pragma unroll

@@ -230,6 +230,18 @@ def attention(Qh, Kh, Vt, N, Npad, heads, out):
     return out
 
 
+def _v8_store_index(npad):
+    """position p of a V8t row holds key _v8_store_index[p]: inside every 32-key block the quads are stored [0,2,4,6,1,3,5,7]."""
+    idx = torch.arange(npad)
+    qs = (idx >> 2) & 7
+    return (idx & ~31) | (((qs & 3) * 2 + (qs >> 2)) << 2) | (idx & 3)
+
+
+def v8_store_order(x):
+    """natural key order -> the stored order of dove_qkv_post_mxfp8 (last dim = keys)."""
+    return x[..., _v8_store_index(x.shape[-1])]
+
+
 def qkv_post_mx(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Q8, K8, V8t, Vs):
     """dove_qkv_post_mxfp8: same pre-processing, e4m3 outputs (uint8 views); V in MXFP8 along the keys (32-key blocks per d row)."""
     Qf = torch.zeros(heads, Npad, 64)
@@ -254,7 +266,7 @@ def qkv_post_mx(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale,
     Q8.copy_(Qf.to(torch.float8_e4m3fn).view(torch.uint8))
     K8.copy_(Kf.to(torch.float8_e4m3fn).view(torch.uint8))
     vq, ve = mx_quant_ref(Vf.reshape(heads * 64, Npad))                  # blocks of 32 consecutive keys
-    V8t.copy_(vq.view(torch.uint8).reshape(heads, 64, Npad))
+    V8t.copy_(v8_store_order(vq.view(torch.uint8).reshape(heads, 64, Npad)))
     Vs.copy_(ve.reshape(heads, 64, Npad // 64, 2).permute(0, 2, 1, 3))
 
 
@@ -266,7 +278,10 @@ def attention_mx(Q8, K8, V8t, Vs, N, Npad, heads, out, thr=6.0):
     q[:, :N] = Q8.view(torch.float8_e4m3fn).float()[:, :N] * 0.125
     k = K8.view(torch.float8_e4m3fn).float()
     ve = Vs.permute(0, 2, 1, 3).reshape(heads * 64, Npad // 32)
-    v = mx_dequant(V8t.view(torch.float8_e4m3fn).reshape(heads * 64, Npad), ve).reshape(heads, 64, Npad)
+    inv = torch.empty(Npad, dtype=torch.long)
+    inv[_v8_store_index(Npad)] = torch.arange(Npad)                      # natural key k sits at stored position inv[k]
+    v8 = V8t[..., inv].contiguous()
+    v = mx_dequant(v8.view(torch.float8_e4m3fn).reshape(heads * 64, Npad), ve).reshape(heads, 64, Npad)
     m = torch.zeros(heads, Npad)
     l = torch.zeros(heads, Npad)
     o = torch.zeros(heads, Npad, 64)

@@ -331,7 +331,7 @@ def test_attention_mx_spike_and_flat_tail():
     vp = torch.zeros(heads * 64, npad)
     vp[:, :N] = v.reshape(heads * 64, N)
     vq, ve = E.mx_quant_ref(vp)
-    V8.copy_(vq.view(torch.uint8).reshape(heads, 64, npad))
+    V8.copy_(E.v8_store_order(vq.view(torch.uint8).reshape(heads, 64, npad)))    # the kernel's key order inside a 32-key block
     Vs.copy_(ve.reshape(heads, 64, npad // 64, 2).permute(0, 2, 1, 3))
     ref = E.attention_mx(Q8, K8, V8, Vs, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
     got = ops.attention_mx(Q8.cuda(), K8.cuda(), V8.cuda(), Vs.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
