@@ -32,6 +32,7 @@ def main(argv=None):
     ap.add_argument("--chunk_len", type=int, default=0)
     ap.add_argument("--overlap_t", type=int, default=8)
     ap.add_argument("--eval_psnr_dir", type=str, default=None)
+    ap.add_argument("--num_layers", type=int, default=None, help="debug (with --random_init): fewer DiT layers than the 42 of CogVideoX1.5-5B")
     ap.add_argument("--prompt_embedding", type=str,
                     default="pretrained_models/prompt_embeddings/e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855.safetensors")
     args = ap.parse_args(argv)
@@ -48,9 +49,13 @@ def main(argv=None):
     torch.manual_seed(args.seed)
     emb = load_file(args.prompt_embedding)["prompt_embedding"] if os.path.exists(args.prompt_embedding) else None
     if emb is None:
-        raise FileNotFoundError(f"empty-prompt embedding not found at {args.prompt_embedding} (the T5 path is not accelerated)")
+        raise FileNotFoundError(f"empty-prompt embedding not found at {args.prompt_embedding} (the reference ships it; ref :668-676)")
     if args.random_init or not args.model_path:
-        pipe = CogVideoXPipeline.from_config(device="cuda", init_device="cuda")
+        from . import config
+        v, t, s = config.default_configs()
+        if args.num_layers:
+            t["num_layers"] = args.num_layers
+        pipe = CogVideoXPipeline.from_config(v, t, s, device="cuda", init_device="cuda")
     else:
         pipe = CogVideoXPipeline.from_pretrained(args.model_path, torch_dtype=torch.bfloat16)
     pipe.scheduler = CogVideoXDPMScheduler.from_config(pipe.scheduler.config, timestep_spacing="trailing")

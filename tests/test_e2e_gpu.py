@@ -350,3 +350,23 @@ def test_long_clip_chunked_tiled_configs3(golden_dir):
     gen = torch.Generator(device="cuda").manual_seed(5)
     untiled = process_video(pipe, video[:, :, :33], empty_prompt_embedding=text, generator=gen).float().cpu()
     assert not torch.equal(untiled, piece), "enable_tiling() had no effect at 1088x1920"
+
+
+def test_cli_random_init_npy_and_png(golden_dir, tmp_path):
+    """python -m dove_amd.cli with the reference's flags (ref :506-778) on a tiny .npy clip: pad to 8N+1 frames / multiples of 16,
+    x4 upscale, one process_video, un-pad, uint8 frames out (.npy and --png_save), coverage check inside."""
+    import numpy as np
+
+    from dove_amd import cli
+    inp, out = tmp_path / "in", tmp_path / "out"
+    inp.mkdir()
+    rng = np.random.default_rng(0)
+    clip = rng.integers(0, 256, size=(7, 20, 28, 3), dtype=np.uint8)            # 7 frames -> padded to 9; 80x112 -> 80x112 (x4)
+    np.save(inp / "clip0.npy", clip)
+    emb = os.path.join(golden_dir, "empty_prompt_embedding.safetensors")
+    common = ["--input_dir", str(inp), "--random_init", "--num_layers", "2", "--prompt_embedding", emb]
+    cli.main(common + ["--output_path", str(out)])
+    res = np.load(out / "clip0.npy")
+    assert res.shape == (7, 80, 112, 3) and res.dtype == np.uint8 and res.std() > 0
+    cli.main(common + ["--output_path", str(out), "--png_save"])
+    assert len(list((out / "clip0").glob("*.png"))) == 7
