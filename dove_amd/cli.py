@@ -1,7 +1,7 @@
 """Command-line driver mirroring the reference's ``python inference_script.py ...`` (ref :506-778) on the HIP path.
 
-Same flags where they apply (``--input_dir --model_path --output_path --dtype --seed --upscale --noise_step
---sr_noise_step --is_vae_st --png_save --tile_size_hw --overlap_hw --chunk_len --overlap_t``); inputs are PNG folders
+Same flags where they apply (``--input_dir --input_json --model_path --lora_path --output_path --dtype --seed --upscale
+--noise_step --sr_noise_step --is_vae_st --png_save --tile_size_hw --overlap_hw --chunk_len --overlap_t``); inputs are PNG folders
 or ``.npy`` clips (uint8 [F,H,W,3]) because H.264 decoding (decord) is outside the accelerated path; outputs are PNG
 folders or ``.npy``.  ``--random_init`` builds the CogVideoX1.5-5B architecture with synthetic weights (no checkpoint is
 available offline).  Metrics (pyiqa) are not provided; ``--eval_psnr_dir`` computes plain PSNR (10*log10(1/MSE), per-frame
@@ -17,7 +17,9 @@ import torch
 def main(argv=None):
     ap = argparse.ArgumentParser(description="VSR using DOVE on MI355X (dove_amd)")
     ap.add_argument("--input_dir", type=str, required=True)
+    ap.add_argument("--input_json", type=str, default=None, help="{clip name: prompt}; clips without an entry use the empty prompt (ref :590-594, :676)")
     ap.add_argument("--model_path", type=str, default=None)
+    ap.add_argument("--lora_path", type=str, default=None, help="LoRA weights to fuse into the transformer (ref :613-621)")
     ap.add_argument("--random_init", action="store_true")
     ap.add_argument("--output_path", type=str, default="./results")
     ap.add_argument("--dtype", type=str, default="bfloat16")
@@ -58,6 +60,10 @@ def main(argv=None):
         pipe = CogVideoXPipeline.from_config(v, t, s, device="cuda", init_device="cuda")
     else:
         pipe = CogVideoXPipeline.from_pretrained(args.model_path, torch_dtype=torch.bfloat16)
+    if args.lora_path:
+        print(f"Loading LoRA weights from {args.lora_path}")
+        pipe.load_lora_weights(args.lora_path, weight_name="pytorch_lora_weights.safetensors", adapter_name="test_1")
+        pipe.fuse_lora(components=["transformer"], lora_scale=1.0)
     pipe.scheduler = CogVideoXDPMScheduler.from_config(pipe.scheduler.config, timestep_spacing="trailing")
     pipe.to("cuda")
     if args.is_vae_st:
@@ -69,17 +75,23 @@ def main(argv=None):
                    if n.lower().endswith(".npy") or os.path.isdir(os.path.join(args.input_dir, n)))
     if not names:
         raise ValueError(f"No clips (.npy or PNG folders) found in {args.input_dir}")
+    prompts = {}
+    if args.input_json is not None:
+        import json
+        with open(args.input_json) as f:
+            prompts = json.load(f)
     psnrs = {}
     for name in names:
+        prompt = prompts.get(name, "")
         frames = prepost.load_frames(os.path.join(args.input_dir, name))
         video, pad_f, pad_h, pad_w, orig = prepost.preprocess_frames(frames, args.upscale)
         items = tiling.plan(video.shape, args.chunk_len, overlap_t, tuple(args.tile_size_hw), tuple(args.overlap_hw))
         out = torch.zeros(video.shape, dtype=torch.bfloat16, device=video.device)
         wc = torch.zeros(video.shape, dtype=torch.int32, device=video.device)
-        print(f"Process video: {name} | Frame: {video.shape[2]} (ori: {orig[0]}; pad: {pad_f}) | Target Resolution: "
+        print(f"Process video: {name} | Prompt: {prompt} | Frame: {video.shape[2]} (ori: {orig[0]}; pad: {pad_f}) | Target Resolution: "
               f"{video.shape[3]}, {video.shape[4]} | Chunk Num: {len(items)}")
         for (t0, t1, h0, h1, w0, w1), region in items:
-            piece = process_video(pipe, video[:, :, t0:t1, h0:h1, w0:w1], noise_step=args.noise_step,
+            piece = process_video(pipe, video[:, :, t0:t1, h0:h1, w0:w1], prompt=prompt, noise_step=args.noise_step,
                                   sr_noise_step=args.sr_noise_step, empty_prompt_embedding=emb)
             tiling.stitch(out, wc, piece, region)
         tiling.check_coverage(wc)
