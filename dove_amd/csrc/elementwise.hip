@@ -70,6 +70,64 @@ extern "C" int dove_ncthw_from_cl(const void* x, long long ld, int C, long long 
   return DOVE_OK;
 }
 
+// ---- tap-split decoder.conv_out, second half: sum the 9 spatially shifted partial planes (see include/dove_hip.h) ----
+// One workgroup = 8 x 64 output pixels of one frame: the 10 x 66 partial-plane records they touch are read ONCE, coalesced, into LDS
+// (record stride ldp + 1 floats: conflict-free for the per-lane reads below), then every thread sums its 9 x C values out of LDS.
+// (A direct gather - 27 scattered 4-byte loads per pixel - ran at 0.33 TB/s.)
+__global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __restrict__ p, int ldp, int T, int H, int W, int C,
+                                                              const float* __restrict__ bias, float scale, float shift, float lo, float hi,
+                                                              void* __restrict__ y, int dt) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];
+  constexpr int TH = 8, TW = 64, RW = TW + 2, NREC = (TH + 2) * RW;
+  const int lrec = ldp + 1, f4n = ldp >> 2;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, t = blockIdx.z;
+  for (int i = threadIdx.x; i < NREC * f4n; i += 256) {
+    const int rec = i / f4n, f4 = i - rec * f4n;
+    const int ry = rec / RW, rx = rec - ry * RW;
+    const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};                                        // zero padding at the frame border
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const f32x4*)(p + (((long long)t * H + iy) * W + ix) * ldp + f4 * 4);
+    float* d = tile + rec * lrec + f4 * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 63;
+  const long long npix = (long long)T * H * W;
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    const int rr = (threadIdx.x >> 6) + 4 * h2;
+    const int oy = y0 + rr, ox = x0 + lx;
+    if (oy >= H || ox >= W) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* q = tile + ((rr + dy) * RW + lx + dx) * lrec + (dy * 3 + dx) * C;
+        for (int c = 0; c < C; ++c) acc[c] += q[c];
+      }
+    const long long pix = ((long long)t * H + oy) * W + ox;
+    for (int c = 0; c < C; ++c) {
+      const float v = bf2f(f2bf(acc[c] + (bias ? bias[c] : 0.f)));          // the conv's bf16 output rounding
+      store_any(y, (long long)c * npix + pix, dt, fminf(fmaxf(v * scale + shift, lo), hi));
+    }
+  }
+}
+extern "C" int dove_conv_out_gather(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, float scale, float shift,
+                                    float lo, float hi, void* y, int dtype, void* stream) {
+  DOVE_CHECK_ARG(p && y, "conv_out_gather: null pointer");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "conv_out_gather: bad dtype %d", dtype);
+  DOVE_CHECK_ARG(C >= 1 && C <= 4 && ldp >= 9 * C && ldp <= 36 && ldp % 4 == 0 && T > 0 && H > 0 && W > 0,
+                 "conv_out_gather: need 1 <= C <= 4 and 9 C <= ldp <= 36, ldp %% 4 == 0");
+  const int lds = 10 * 66 * ((int)ldp + 1) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)conv_out_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 66 * 37 * 4); attr = true; }
+  dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 7) / 8), (unsigned)T);
+  hipLaunchKernelGGL(conv_out_gather_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, (int)ldp, T, H, W, C, bias, scale, shift, lo, hi, y, dtype);
+  DOVE_CHECK_LAUNCH("dove_conv_out_gather");
+  return DOVE_OK;
+}
+
 // ---- Downsample3D temporal pool: odd T keeps frame 0 and averages pairs (1,2),(3,4)..; even T pairs (0,1).. ----
 __global__ void avgpool_time_kernel(const bf16_t* __restrict__ x, int T, long long frame8, bf16_t* __restrict__ y) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-element chunk within a frame

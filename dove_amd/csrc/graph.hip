@@ -58,6 +58,17 @@ __global__ void pack_weight_kernel(const void* src, int dt, int cout, int cin, i
     dst[((long long)t * cout_pad + row0 + co) * cin_pad + ci] = f2bf(v);
   }
 }
+// decoder.conv_out split by spatial tap (dove_conv_out_gather): src [C][cin][kt][3][3] -> dst [kt][32][cin_pad] bf16, row (dy*3+dx)*C + c
+__global__ void pack_taps_kernel(const void* src, int dt, int C, int cin, int kt, int cin_pad, bf16_t* dst) {
+  const long long n = (long long)kt * 9 * C * cin;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % cin);
+    long long r = i / cin;
+    const int row = (int)(r % (9 * C)), t = (int)(r / (9 * C));
+    const int c = row % C, tap = row / C;                       // tap = dy*3 + dx
+    dst[((long long)t * 32 + row) * cin_pad + ci] = f2bf(load_any(src, dt, (((long long)c * cin + ci) * kt + t) * 9 + tap));
+  }
+}
 __global__ void to_f32_kernel(const void* src, int dt, long long n, float* dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = load_any(src, dt, i);
 }
@@ -172,6 +183,7 @@ struct dove_ctx {
   std::unordered_map<std::string, Tensor> cache;        // conv_cache of the running clip (views or copies)
   std::unordered_map<std::string, void*> cache_owner;   // arena block a cache entry keeps alive (a retained conv input) or the copy itself
   float* gn_ws = nullptr;
+  float* conv_out_bias = nullptr;                       // != NULL: decoder.conv_out runs tap-split ("decoder.conv_out.taps" + gather)
   Arena arena;
   std::string err;
   // multi-GPU (dove_comm_init*): this rank's frame-batches of a clip; halos travel rank -> rank + 1 in layer order
@@ -267,7 +279,8 @@ void free_t(dove_ctx* c, Tensor& t) { c->arena.release(t.p); t.p = nullptr; }
 
 struct ConvOpt { const Tensor* cache = nullptr; int stride = 1, pad_h = -1, pad_w = -1, up = 0, tmode = 0, t_out = -1, act = 0;
                  const bf16_t* resid = nullptr; int ldr = 0; const float* gate = nullptr; long long gate_split = 0; bf16_t* out = nullptr; int ldo = -1;
-                 float gn_eps = -1.f; float** gn_stats = nullptr; };
+                 float gn_eps = -1.f; float** gn_stats = nullptr;
+                 bool out_f32 = false; };   // out_f32: the returned Tensor holds float [..][ldo] (its C counts bf16 units = 2 * ldo)
 // x [T,H,W,cin_pad] -> out (allocated unless opt.out).  When opt.gn_eps >= 0 and the kernel fuses GroupNorm statistics, *opt.gn_stats
 // receives [32][2] (mean, rstd) from the arena (caller releases); otherwise it is left NULL.
 int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tensor* out, void* stream) {
@@ -280,7 +293,7 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   const int ldo = o.ldo < 0 ? pc.cout_store() : o.ldo;
   Tensor y;
   if (o.out) { y.p = o.out; y.T = t_out; y.H = ho; y.W = wo; y.C = ldo; }
-  else CHK(alloc_t(c, t_out, ho, wo, ldo, &y));
+  else CHK(alloc_t(c, t_out, ho, wo, o.out_f32 ? 2 * ldo : ldo, &y));
   dove_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
@@ -288,6 +301,7 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
   d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
   d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;
+  d.out_f32 = o.out_f32 ? 1 : 0;
   float* partial = nullptr;
   long long rows = 0;
   if (o.gn_eps >= 0.f && o.gn_stats && ldo == pc.cout_store()) {
@@ -518,7 +532,12 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
   Tensor n;
   CHK(norm_silu(c, h, hs, "decoder.norm_out", &z, &n, stream));
   free_t(c, h);
-  CHK(cconv(c, n, true, "decoder.conv_out", ConvOpt(), out, stream));
+  if (c->conv_out_bias) {                                      // tap-split conv_out: fp32 partial planes for dove_conv_out_gather
+    ConvOpt ot; ot.out_f32 = true;
+    CHK(cconv(c, n, true, "decoder.conv_out.taps", ot, out, stream));
+  } else {
+    CHK(cconv(c, n, true, "decoder.conv_out", ConvOpt(), out, stream));
+  }
   return 0;
 }
 void clear_caches(dove_ctx* c) {
@@ -757,6 +776,21 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
     }
   }
   DOVE_CHECK_ARG(c->pc.count("encoder.conv_in") && c->pc.count("decoder.conv_out"), "dove_finalize_weights: VAE weights missing");
+  {
+    // decoder.conv_out split by spatial tap (dove_amd/vae.py _pack; include/dove_hip.h dove_conv_out_gather)
+    const Raw* w; CHK(need(c, "decoder.conv_out.conv.weight", &w, 5));
+    const int C = (int)w->shape[0], cin = (int)w->shape[1], kt = (int)w->shape[2];
+    if (w->shape[3] == 3 && w->shape[4] == 3 && 9 * C <= 32) {
+      Packed q; q.kt = kt; q.kh = 1; q.kw = 1; q.cin = cin; q.cin_pad = (cin <= 32 || cin % 64) ? (int)ru(cin, 32) : cin; q.cout = 9 * C; q.cout_pad = 32;
+      const size_t wbytes = (size_t)kt * 32 * q.cin_pad * 2;
+      void* wp; CHK(dev_alloc(c, wbytes, &wp));
+      HIPCHK(hipMemsetAsync(wp, 0, wbytes, 0));
+      hipLaunchKernelGGL(pack_taps_kernel, dim3(256), dim3(256), 0, 0, w->p, w->dt, C, cin, kt, q.cin_pad, (bf16_t*)wp);
+      q.w = (bf16_t*)wp;
+      c->pc["decoder.conv_out.taps"] = q;
+      CHK(to_f32(c, "decoder.conv_out.conv.bias", &c->conv_out_bias));
+    }
+  }
   // ---- DiT (dove_amd/transformer.py _pack) ----
   const int D = cf.dit_heads * cf.dit_head_dim;
   CHK(pack(c, {"patch_embed.proj.weight"}, {"patch_embed.proj.bias"}, &c->pe_proj));
@@ -952,8 +986,13 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
       // [C][F][H][W] output: this batch's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
       void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
       DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
-      CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
-                             range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+      if (c->conv_out_bias) {
+        CHK(dove_conv_out_gather((const float*)o.p, o.C / 2, o.T, H, W, cf.vae_out_channels, c->conv_out_bias, range01 ? 0.5f : 1.0f,
+                                 range01 ? 0.5f : 0.0f, range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+      } else {
+        CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
+                               range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+      }
       CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
                  cf.vae_out_channels, (hipStream_t)stream));
       c->arena.release(tmp);

@@ -53,6 +53,7 @@ struct IgemmArgs {
   int debug;  // -DDOVE_TIMING_BUILD only (tools/, never the product library): 1 skip A loads, 2 skip B loads, 4 skip MFMA
   float* gn_partial;   // conv3x3_halo4x only: fused GroupNorm(32) partial sums of the stored output, [rows][32][2]
   int cpg_log;         // log2(channels per group) = log2(Cout / 32)
+  int out_f32;         // igemm_fast only: `out` is float [..][ldo] (no bf16 rounding): the tap-split conv_out's partial sums
 };
 
 template <int BN, int BK>
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
         uint2 o;
         o.x = pack_bf2(v[0], v[1]);
         o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(a.out + pix * a.ldo + cb) = o;
+        if (a.out_f32) *(f32x4*)((float*)a.out + pix * a.ldo + cb) = f32x4{v[0], v[1], v[2], v[3]};
+        else *(uint2*)(a.out + pix * a.ldo + cb) = o;
       }
     }
   }
@@ -2009,6 +2011,8 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
                  "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
   const ConvKernel kern0 = select_kernel(d);
+  DOVE_CHECK_ARG(!d->out_f32 || (kern0 == K_IGEMM_FAST && !d->resid && d->act == 0),
+                 "conv_igemm: out_f32 is only implemented for plain convs that dispatch to igemm_fast_kernel");
   long long rows_main = 0;
   if (kern0 == K_GEMM4X && !d->debug_buf && gemm4x_tail_split(d, &rows_main)) {
     dove_conv_desc m = *d, t = *d;
@@ -2037,6 +2041,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
+  a.out_f32 = d->out_f32;
   a.debug = 0;
 #ifdef DOVE_TIMING_BUILD
   {

@@ -362,7 +362,13 @@ def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0, gather="al
     assert z.shape[0] == 1
     z = z.to(vae.device).contiguous()
     z_cl = ops.cl_from_ncthw(z[0], vae.pc["decoder.conv_in"].cin_pad, scale=_prescale)
-    outs, cache = _run_sharded(vae, z_cl, frame_batches(z_cl.shape[0], vae.dec_batch), world, rank, group, vae._decoder, "dec")
+    split = getattr(vae, "_conv_out_split", False)              # the single-GPU decode runs conv_out tap-split: same arithmetic here
+    dec = (lambda zb, cache: vae._decoder(zb, cache, split_out=True)) if split else vae._decoder
+    outs, cache = _run_sharded(vae, z_cl, frame_batches(z_cl.shape[0], vae.dec_batch), world, rank, group, dec, "dec")
+    if split:      # partial planes -> conv_out's bf16 output, channels-last [T,H,W,4] (the range map comes after the gather)
+        cc = vae.config["out_channels"]
+        outs = [torch.nn.functional.pad(ops.conv_out_gather(o, cc, vae.conv_out_bias, torch.bfloat16).permute(1, 2, 3, 0), (0, 4 - cc)).contiguous()
+                for o in outs]
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
     vae.last_halo_bytes = cache.bytes_sent
     if gather == "none":

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
         ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong), ("debug_buf", C.c_void_p),
-        ("gn_partial", C.c_void_p),
+        ("gn_partial", C.c_void_p), ("out_f32", C.c_int),
     ]
 
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "dove_layernorm_modulate_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP, _VP, _LL, _VP],
     "dove_qkv_post_bf16": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _I, _VP],
     "dove_vt_quad_swap_bf16": [_VP, _LL, _LL, _VP],
+    "dove_conv_out_gather": [_VP, _LL, _I, _I, _I, _I, _VP, _F, _F, _F, _F, _VP, _I, _VP],
     "dove_attention_fwd_bf16": [_VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP],
     "dove_qkv_post_mxfp8": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP, _VP],
     "dove_attention_fwd_mxfp8": [_VP, _VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP],

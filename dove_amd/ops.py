@@ -88,7 +88,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
          out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None,
-         gn_eps: float | None = None) -> torch.Tensor:
+         gn_eps: float | None = None, out_f32: bool = False) -> torch.Tensor:
     """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo].
 
     ``gn_eps``: the output feeds an nn.GroupNorm(32, C, eps) (resnet norm1/norm2, SpatialNorm's norm_layer).  When the
@@ -108,10 +108,11 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         hw_out = (H << up, W << up) if stride == 1 else ((H + 1 - pc.kh) // stride + 1, (W + 1 - pc.kw) // stride + 1)
     if ldo is None:
         ldo = pc.cout_store
+    odt = torch.float32 if out_f32 else torch.bfloat16        # out_f32: un-rounded accumulators (tap-split conv_out, conv_out_gather)
     if out is None:
-        out = torch.empty(t_out, hw_out[0], hw_out[1], ldo, dtype=torch.bfloat16, device=x.device)
+        out = torch.empty(t_out, hw_out[0], hw_out[1], ldo, dtype=odt, device=x.device)
     else:
-        assert out.shape == (t_out, hw_out[0], hw_out[1], ldo) and out.dtype == torch.bfloat16
+        assert out.shape == (t_out, hw_out[0], hw_out[1], ldo) and out.dtype == odt
     if cache is not None:
         assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
     d = L.ConvDesc()
@@ -129,6 +130,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     d.ldr = resid.shape[-1] if resid is not None else 0
     d.gate_split = gate_split
     d.debug_buf = debug_buf.data_ptr() if debug_buf is not None else None
+    d.out_f32 = int(out_f32)
     if resid is not None:
         assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
     if gate is not None:
@@ -303,6 +305,18 @@ def attention_mx(Q8, K8, V8t, Vs, N, Npad, heads, out):
     L.check(L.load().dove_attention_fwd_mxfp8(L.ptr(Q8), L.ptr(K8), L.ptr(V8t), L.ptr(Vs), L.ptr(out), N, Npad, heads, 64,
                                               out.shape[1], L.stream_ptr()), "dove_attention_fwd_mxfp8")
     return out
+
+
+def conv_out_gather(p: torch.Tensor, Cc: int, bias, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf) -> torch.Tensor:
+    """Second half of the tap-split decoder.conv_out (include/dove_hip.h dove_conv_out_gather): p [T,H,W,ld] fp32 partial planes ->
+    [Cc,T,H,W] ``dtype`` with the range map of ``ncthw_from_cl``."""
+    L.require_cuda(p, bias)
+    assert p.dtype == torch.float32 and p.dim() == 4
+    T, H, W, ld = p.shape
+    y = torch.empty(Cc, T, H, W, dtype=dtype, device=p.device)
+    L.check(L.load().dove_conv_out_gather(L.ptr(p), ld, T, H, W, Cc, L.ptr(bias), scale, shift, lo, hi, L.ptr(y), L.dt_code(y),
+                                          L.stream_ptr()), "dove_conv_out_gather")
+    return y
 
 
 def cl_from_ncthw(x: torch.Tensor, cp: int, scale=1.0, shift=0.0) -> torch.Tensor:

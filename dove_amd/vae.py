@@ -126,6 +126,16 @@ class AutoencoderKLCogVideoX:
             elif k.endswith(".weight") and sd[k].dim() == 1 and ".norm_layer." not in k:
                 n = k[: -len(".weight")]
                 self.aff[n] = (sd[k].to(dev, torch.float32).contiguous(), sd[n + ".bias"].to(dev, torch.float32).contiguous())
+        # decoder.conv_out split by spatial tap (include/dove_hip.h dove_conv_out_gather): with 3 output channels a direct 3x3x3
+        # conv pads Cout 3 -> 32 and stages every input pixel 27 times; as a (3,1,1) conv with the 9 spatial taps as 27 output
+        # channels it stages them 3 times and wastes 5 of 32 MFMA columns, the 9-tap shifted sum rides in the layout kernel
+        w = sd["decoder.conv_out.conv.weight"]                      # [Cout, Cin, 3, 3, 3]
+        co, ci, kt, kh, kw = w.shape
+        self._conv_out_split = kh == 3 and kw == 3 and 9 * co <= 32
+        if self._conv_out_split:
+            w27 = w.float().permute(3, 4, 0, 1, 2).reshape(kh * kw * co, ci, kt, 1, 1)    # row (dy*3+dx)*Cout + c
+            self.pc["decoder.conv_out.taps"] = ops.pack_conv(w27, None, dev)
+            self.conv_out_bias = sd["decoder.conv_out.conv.bias"].to(dev, torch.float32).contiguous()
 
     # ---- toggles kept for API parity (ref :644-645) ---------------------------------------------
     def enable_slicing(self):
@@ -230,7 +240,9 @@ class AutoencoderKLCogVideoX:
         h = self._norm_silu(h, "encoder.norm_out")
         return self._cconv(h, "encoder.conv_out", cache)
 
-    def _decoder(self, z, cache):
+    def _decoder(self, z, cache, split_out=False):
+        """``split_out``: return the tap-split conv_out's fp32 partial planes [T,H,W,32] for ``ops.conv_out_gather`` instead of the
+        conv_out result (untiled single-process decode only: the tile blend and the sharded gather want the real output)."""
         h = self._cconv(z, "decoder.conv_in", cache)
         for j in range(2):
             h = self._resnet(h, f"decoder.mid_block.resnets.{j}", cache, zq=z)
@@ -241,6 +253,8 @@ class AutoencoderKLCogVideoX:
             if i < nb - 1:
                 h = self._upsample(h, f"decoder.up_blocks.{i}.upsamplers.0", i < self.n_tdown)
         h = self._norm_silu(h, "decoder.norm_out", zq=z)
+        if split_out and self._conv_out_split:
+            return self._cconv(h, "decoder.conv_out.taps", cache, out_f32=True)
         return self._cconv(h, "decoder.conv_out", cache)
 
     # ---- diffusers spatial tiling (enable_tiling; SURVEY.md App. A.4, all published numbers use --is_vae_st) --------
@@ -359,7 +373,11 @@ class AutoencoderKLCogVideoX:
             if tiled:
                 vids.append(ops.ncthw_from_cl(self._tiled_decode(z_cl), cout, self.dtype, **post))
                 continue
-            outs = self._run_batches(z_cl, self.dec_batch, self._decoder, post=lambda o: ops.ncthw_from_cl(o, cout, self.dtype, **post))
+            if self._conv_out_split:
+                outs = self._run_batches(z_cl, self.dec_batch, lambda zb, cache: self._decoder(zb, cache, split_out=True),
+                                         post=lambda o: ops.conv_out_gather(o, cout, self.conv_out_bias, self.dtype, **post))
+            else:
+                outs = self._run_batches(z_cl, self.dec_batch, self._decoder, post=lambda o: ops.ncthw_from_cl(o, cout, self.dtype, **post))
             vids.append(torch.cat(outs, dim=1) if len(outs) > 1 else outs[0])
         sample = torch.stack(vids)
         return _Out(sample=sample) if return_dict else (sample,)

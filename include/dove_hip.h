@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 7
+#define DOVE_ABI_VERSION 8
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -63,6 +63,9 @@ typedef struct dove_conv_desc {
    * squares) per group over the bf16-rounded stored values; reduce with dove_groupnorm_finalize_partials.  Only the
    * kernels for which dove_conv_gn_partial_rows() > 0 produce them; anything else with gn_partial != NULL is an error. */
   float* gn_partial;
+  /* != 0: `out` is float [..][ldo] and receives the un-rounded fp32 accumulators (+ bias): partial sums another kernel finishes
+   * (dove_conv_out_gather).  Only for plain convs (no act / resid) that dispatch to igemm_fast_kernel; an error otherwise. */
+  int out_f32;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 /* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo8_kernel, conv3x3_halo4x_kernel,
@@ -124,6 +127,13 @@ int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, 
                        void* stream);
 int dove_ncthw_from_cl(const void* x, long long ld, int C, long long npix, float scale, float shift, float lo,
                        float hi, void* y, int dtype, void* stream);
+/* decoder.conv_out (128 -> 3 channels, 3x3x3) split by spatial tap: a (3,1,1) conv with 27 (padded 32) output channels
+ * P[t][y][x][(dy*3+dx)*C + c] = sum_{kt,ci} x[t+kt-2][y][x][ci] w[c][ci][kt][dy][dx] (dove_conv_igemm_bf16 with out_f32 = 1: K = 3*Cin
+ * instead of 27*Cin per staged pixel, and no 32/3 padding waste on the MFMAs) followed by this gather:
+ * y[c][t][oy][ox] = clamp(bf16(bias[c] + sum_{dy,dx} P[t][oy+dy-1][ox+dx-1][(dy*3+dx)*C + c]) * scale + shift, lo, hi), zero padding at
+ * the frame border; the bf16 rounding is the conv's own output rounding in the reference. */
+int dove_conv_out_gather(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, float scale, float shift, float lo,
+                         float hi, void* y, int dtype, void* stream);
 /* CogVideoXDownsample3D temporal average pool (odd T keeps the first frame) */
 int dove_avgpool_time_bf16(const void* x, int T, long long frame_elems, void* y, void* stream);
 /* DiagonalGaussianDistribution.sample(): out[c] = mean + exp(0.5*clamp(logvar,-30,20)) * noise  (ref :409) */

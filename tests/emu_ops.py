@@ -64,7 +64,7 @@ def _frame_index(t, tmode):
 
 
 def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, resid=None,
-         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None):
+         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None, out_f32=False):
     T, H, W, Cx = x.shape
     assert Cx == pc.cin_pad
     ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
@@ -106,10 +106,25 @@ def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=
             y = r + g * y
         else:
             y = r + y
+    odt = torch.float32 if out_f32 else BF
     if out is None:
-        out = torch.zeros(t_out, hw_out[0], hw_out[1], ldo, dtype=BF)
-    out[..., : pc.cout_store] = y.to(BF)
+        out = torch.zeros(t_out, hw_out[0], hw_out[1], ldo, dtype=odt)
+    out[..., : pc.cout_store] = y.to(odt)
     return out
+
+
+def conv_out_gather(p, Cc, bias, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf):
+    """dove_conv_out_gather: y[c][t][oy][ox] = sum over the 9 taps of p[t][oy+dy-1][ox+dx-1][(dy*3+dx)*Cc + c] (zero padded) + bias,
+    rounded to bf16 (the conv's output dtype), then the range map."""
+    T, H, W, _ = p.shape
+    pp = F.pad(p.float().permute(0, 3, 1, 2), (1, 1, 1, 1))               # [T, ld, H+2, W+2]
+    acc = torch.zeros(T, Cc, H, W)
+    for dy in range(3):
+        for dx in range(3):
+            k = (dy * 3 + dx) * Cc
+            acc += pp[:, k:k + Cc, dy:dy + H, dx:dx + W]
+    v = (acc + bias.float().view(1, Cc, 1, 1)).to(BF).float()
+    return (v * scale + shift).clamp(lo, hi).permute(1, 0, 2, 3).contiguous().to(dtype)
 
 
 def linear(x, pc, **kw):
@@ -444,7 +459,7 @@ def attention_bias(qkv, bias, heads):
     return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
 
 
-ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "qkv_post_mx", "attention_mx",
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "qkv_post_mx", "attention_mx",
        "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

@@ -141,6 +141,34 @@ LIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("T,H,W,use_cache", [(3, 20, 37, True), (2, 9, 70, False), (1, 16, 16, False)])
+def test_conv_out_tap_split(T, H, W, use_cache):
+    """decoder.conv_out as a (3,1,1) conv with the 9 spatial taps as 27 fp32 output channels + dove_conv_out_gather: same result as
+    the direct 3x3x3 conv followed by the layout kernel (fp32 sums in another order, one bf16 rounding each), incl. the frame border."""
+    cin, co = 128, 3
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(co, cin, 3, 3, 3, generator=g) * (cin * 27) ** -0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = rnd(T, H, W, cin, seed=32)
+    cache = rnd(2, H, W, cin, seed=33) if use_cache else None
+    post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0)
+    pc_c, pc_g = E.pack_conv(w, b, "cpu"), ops.pack_conv(w, b, "cuda")
+    want = E.ncthw_from_cl(E.conv(x, pc_c, cache=cache), co, torch.float32, **post)
+    direct = ops.ncthw_from_cl(ops.conv(x.cuda(), pc_g, cache=None if cache is None else cache.cuda()), co, torch.float32, **post)
+    w27 = w.permute(3, 4, 0, 1, 2).reshape(27, cin, 3, 1, 1)
+    pt_c, pt_g = E.pack_conv(w27, None, "cpu"), ops.pack_conv(w27, None, "cuda")
+    p = ops.conv(x.cuda(), pt_g, cache=None if cache is None else cache.cuda(), out_f32=True)
+    assert p.dtype == torch.float32 and p.shape == (T, H, W, 28)
+    got = ops.conv_out_gather(p, co, b.cuda(), torch.float32, **post)
+    emu = E.conv_out_gather(E.conv(x, pt_c, cache=cache, out_f32=True), co, b, torch.float32, **post)
+    torch.cuda.synchronize()
+    close("conv_out_split.vs_direct_hip", got, direct, rtol=8e-3, afrac=4e-3)
+    close("conv_out_split.vs_emu", got, emu, rtol=8e-3, afrac=4e-3)
+    close("conv_out_split.vs_direct_emu", got, want, rtol=8e-3, afrac=4e-3)
+    got_bf = ops.conv_out_gather(p, co, b.cuda(), BF)
+    assert got_bf.dtype == BF and got_bf.shape == (co, T, H, W)
+
+
 @pytest.mark.parametrize("case", LIN_CASES, ids=[c[0] for c in LIN_CASES])
 def test_linear(case):
     name, N, cin, cout, kw = case
