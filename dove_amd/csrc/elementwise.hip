@@ -43,6 +43,40 @@ extern "C" int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npi
   return DOVE_OK;
 }
 
+// ---- [C,T,H,W] -> [T,H,W,Cp] bf16 with the 3x3 spatial neighbourhood unrolled into channels: y[..][(dy*3+dx)*C + c] =
+//      x[c][t][h+dy-1][w+dx-1] (zero outside the frame), channels >= 9C zero.  encoder.conv_in (3 -> 128, 3x3x3) then runs as a
+//      (3,1,1) conv with K = 3 x 32 instead of 27 x 32 (29 of 32 input channels were padding) ----
+__global__ void cl_im2col3x3_kernel(const void* __restrict__ x, int dt, int C, int T, int H, int W, int Cp, float scale, float shift,
+                                    bf16_t* __restrict__ y) {
+  const long long npix = (long long)T * H * W;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= npix) return;
+  const int w = (int)(p % W), h = (int)((p / W) % H);
+  bf16_t* yr = y + p * Cp;
+  for (int c0 = 0; c0 < Cp; c0 += 8) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = c0 + e, tap = k / C, c = k - tap * C;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const bool in = tap < 9 && h + dy >= 0 && h + dy < H && w + dx >= 0 && w + dx < W;
+      f[e] = in ? load_any(x, (long long)c * npix + p + (long long)dy * W + dx, dt) * scale + shift : 0.f;
+    }
+    *(uint4*)(yr + c0) = pack8(f);
+  }
+}
+extern "C" int dove_cl_im2col3x3_from_ncthw(const void* x, int dtype, int C, int T, int H, int W, int Cp, float scale, float shift, void* y,
+                                            void* stream) {
+  DOVE_CHECK_ARG(x && y, "cl_im2col3x3: null pointer");
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "cl_im2col3x3: bad dtype %d", dtype);
+  DOVE_CHECK_ARG(C > 0 && Cp % 8 == 0 && Cp >= 9 * C && T > 0 && H > 0 && W > 0, "cl_im2col3x3: need Cp %% 8 == 0 and Cp >= 9 C");
+  const long long npix = (long long)T * H * W;
+  hipLaunchKernelGGL(cl_im2col3x3_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dtype, C, T, H, W, Cp,
+                     scale, shift, (bf16_t*)y);
+  DOVE_CHECK_LAUNCH("dove_cl_im2col3x3_from_ncthw");
+  return DOVE_OK;
+}
+
 // ---- [T,H,W,ld] bf16 -> [C,T,H,W] (fp32|bf16), y = clamp(x*scale + shift, lo, hi) ----
 __global__ void ncthw_from_cl_kernel(const bf16_t* __restrict__ x, long long ld, int C, long long npix, float scale,
                                      float shift, float lo, float hi, void* __restrict__ y, int dt) {

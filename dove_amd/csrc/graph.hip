@@ -69,6 +69,18 @@ __global__ void pack_taps_kernel(const void* src, int dt, int C, int cin, int kt
     dst[((long long)t * 32 + row) * cin_pad + ci] = f2bf(load_any(src, dt, (((long long)c * cin + ci) * kt + t) * 9 + tap));
   }
 }
+// encoder.conv_in with the spatial taps in the input channels (dove_cl_im2col3x3_from_ncthw): src [cout][C][kt][3][3] ->
+// dst [kt][cout_pad][cin_pad] bf16, column (dy*3+dx)*C + c
+__global__ void pack_in_taps_kernel(const void* src, int dt, int cout, int C, int kt, int cout_pad, int cin_pad, bf16_t* dst) {
+  const long long n = (long long)kt * cout * 9 * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (9 * C));
+    long long r = i / (9 * C);
+    const int co = (int)(r % cout), t = (int)(r / cout);
+    const int c = col % C, tap = col / C;
+    dst[((long long)t * cout_pad + co) * cin_pad + col] = f2bf(load_any(src, dt, (((long long)co * C + c) * kt + t) * 9 + tap));
+  }
+}
 __global__ void to_f32_kernel(const void* src, int dt, long long n, float* dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = load_any(src, dt, i);
 }
@@ -477,7 +489,7 @@ int encoder(dove_ctx* c, const Tensor& x, Tensor* out, void* stream) {
   const auto& cf = c->cfg;
   Tensor h; float* hs = nullptr;
   Tensor xin = x;
-  CHK(cconv(c, xin, false, "encoder.conv_in", ConvOpt(), &h, stream));
+  CHK(cconv(c, xin, false, c->pc.count("encoder.conv_in.taps") ? "encoder.conv_in.taps" : "encoder.conv_in", ConvOpt(), &h, stream));
   char nm[128];
   int n_tdown = 0;
   for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
@@ -777,6 +789,21 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
   }
   DOVE_CHECK_ARG(c->pc.count("encoder.conv_in") && c->pc.count("decoder.conv_out"), "dove_finalize_weights: VAE weights missing");
   {
+    // encoder.conv_in with the 3x3 spatial taps unrolled into the input channels (dove_amd/vae.py _pack)
+    const Raw* w; CHK(need(c, "encoder.conv_in.conv.weight", &w, 5));
+    const int cout = (int)w->shape[0], C = (int)w->shape[1], kt = (int)w->shape[2];
+    if (w->shape[3] == 3 && w->shape[4] == 3 && 9 * C <= 32) {
+      Packed q; q.kt = kt; q.kh = 1; q.kw = 1; q.cin = 9 * C; q.cin_pad = 32; q.cout = cout; q.cout_pad = (int)ru(cout, 32);
+      const size_t wbytes = (size_t)kt * q.cout_pad * 32 * 2;
+      void* wp; CHK(dev_alloc(c, wbytes, &wp));
+      HIPCHK(hipMemsetAsync(wp, 0, wbytes, 0));
+      hipLaunchKernelGGL(pack_in_taps_kernel, dim3(256), dim3(256), 0, 0, w->p, w->dt, cout, C, kt, q.cout_pad, 32, (bf16_t*)wp);
+      q.w = (bf16_t*)wp;
+      q.bias = c->pc.at("encoder.conv_in").bias;                  // same bias vector (already padded to cout_pad)
+      c->pc["encoder.conv_in.taps"] = q;
+    }
+  }
+  {
     // decoder.conv_out split by spatial tap (dove_amd/vae.py _pack; include/dove_hip.h dove_conv_out_gather)
     const Raw* w; CHK(need(c, "decoder.conv_out.conv.weight", &w, 5));
     const int C = (int)w->shape[0], cin = (int)w->shape[1], kt = (int)w->shape[2];
@@ -880,7 +907,11 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   const auto& cf = c->cfg;
   Tensor xcl;
   CHK(alloc_t(c, F, H, W, c->pc.at("encoder.conv_in").cin_pad, &xcl));
-  CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+  if (c->pc.count("encoder.conv_in.taps")) {
+    CHK(dove_cl_im2col3x3_from_ncthw(x, dtype, cf.vae_in_channels, F, H, W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+  } else {
+    CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+  }
   std::vector<std::pair<int, int>> fb;
   frame_batches(F, cf.vae_enc_batch, &fb);
   clear_caches(c);

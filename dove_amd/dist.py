@@ -345,8 +345,13 @@ def encode_sharded(vae, x, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     assert x.shape[0] == 1, "sharded path runs B = 1 (the reference's batch)"
     x = x.to(vae.device).contiguous()
-    x_cl = ops.cl_from_ncthw(x[0], vae.pc["encoder.conv_in"].cin_pad)
-    outs, cache = _run_sharded(vae, x_cl, frame_batches(x_cl.shape[0], vae.enc_batch), world, rank, group, vae._encoder)
+    if getattr(vae, "_conv_in_split", False):                   # same form of conv_in as the single-GPU encode (bit-identity)
+        x_cl = ops.cl_im2col3x3_from_ncthw(x[0], vae.pc["encoder.conv_in.taps"].cin_pad)
+        enc = lambda xb, cache: vae._encoder(xb, cache, split_in=True)      # noqa: E731
+    else:
+        x_cl = ops.cl_from_ncthw(x[0], vae.pc["encoder.conv_in"].cin_pad)
+        enc = vae._encoder
+    outs, cache = _run_sharded(vae, x_cl, frame_batches(x_cl.shape[0], vae.enc_batch), world, rank, group, enc)
     moments = _gather_time(outs, group, world, vae.device)
     vae.last_halo_bytes = cache.bytes_sent
     return _SharedPosterior([moments], vae.lat, vae.dtype, group)

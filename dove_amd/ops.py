@@ -307,6 +307,16 @@ def attention_mx(Q8, K8, V8t, Vs, N, Npad, heads, out):
     return out
 
 
+def cl_im2col3x3_from_ncthw(x: torch.Tensor, cp: int, scale=1.0, shift=0.0) -> torch.Tensor:
+    """[C,T,H,W] -> [T,H,W,cp] bf16 with the 3x3 neighbourhood in the channels ((dy*3+dx)*C + c; zero outside the frame and beyond 9C)."""
+    L.require_cuda(x)
+    Cc, T, H, W = x.shape
+    y = torch.empty(T, H, W, cp, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_cl_im2col3x3_from_ncthw(L.ptr(x), L.dt_code(x), Cc, T, H, W, cp, scale, shift, L.ptr(y), L.stream_ptr()),
+            "dove_cl_im2col3x3_from_ncthw")
+    return y
+
+
 def conv_out_gather(p: torch.Tensor, Cc: int, bias, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf) -> torch.Tensor:
     """Second half of the tap-split decoder.conv_out (include/dove_hip.h dove_conv_out_gather): p [T,H,W,ld] fp32 partial planes ->
     [Cc,T,H,W] ``dtype`` with the range map of ``ncthw_from_cl``."""

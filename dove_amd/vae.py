@@ -129,6 +129,13 @@ class AutoencoderKLCogVideoX:
         # decoder.conv_out split by spatial tap (include/dove_hip.h dove_conv_out_gather): with 3 output channels a direct 3x3x3
         # conv pads Cout 3 -> 32 and stages every input pixel 27 times; as a (3,1,1) conv with the 9 spatial taps as 27 output
         # channels it stages them 3 times and wastes 5 of 32 MFMA columns, the 9-tap shifted sum rides in the layout kernel
+        # encoder.conv_in the other way round (dove_cl_im2col3x3_from_ncthw): 3 input channels pad to 32 with 29 zeros; with the 9 spatial
+        # taps unrolled into the input channels (27 real) it is a (3,1,1) conv - a ninth of the MFMA work and of the staged bytes
+        wi = sd["encoder.conv_in.conv.weight"]                      # [Cout, Cin, 3, 3, 3]
+        self._conv_in_split = wi.shape[3] == 3 and wi.shape[4] == 3 and 9 * wi.shape[1] <= 32
+        if self._conv_in_split:
+            w27 = wi.float().permute(0, 3, 4, 1, 2).reshape(wi.shape[0], 9 * wi.shape[1], wi.shape[2], 1, 1)   # column (dy*3+dx)*Cin + c
+            self.pc["encoder.conv_in.taps"] = ops.pack_conv(w27, sd["encoder.conv_in.conv.bias"], dev)
         w = sd["decoder.conv_out.conv.weight"]                      # [Cout, Cin, 3, 3, 3]
         co, ci, kt, kh, kw = w.shape
         self._conv_out_split = kh == 3 and kw == 3 and 9 * co <= 32
@@ -227,8 +234,10 @@ class AutoencoderKLCogVideoX:
             tmode, t_out = 0, T
         return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps)
 
-    def _encoder(self, x, cache):
-        h = self._cconv(x, "encoder.conv_in", cache)
+    def _encoder(self, x, cache, split_in=False):
+        """``split_in``: x is the im2col'ed input of ``ops.cl_im2col3x3_from_ncthw`` (untiled encode: a spatial tile must see zero
+        padding at ITS border, so the tiled path keeps the direct conv)."""
+        h = self._cconv(x, "encoder.conv_in.taps" if split_in and self._conv_in_split else "encoder.conv_in", cache)
         nb = len(self.boc)
         for i in range(nb):
             for j in range(self.layers):
@@ -349,11 +358,14 @@ class AutoencoderKLCogVideoX:
         cin_pad = self.pc["encoder.conv_in"].cin_pad
         moments = []
         for b in range(x.shape[0]):
-            x_cl = ops.cl_from_ncthw(x[b], cin_pad)
             if tiled:
-                moments.append(self._tiled_encode(x_cl))
+                moments.append(self._tiled_encode(ops.cl_from_ncthw(x[b], cin_pad)))
                 continue
-            outs = self._run_batches(x_cl, self.enc_batch, self._encoder)
+            if self._conv_in_split:
+                x_cl = ops.cl_im2col3x3_from_ncthw(x[b], self.pc["encoder.conv_in.taps"].cin_pad)
+                outs = self._run_batches(x_cl, self.enc_batch, lambda xb, cache: self._encoder(xb, cache, split_in=True))
+            else:
+                outs = self._run_batches(ops.cl_from_ncthw(x[b], cin_pad), self.enc_batch, self._encoder)
             moments.append(torch.cat(outs, dim=0) if len(outs) > 1 else outs[0])
         dist = DiagonalGaussianDistribution(moments, self.lat, self.dtype)
         return _Out(latent_dist=dist) if return_dict else (dist,)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 8
+#define DOVE_ABI_VERSION 9
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -127,6 +127,11 @@ int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, 
                        void* stream);
 int dove_ncthw_from_cl(const void* x, long long ld, int C, long long npix, float scale, float shift, float lo,
                        float hi, void* y, int dtype, void* stream);
+/* encoder.conv_in (3 -> 128 channels, 3x3x3) with the spatial taps moved into the input channels: [C][T][H][W] -> [T][H][W][Cp] bf16,
+ * y[..][(dy*3+dx)*C + c] = x[c][t][h+dy-1][w+dx-1] * scale + shift (0 outside the frame; channels >= 9C zero).  The conv then is a (3,1,1)
+ * conv on 27 real input channels (weights re-laid the same way) instead of a 3x3x3 conv on 3 real channels padded to 32. */
+int dove_cl_im2col3x3_from_ncthw(const void* x, int dtype, int C, int T, int H, int W, int Cp, float scale, float shift, void* y,
+                                 void* stream);
 /* decoder.conv_out (128 -> 3 channels, 3x3x3) split by spatial tap: a (3,1,1) conv with 27 (padded 32) output channels
  * P[t][y][x][(dy*3+dx)*C + c] = sum_{kt,ci} x[t+kt-2][y][x][ci] w[c][ci][kt][dy][dx] (dove_conv_igemm_bf16 with out_f32 = 1: K = 3*Cin
  * instead of 27*Cin per staged pixel, and no 32/3 padding waste on the MFMAs) followed by this gather:

@@ -330,6 +330,17 @@ def cl_from_ncthw(x, cp, scale=1.0, shift=0.0):
     return y
 
 
+def cl_im2col3x3_from_ncthw(x, cp, scale=1.0, shift=0.0):
+    Cc, T, H, W = x.shape
+    xp = F.pad(x.float() * scale + shift, (1, 1, 1, 1))                  # [C, T, H+2, W+2], zeros outside the frame
+    y = torch.zeros(T, H, W, cp, dtype=BF)
+    for dy in range(3):
+        for dx in range(3):
+            k = (dy * 3 + dx) * Cc
+            y[..., k:k + Cc] = xp[:, :, dy:dy + H, dx:dx + W].permute(1, 2, 3, 0).to(BF)
+    return y
+
+
 def ncthw_from_cl(x, Cc, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf):
     return (x.float()[..., :Cc] * scale + shift).clamp(lo, hi).permute(3, 0, 1, 2).contiguous().to(dtype)
 
@@ -460,7 +471,7 @@ def attention_bias(qkv, bias, heads):
 
 
 ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "qkv_post_mx", "attention_mx",
-       "cl_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
+       "cl_from_ncthw", "cl_im2col3x3_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 
 def install(monkeypatch):

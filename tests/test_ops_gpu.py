@@ -141,6 +141,30 @@ LIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("T,H,W,use_cache", [(3, 20, 37, True), (9, 18, 70, False)])
+def test_conv_in_im2col(T, H, W, use_cache):
+    """encoder.conv_in as a (3,1,1) conv on the im2col'ed input (dove_cl_im2col3x3_from_ncthw) against the direct 3x3x3 conv on the
+    3-channel input: same products, fp32 sums in another order."""
+    cin, co = 3, 128
+    g = torch.Generator().manual_seed(41)
+    w = torch.randn(co, cin, 3, 3, 3, generator=g) * (cin * 27) ** -0.5
+    b = torch.randn(co, generator=g) * 0.1
+    x = torch.randn(cin, T + 2, H, W, generator=g)                       # [C, frames, H, W]; the first two frames act as the cache
+    xs = x[:, 2:] if use_cache else x[:, :T]
+    xc = x[:, :2] if use_cache else None
+    im = ops.cl_im2col3x3_from_ncthw(xs.cuda(), 32)
+    assert torch.equal(im.cpu(), E.cl_im2col3x3_from_ncthw(xs, 32))
+    w27 = w.permute(0, 3, 4, 1, 2).reshape(co, 27, 3, 1, 1)
+    pt_g = ops.pack_conv(w27, b, "cuda")
+    got = ops.conv(im, pt_g, cache=None if xc is None else ops.cl_im2col3x3_from_ncthw(xc.cuda(), 32))
+    pc_c, pc_g = E.pack_conv(w, b, "cpu"), ops.pack_conv(w, b, "cuda")
+    direct = ops.conv(ops.cl_from_ncthw(xs.cuda(), 32), pc_g, cache=None if xc is None else ops.cl_from_ncthw(xc.cuda(), 32))
+    want = E.conv(E.cl_from_ncthw(xs, 32), pc_c, cache=None if xc is None else E.cl_from_ncthw(xc, 32))
+    torch.cuda.synchronize()
+    close("conv_in_im2col.vs_direct_hip", got, direct, rtol=8e-3, afrac=4e-3)
+    close("conv_in_im2col.vs_emu", got, want)
+
+
 @pytest.mark.parametrize("T,H,W,use_cache", [(3, 20, 37, True), (2, 9, 70, False), (1, 16, 16, False)])
 def test_conv_out_tap_split(T, H, W, use_cache):
     """decoder.conv_out as a (3,1,1) conv with the 9 spatial taps as 27 fp32 output channels + dove_conv_out_gather: same result as
