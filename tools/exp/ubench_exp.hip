@@ -33,7 +33,7 @@ __global__ __launch_bounds__(1024) void ub_kernel(unsigned long long* out, int r
     } else if (MODE == 2) {   // 16 exp + 16 add interleaved
       asm volatile(R4("v_exp_f32 %0, %0\n v_add_f32 %4, %4, %8\n v_exp_f32 %1, %1\n v_add_f32 %5, %5, %8\n v_exp_f32 %2, %2\n v_add_f32 %6, %6, %8\n v_exp_f32 %3, %3\n v_add_f32 %7, %7, %8\n")
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));
-    } else if (MODE == 3) {   // 8 MFMA on 4 accumulators
+    } else if (MODE == 3) {   // 16 MFMA on 4 accumulators (2 x R4 of 2; an earlier label said 8 and halved the derived rate)
       asm volatile(R4("v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n v_mfma_f32_32x32x16_bf16 %1, %4, %5, %1\n")
                    R4("v_mfma_f32_32x32x16_bf16 %2, %4, %5, %2\n v_mfma_f32_32x32x16_bf16 %3, %4, %5, %3\n")
                    : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(fa), "v"(fb));

@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libubench_exp.so"))
 lib.ubench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-NAMES = {0: "32 v_exp_f32", 1: "32 v_add_f32", 2: "16 exp + 16 add interleaved", 3: "8 MFMA 32x32x16 (4 acc)", 4: "8 MFMA + 32 add (4/gap)",
+NAMES = {0: "32 v_exp_f32", 1: "32 v_add_f32", 2: "16 exp + 16 add interleaved", 3: "16 MFMA 32x32x16 (4 acc; two groups of 8)", 4: "8 MFMA + 32 add (4/gap)",
          5: "8 MFMA + 16 exp (2/gap)", 6: "8 MFMA + 16 exp + 40 add + 8 cvt", 7: "32 v_max3_f32", 8: "32 v_cvt_pk_bf16_f32",
          9: "32 v_permlane32_swap", 10: "16 v_pk_add_f32", 11: "8 MFMA then 16 exp (phases)", 12: "32 v_fma_f32"}
 out = torch.zeros(4, dtype=torch.int64, device="cuda")
