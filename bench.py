@@ -3,7 +3,10 @@
 One "step" = one `process_video` call on one [1,3,33,720,1280] clip already resident in HBM: VAE encode ->
 posterior sample -> 42-layer DiT at t=399 -> get_velocity -> VAE decode -> [0,1] range map, all through the C-ABI
 HIP operators (full CogVideoX1.5-5B architecture, deterministic random-init weights, bf16 storage / fp32
-accumulate).  N GPUs = N independent clips (the reference's chunk farm: no data-path collective; weak scaling).
+accumulate).  N GPUs = N independent clips (the reference's chunk farm: no data-path collective; weak scaling).  With N > 1 the
+same line also carries `single_clip`: ONE clip sharded over the N ranks (BASELINE configs[2]: halo-exact VAE with RCCL send/recv of
+the temporal-conv borders + sequence/head-parallel DiT), timed in the same run, with halo bytes per rank and the strong-scaling
+efficiency against this run's own one-GPU clip time.
 
 `python bench.py --gpus N` launches its own N ranks (re-exec under torch.distributed.run on 127.0.0.1) when it was not
 started by a launcher already; either way every rank asserts WORLD_SIZE == --gpus and that it owns a distinct GPU.
@@ -88,7 +91,7 @@ def relaunch_if_needed(args):
         return
     import socket
     n = torch.cuda.device_count()
-    if n < args.gpus:
+    if n < args.gpus and not args.oversubscribe:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n} GPU(s) are visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -115,6 +118,10 @@ def main():
                          "never the headline: the line says so in `dtype` and `config.variant`")
     ap.add_argument("--dit-attention", choices=["bf16", "mxfp8"], default="bf16",
                     help="same configs[4] variant: attention products on the block-scaled fp8 MFMA; never the headline")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra (never headline) MXFP8 measurement of the N=1 line")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="debug only: play the N ranks as N processes on GPU 0 over gloo (RCCL refuses two ranks on one device) to "
+                         "exercise the multi-rank code path on a one-GPU box; the line is marked invalid")
     ap.add_argument("--single-clip", action="store_true",
                     help="strong scaling: ONE clip sharded over all ranks (halo-exact VAE + Ulysses DiT, dove_amd.dist."
                          "process_video_sharded) instead of one clip per rank; not the driver's default")
@@ -129,8 +136,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.oversubscribe:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if world != args.gpus:
         raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if torch.cuda.device_count() < (local + 1):
@@ -157,11 +169,14 @@ def main():
     T = 1 + (args.frames - 1) // 4
     noise = torch.randn(1, 16, T, args.height // 8, args.width // 8, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
 
+    def step_sharded(clip):
+        from dove_amd.dist import process_video_sharded
+        # every rank keeps the frames it decoded (no gather of the 183 MB clip: each rank would write its own frames)
+        return process_video_sharded(pipe, clip, empty_prompt_embedding=text, posterior_noise=noise, gather="none")
+
     def step():
         if strong:
-            from dove_amd.dist import process_video_sharded
-            # every rank keeps the frames it decoded (no gather of the 183 MB clip: each rank would write its own frames)
-            return process_video_sharded(pipe, video, empty_prompt_embedding=text, posterior_noise=noise, gather="none")
+            return step_sharded(video)
         return process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
 
     def barrier():
@@ -186,17 +201,56 @@ def main():
     if use_dist:
         import torch.distributed as dist
         observed_world = dist.get_world_size()                    # what RCCL's communicator actually spans
-        mine = torch.tensor([elapsed, float(local)], device=dev, dtype=torch.float64)
+        gdev = "cpu" if args.oversubscribe else dev            # gloo gathers host tensors
+        mine = torch.tensor([elapsed, float(local)], device=gdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(observed_world)]
         dist.all_gather(allr, mine)
         per_rank = [float(x[0]) for x in allr]
         gpu_ids = [f"cuda:{int(x[1])}" for x in allr]
-        assert len(set(gpu_ids)) == observed_world == args.gpus, (gpu_ids, observed_world, args.gpus)
+        assert observed_world == args.gpus and (args.oversubscribe or len(set(gpu_ids)) == observed_world), (gpu_ids, observed_world, args.gpus)
         elapsed = max(per_rank)
     if strong:
         assert out is None or (out.shape[0:2] == (1, 3) and out.shape[3:] == (args.height, args.width) and bool(torch.isfinite(out).all()))
     else:
         assert out.shape == (1, 3, args.frames, args.height, args.width) and bool(torch.isfinite(out).all())
+
+    # ---- N > 1: the same ranks now run ONE clip together (BASELINE configs[2]); same barrier / max-over-ranks timing ----
+    single = None
+    if use_dist and world > 1 and not strong:
+        import torch.distributed as dist
+        clip0 = video if rank == 0 else prepare_clip(synth_lr_clip(args.frames, args.height // up, args.width // up, seed=42, device=dev), up)
+        for _ in range(max(1, args.warmup)):            # the first sharded call records the halo plan (blocking receives)
+            step_sharded(clip0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mine = step_sharded(clip0)
+        barrier()
+        el1 = time.perf_counter() - t1
+        info = torch.tensor([el1, 0.0 if mine is None else float(mine.shape[2]), float(getattr(pipe.vae, "last_halo_bytes_encode", 0)),
+                             float(getattr(pipe.vae, "last_halo_bytes_decode", 0))], device=dev, dtype=torch.float64)
+        info = info.to(gdev)
+        infos = [torch.zeros_like(info) for _ in range(observed_world)]
+        dist.all_gather(infos, info)
+        el1 = max(float(x[0]) for x in infos)
+        assert mine is None or bool(torch.isfinite(mine).all())
+        assert sum(int(x[1]) for x in infos) == args.frames, "the ranks' decoded frames do not add up to the clip"
+        macs1 = flops.clip_macs(v, t, args.frames, args.height, args.width)
+        n_tok = macs1["tokens"]
+        single = {
+            "what": "ONE clip sharded over all ranks (BASELINE configs[2]): halo-exact VAE (frame-batches / paired pieces per rank, "
+                    "temporal-conv borders by send/recv rank -> rank+1) + sequence/head-parallel DiT (one all_to_all each way per layer); "
+                    "bit-identical to the one-GPU result (tests/test_dist_gpu.py)",
+            "scaling": "strong", "world_size_observed": observed_world, "steps": args.steps,
+            "value": args.steps * args.frames / el1, "unit": "frames/s", "ms_per_clip": el1 / args.steps * 1e3,
+            "frames_decoded_per_rank": [int(x[1]) for x in infos],
+            "vae_halo_bytes_sent_per_rank": {"encode": [int(x[2]) for x in infos], "decode": [int(x[3]) for x in infos]},
+            "dit_all_to_all_bytes_per_rank_per_layer": int(4 * n_tok * t["num_attention_heads"] * t["attention_head_dim"] * 2 / observed_world),
+            # strong-scaling efficiency against THIS run's one-GPU clip time (the weak region above: one clip per GPU)
+            "one_gpu_ms_per_clip_this_run": elapsed / args.steps * 1e3,
+            "efficiency_vs_n1": (elapsed / args.steps) / (observed_world * (el1 / args.steps)),
+            "transport": "gloo through host memory (--oversubscribe debug run)" if args.oversubscribe else "RCCL (backend nccl) over xGMI",
+        }
 
     if rank == 0:
         macs = flops.clip_macs(v, t, args.frames, args.height, args.width)
@@ -268,6 +322,10 @@ def main():
                                          for k, a in top}},
             "model_build_s": t_build,
         }
+        if single is not None:
+            res["single_clip"] = single
+        if args.oversubscribe:
+            res["invalid"] = "debug run: all ranks share GPU 0 over gloo (--oversubscribe)"
         if strong:
             res["halo_exchange"] = {"vae_halo_bytes_sent_rank0_last_stage": int(getattr(pipe.vae, "last_halo_bytes", 0)),
                                     "mode": "isend + pre-posted irecv per causal conv, GroupNorm pair sums on a side communicator"}
@@ -283,6 +341,32 @@ def main():
             res["psnr_note"] = ("9x256x256 clip, full 42-layer model; random-init weights saturate "
                                 f"{100 * float(((sref <= 0) | (sref >= 1)).float().mean()):.0f} % of the reference pixels - un-saturated "
                                 "gates live in tests/test_parity_gpu.py")
+        if world == 1 and headline and not args.no_variants and args.layers is None:
+            # BASELINE configs[4] measured in the SAME run on the same clip (never the headline): the DiT rebuilt with MXFP8 linears +
+            # attention (same seed), the VAE object shared.  PSNR gates of this variant: tests/test_parity_gpu.py::test_mxfp8_dit_psnr_gate
+            del pipe.transformer
+            torch.cuda.empty_cache()
+            from dove_amd import weights as W_
+            from dove_amd.transformer import CogVideoXTransformer3DModel
+            pipe.transformer = CogVideoXTransformer3DModel(t, W_.LazyStateDict(W_.dit_param_shapes(t), 1234, dev), dev, torch.bfloat16,
+                                                           "mxfp8", "mxfp8")
+            vsteps = max(1, min(args.steps, 5))
+            ref_out = out
+            out8 = step()
+            barrier()
+            tv = time.perf_counter()
+            for _ in range(vsteps):
+                out8 = step()
+            barrier()
+            tv = time.perf_counter() - tv
+            mse = ((out8.float() - ref_out.float()) ** 2).flatten(3).mean(-1)
+            res["variants"] = [{
+                "name": "BASELINE configs[4]: DiT linears + attention in MXFP8 (e4m3 + E8M0 block scales, v_mfma_scale_f32_32x32x64_f8f6f4), "
+                        "everything else bf16 - NOT the headline dtype",
+                "dtype": "mxfp8 + bf16", "value": vsteps * args.frames / tv, "unit": "frames/s", "steps": vsteps, "ms_per_step": tv / vsteps * 1e3,
+                "speedup_vs_headline_this_run": (vsteps * args.frames / tv) / value,
+                "psnr_vs_bf16_path_db_this_clip": float((10 * torch.log10(1.0 / (mse + 1e-8))).mean()),
+                "psnr_note": "full-size clip, random-init weights (saturated output); the un-saturated 42-layer gate is in tests/test_parity_gpu.py"}]
         print(json.dumps(res), flush=True)
     if use_dist:
         import torch.distributed as dist

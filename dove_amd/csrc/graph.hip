@@ -443,7 +443,7 @@ int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::strin
   float* stats = fused_stats;
   if (!stats) {
     stats = (float*)c->arena.alloc(64 * 4);
-    CHK(dove_groupnorm_stats_bf16(x.p, x.elems() / x.C, x.C, eps, c->gn_ws, 2048, stats, stream));
+    CHK(dove_groupnorm_stats_bf16(x.p, x.elems() / x.C, (long long)x.H * x.W, x.C, eps, c->gn_ws, 4096, stats, stream));
   }
   const auto& gb = c->aff.at(name);
   CHK(alloc_t(c, x.T, x.H, x.W, x.C, out));
@@ -854,7 +854,7 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
   CHK(dev_alloc(c, (size_t)cf.dit_time_embed_dim * 4, &m)); c->e1 = (float*)m;
   CHK(dev_alloc(c, (size_t)D * 4, &m)); c->temb = (float*)m;
   CHK(dev_alloc(c, (size_t)6 * D * 4, &m)); c->vtmp = (float*)m;
-  CHK(dev_alloc(c, (size_t)2048 * 64 * 4, &m)); c->gn_ws = (float*)m;
+  CHK(dev_alloc(c, (size_t)4096 * 64 * 4, &m)); c->gn_ws = (float*)m;
   HIPCHK(hipDeviceSynchronize());                             // the borrowed source tensors may be released by the caller now
   c->raw.clear();
   c->finalized = true;

@@ -12,9 +12,14 @@
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics: partial (sum, sumsq) per block and group, then an fp64 combine.
 // Thread layout: cpp = C/8 chunk columns x (256/cpp) pixel lanes; deterministic (no atomics).
+// Grid = (blocks per frame, frames): a block's pixels and their summation order depend on the FRAME SIZE only, so the partial
+// rows of two pieces of a frame-batch (dove_amd.dist: a batch split over a rank pair) are exactly the rows of the whole batch and
+// the fp64 combine of either set gives the same statistics.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, long long npix, int C,
-                                                         int cpp_log, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ xall, long long npix, int C,
+                                                         int cpp_log, float* __restrict__ partial_all) {
+  const bf16_t* __restrict__ x = xall + (long long)blockIdx.y * npix * C;      // npix = pixels of ONE frame
+  float* __restrict__ partial = partial_all + (long long)blockIdx.y * gridDim.x * 64;
   __shared__ float red[256 * 17];
   __shared__ float chan[2 * 2048];
   const int tid = threadIdx.x;
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count,
+template <typename PT>   // float: per-block partials; double: the first-level sums of gn_reduce_rows_kernel
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const PT* __restrict__ partial, int nblocks, double count,
                                                           float eps, float* __restrict__ stats) {
   const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;  // 4 strided partial sums per (group, which)
   double acc = 0.0;
@@ -75,7 +81,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // raw fp64 (sum, sumsq) per group from the per-block partials (distributed pieces add these before finalising)
-__global__ __launch_bounds__(256) void gn_sums_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ sums) {
+template <typename PT>
+__global__ __launch_bounds__(256) void gn_sums_kernel(const PT* __restrict__ partial, int nblocks, double* __restrict__ sums) {
   const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
   double acc = 0.0;
 #pragma unroll 8
@@ -87,6 +94,7 @@ __global__ __launch_bounds__(256) void gn_sums_kernel(const float* __restrict__ 
 }
 __global__ void gn_finalize_sums_kernel(const double* __restrict__ sums, double count, float eps, float* __restrict__ stats) {
   const int g = threadIdx.x;
+  if (count <= 0.0) count = sums[64];      // the 65-double message of a rank pair carries the element count behind the sums
   if (g < 32) {
     const double mean = sums[g * 2] / count;
     double var = sums[g * 2 + 1] / count - mean * mean;
@@ -96,16 +104,18 @@ __global__ void gn_finalize_sums_kernel(const double* __restrict__ sums, double 
   }
 }
 
-// partial rows written by a conv epilogue (one per tile x wave) -> 256 rows for gn_finalize_kernel; fp64, fixed order
+// partial rows written by a conv epilogue (one per tile x wave) -> 256 rows for gn_finalize_kernel; fixed order.  The first-level
+// sums stay fp64 (they used to be rounded to fp32 here): sums of fp32 tile partials are then exact in practice at every level, so
+// a frame-batch split over a rank pair (dove_amd.dist, whose pieces have other row counts) finalises to the same (mean, rstd)
 __global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ partial, long long rows,
-                                                             float* __restrict__ out) {
+                                                             double* __restrict__ out) {
   const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
   double acc = 0.0;
   for (long long r = (long long)blockIdx.x * 4 + part; r < rows; r += (long long)gridDim.x * 4) acc += (double)partial[r * 64 + j];
   __shared__ double sh[256];
   sh[tid] = acc;
   __syncthreads();
-  if (tid < 64) out[blockIdx.x * 64 + tid] = (float)((sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]));
+  if (tid < 64) out[blockIdx.x * 64 + tid] = (sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]);
 }
 
 extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws,
@@ -114,11 +124,11 @@ extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long 
   DOVE_CHECK_ARG(rows > 0 && count > 0, "groupnorm_finalize_partials: empty input");
   hipStream_t s = (hipStream_t)stream;
   if (rows <= 1024) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, partial, (int)rows, count, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(1), dim3(256), 0, s, partial, (int)rows, count, eps, stats);
   } else {
-    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (float*)ws);
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (double*)ws);
     DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials(reduce)");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, 256, count, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(1), dim3(256), 0, s, (const double*)ws, 256, count, eps, stats);
   }
   DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials");
   return DOVE_OK;
@@ -128,59 +138,67 @@ extern "C" int dove_groupnorm_sums_from_partials(const float* partial, long long
   DOVE_CHECK_ARG(partial && ws && sums && rows > 0, "groupnorm_sums_from_partials: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (rows <= 1024) {
-    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, partial, (int)rows, sums);
+    hipLaunchKernelGGL(gn_sums_kernel<float>, dim3(1), dim3(256), 0, s, partial, (int)rows, sums);
   } else {
-    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (float*)ws);
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (double*)ws);
     DOVE_CHECK_LAUNCH("dove_groupnorm_sums_from_partials(reduce)");
-    hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, 256, sums);
+    hipLaunchKernelGGL(gn_sums_kernel<double>, dim3(1), dim3(256), 0, s, (const double*)ws, 256, sums);
   }
   DOVE_CHECK_LAUNCH("dove_groupnorm_sums_from_partials");
   return DOVE_OK;
 }
 
 extern "C" int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream) {
-  DOVE_CHECK_ARG(sums && stats && count > 0, "groupnorm_finalize_sums: bad arguments");
+  DOVE_CHECK_ARG(sums && stats, "groupnorm_finalize_sums: bad arguments");
   hipLaunchKernelGGL(gn_finalize_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, count, eps, stats);
   DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_sums");
   return DOVE_OK;
 }
 
-extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws,
-                                          int ws_blocks, float* stats, void* stream) {
-  DOVE_CHECK_ARG(x && partial_ws && stats, "groupnorm_stats: null pointer");
-  DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_stats: C (%d) must be a power of two in [32,2048]", C);
-  DOVE_CHECK_ARG(npix > 0 && ws_blocks > 0, "groupnorm_stats: empty input");
+// launches gn_partial_kernel over [frames][frame_pix][C]; returns the number of partial rows written (0 after an argument error)
+static int gn_partial_launch(const void* x, long long npix, long long frame_pix, int C, void* partial_ws, int ws_blocks, hipStream_t s,
+                             const char* who) {
+  if (!(C >= 32 && C <= 2048 && (C & (C - 1)) == 0)) { dove_set_error("%s: C (%d) must be a power of two in [32,2048]", who, C); return 0; }
+  if (!(npix > 0 && ws_blocks > 0)) { dove_set_error("%s: empty input", who); return 0; }
+  if (frame_pix <= 0) frame_pix = npix;
+  if (npix % frame_pix) { dove_set_error("%s: npix (%lld) is not a multiple of frame_pix (%lld)", who, npix, frame_pix); return 0; }
+  const long long frames = npix / frame_pix;
+  if (frames > 65535 || frames > ws_blocks) { dove_set_error("%s: %lld frames exceed the scratch rows (%d)", who, frames, ws_blocks); return 0; }
   int cpp_log = 0;
   while ((1 << cpp_log) < C / 8) ++cpp_log;
-  DOVE_CHECK_ARG(cpp_log <= 8, "groupnorm_stats: C too large");
   const int nsub = 256 >> cpp_log;
-  long long want = (npix + nsub - 1) / nsub;
-  int blocks = (int)(want < ws_blocks ? want : ws_blocks);
-  if (blocks > 1024) blocks = 1024;
+  // blocks per frame: a function of the frame size alone (>= 32 pixels per thread, at most 256 blocks) - see gn_partial_kernel;
+  // only a scratch buffer too small for frames x bpf rows lowers it (the result stays deterministic, but no longer split-invariant)
+  long long bpf = (frame_pix + (long long)nsub * 32 - 1) / ((long long)nsub * 32);
+  if (bpf > 256) bpf = 256;
+  if (bpf * frames > ws_blocks) bpf = ws_blocks / frames;
+  if (bpf < 1) bpf = 1;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)bpf, (unsigned)frames), dim3(256), 0, s, (const bf16_t*)x, frame_pix, C, cpp_log,
+                     (float*)partial_ws);
+  return (int)(bpf * frames);
+}
+
+extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, long long frame_pix, int C, float eps, void* partial_ws,
+                                          int ws_blocks, float* stats, void* stream) {
+  DOVE_CHECK_ARG(x && partial_ws && stats, "groupnorm_stats: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, npix, C, cpp_log, (float*)partial_ws);
+  const int rows = gn_partial_launch(x, npix, frame_pix, C, partial_ws, ws_blocks, s, "groupnorm_stats");
+  if (!rows) return DOVE_EINVAL;
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(partial)");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, blocks,
+  hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)partial_ws, rows,
                      (double)npix * (double)(C / 32), eps, stats);
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
   return DOVE_OK;
 }
 
-extern "C" int dove_groupnorm_sums_bf16(const void* x, long long npix, int C, void* partial_ws, int ws_blocks, double* sums,
-                                        void* stream) {
+extern "C" int dove_groupnorm_sums_bf16(const void* x, long long npix, long long frame_pix, int C, void* partial_ws, int ws_blocks,
+                                        double* sums, void* stream) {
   DOVE_CHECK_ARG(x && partial_ws && sums, "groupnorm_sums: null pointer");
-  DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_sums: C (%d) must be a power of two in [32,2048]", C);
-  DOVE_CHECK_ARG(npix > 0 && ws_blocks > 0, "groupnorm_sums: empty input");
-  int cpp_log = 0;
-  while ((1 << cpp_log) < C / 8) ++cpp_log;
-  const int nsub = 256 >> cpp_log;
-  long long want = (npix + nsub - 1) / nsub;
-  int blocks = (int)(want < ws_blocks ? want : ws_blocks);
-  if (blocks > 1024) blocks = 1024;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, npix, C, cpp_log, (float*)partial_ws);
+  const int rows = gn_partial_launch(x, npix, frame_pix, C, partial_ws, ws_blocks, s, "groupnorm_sums");
+  if (!rows) return DOVE_EINVAL;
   DOVE_CHECK_LAUNCH("dove_groupnorm_sums_bf16(partial)");
-  hipLaunchKernelGGL(gn_sums_kernel, dim3(1), dim3(256), 0, s, (const float*)partial_ws, blocks, sums);
+  hipLaunchKernelGGL(gn_sums_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)partial_ws, rows, sums);
   DOVE_CHECK_LAUNCH("dove_groupnorm_sums_bf16(sums)");
   return DOVE_OK;
 }

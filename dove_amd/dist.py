@@ -36,6 +36,107 @@ from .inference import process_video
 from .vae import DiagonalGaussianDistribution, frame_batches
 
 
+# ---- wires ---------------------------------------------------------------------------------------------
+# RCCL ("nccl") moves device tensors directly.  Any other backend (gloo: the CPU tests, and the GPU test that plays R ranks as R
+# processes on ONE device, tests/test_dist_gpu.py - RCCL refuses two ranks on one GPU) gets bytes, and device tensors are staged
+# through host memory explicitly instead of relying on the backend's optional device support.  Same messages, same order.
+def _direct(group):
+    return dist.get_backend(group) == "nccl"
+
+
+def _bytes(t):
+    return t.view(torch.uint8) if t.dtype == torch.bfloat16 else t
+
+
+class _StagedRecv:
+    """``irecv`` into host memory on behalf of a device buffer: ``wait()`` completes the receive, then uploads."""
+
+    def __init__(self, buf, src, group):
+        self._buf, self._host = buf, torch.empty(buf.shape, dtype=buf.dtype, device="cpu")
+        self._work = dist.irecv(_bytes(self._host), src=src, group=group)
+
+    def wait(self):
+        self._work.wait()
+        self._buf.copy_(self._host)
+
+
+def _isend(t, dst, group):
+    """-> (tensor to keep alive, work).  ``dst`` is a global rank."""
+    if _direct(group):
+        return t, dist.isend(t, dst=dst, group=group)
+    h = t.cpu() if t.is_cuda else t                    # .cpu() waits for the producing stream
+    return h, dist.isend(_bytes(h), dst=dst, group=group)
+
+
+def _irecv(buf, src, group):
+    if _direct(group):
+        return dist.irecv(buf, src=src, group=group)
+    if buf.is_cuda:
+        return _StagedRecv(buf, src, group)
+    return dist.irecv(_bytes(buf), src=src, group=group)
+
+
+def _send(t, dst, group):
+    _isend(t, dst, group)[1].wait()
+
+
+def _exchange(mine, theirs, peer, group):
+    """Symmetric swap with one peer, both directions in flight at once.  On RCCL the pair must be ONE grouped call: two ranks that
+    each enqueue recv-then-send separately wait on each other's send forever."""
+    if _direct(group):
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, peer, group), dist.P2POp(dist.irecv, theirs, peer, group)]):
+            w.wait()
+        return
+    rw = _irecv(theirs, peer, group)
+    keep, sw = _isend(mine, peer, group)
+    rw.wait()
+    sw.wait()
+
+
+def _recv(buf, src, group):
+    _irecv(buf, src, group).wait()
+
+
+def _all_gather(outs, t, group):
+    if _direct(group) or not t.is_cuda:
+        dist.all_gather([_bytes(o) for o in outs], _bytes(t), group=group)
+        return
+    hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+    dist.all_gather([_bytes(h) for h in hs], _bytes(t.cpu()), group=group)
+    for o, h in zip(outs, hs):
+        o.copy_(h)
+
+
+def _all_to_all(out, inp, out_splits, in_splits, group):
+    """all_to_all_single over flat bf16 buffers; splits in ELEMENTS."""
+    ob, ib = [2 * v for v in out_splits], [2 * v for v in in_splits]
+    if _direct(group) or not inp.is_cuda:
+        dist.all_to_all_single(out.view(torch.uint8), inp.view(torch.uint8), ob, ib, group=group)
+        return
+    h = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_to_all_single(h.view(torch.uint8), inp.cpu().view(torch.uint8), ob, ib, group=group)
+    out.copy_(h)
+
+
+def _broadcast(t, src, group):
+    """In place on ``t`` (contiguous)."""
+    if _direct(group) or not t.is_cuda:
+        dist.broadcast(_bytes(t), src=src, group=group)
+        return
+    h = t.cpu()
+    dist.broadcast(_bytes(h), src=src, group=group)
+    t.copy_(h)
+
+
+def _group_key(group):
+    """Stable identity of a process group for plan caches (``id(group)`` can be reused after a group is destroyed)."""
+    g = group if group is not None else dist.group.WORLD
+    return (tuple(dist.get_process_group_ranks(g)), dist.get_backend(g))
+
+
+_poisoned: set = set()          # groups on which a sharded call failed with receives still posted
+
+
 # ---- (A) chunk farm ---------------------------------------------------------------------------------
 def owns(i: int, n: int, rank: int, world: int) -> bool:
     """Round-robin ownership of work item i of n."""
@@ -114,9 +215,6 @@ class HaloCache(dict):
         self._sends = []
         self._dev = None
 
-    def _wire(self, t):
-        return t.view(torch.uint8) if dist.get_backend(self.group) != "nccl" else t
-
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group else r
 
@@ -128,7 +226,7 @@ class HaloCache(dict):
             return
         for name, shape in plan:
             buf = torch.empty(shape, dtype=torch.bfloat16, device=device)
-            self._posted[name] = (buf, dist.irecv(self._wire(buf), src=self._peer(self.rank - 1), group=self.group))
+            self._posted[name] = (buf, _irecv(buf, self._peer(self.rank - 1), self.group))
 
     def fetch(self, name, like_shape, device):
         """Halo for conv ``name`` of the first local batch (None on rank 0: replicate-first-frame padding)."""
@@ -139,7 +237,7 @@ class HaloCache(dict):
                 work.wait()
                 return buf
             buf = torch.empty(like_shape, dtype=torch.bfloat16, device=device)
-            dist.recv(self._wire(buf), src=self._peer(self.rank - 1), group=self.group)
+            _recv(buf, self._peer(self.rank - 1), self.group)
             self._record.append((name, tuple(like_shape)))
             return buf
         return self.get(name)
@@ -147,8 +245,7 @@ class HaloCache(dict):
     def publish(self, name, new):
         self[name] = new
         if self.phase in ("last", "both") and self.rank < self.world - 1:
-            t = new.contiguous()
-            self._sends.append((t, dist.isend(self._wire(t), dst=self._peer(self.rank + 1), group=self.group)))
+            self._sends.append(_isend(new.contiguous(), self._peer(self.rank + 1), self.group))
             self.bytes_sent += new.numel() * 2
 
     def finish(self):
@@ -159,6 +256,15 @@ class HaloCache(dict):
         assert not self._posted, f"pre-posted halos never consumed: {list(self._posted)}"
         if self._record and self.plan_key is not None:
             HaloCache._plans[self.plan_key] = list(self._record)
+
+    def abandon(self):
+        """A stage failed part-way: forget the plan; receives that are still posted cannot be recalled and would pair with the
+        NEXT call's halos, so the group is refused from now on (``_run_sharded``) instead of computing on stale buffers."""
+        HaloCache._plans.pop(self.plan_key, None)
+        if self._posted:
+            _poisoned.add(_group_key(self.group))
+        self._posted.clear()
+        self._sends.clear()
 
 
 def plan_pieces(batches, world, kind):
@@ -216,7 +322,11 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
     mine = plan[rank]
     paired = any(pc["partner"] is not None for r in plan for pc in r)
     gn_group = _side_group(group) if paired else group
-    cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, id(group)))
+    gkey = _group_key(group)
+    if gkey in _poisoned:
+        raise RuntimeError("dove_amd.dist: an earlier sharded call on this process group failed with halo receives still posted; "
+                           "destroy and re-create the process group before the next sharded call")
+    cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, gkey))
     if not paired or gn_group is not None:
         cache.prepost(x_cl.device)
     if gn_group is None:
@@ -226,6 +336,16 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
     def gsrc(r):
         return dist.get_global_rank(group, r) if group else r      # the side group spans the same ranks in the same order
 
+    try:
+        _run_pieces(vae, x_cl, mine, cache, fn, outs, gsrc, gn_group, ops)
+    except BaseException:
+        cache.abandon()
+        raise
+    cache.finish()
+    return outs, cache
+
+
+def _run_pieces(vae, x_cl, mine, cache, fn, outs, gsrc, gn_group, ops):
     for i, pc in enumerate(mine):
         first, last = i == 0, i == len(mine) - 1
         cache.phase = "both" if first and last else ("first" if first else ("last" if last else "mid"))
@@ -238,23 +358,15 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
                 cnt = float(x.numel() // 32)
                 mine_msg = torch.cat([sums.reshape(-1), torch.tensor([cnt], dtype=torch.float64, device=sums.device)])
                 theirs = torch.empty_like(mine_msg)
-                if lower:
-                    dist.send(mine_msg, dst=gsrc(partner), group=gn_group)
-                    dist.recv(theirs, src=gsrc(partner), group=gn_group)
-                else:
-                    dist.recv(theirs, src=gsrc(partner), group=gn_group)
-                    dist.send(mine_msg, dst=gsrc(partner), group=gn_group)
+                _exchange(mine_msg, theirs, gsrc(partner), gn_group)     # 65 doubles each way, ONE round trip per norm
                 a, b = (mine_msg, theirs) if lower else (theirs, mine_msg)      # same summation order on both ranks
-                tot = a + b
-                return ops.groupnorm_from_sums(tot[:64].reshape(32, 2).contiguous(), float(tot[64]), vae.eps)
+                return ops.groupnorm_from_sums(a + b, None, vae.eps)     # element count = the 65th double: no host read-back
 
             vae._gn_hook, vae._piece_role = hook, pc["role"]
         try:
             outs.append(fn(x_cl[pc["s"]:pc["e"]], cache))
         finally:
             vae._gn_hook, vae._piece_role = None, None
-    cache.finish()
-    return outs, cache
 
 
 def _gather_time(parts, group, world, device, to="all"):
@@ -265,13 +377,12 @@ def _gather_time(parts, group, world, device, to="all"):
     if to == "writer":
         rank = dist.get_rank(group)
         peer = (lambda r: dist.get_global_rank(group, r)) if group else (lambda r: r)
-        wire = (lambda t: t.view(torch.uint8)) if dist.get_backend(group) != "nccl" else (lambda t: t)
         meta = torch.tensor(list(local.shape) if local is not None else [0, 0, 0, 0], dtype=torch.int64, device=device)
         metas = [torch.zeros_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta, group=group)
+        _all_gather(metas, meta, group)
         if rank != 0:
             if local is not None:
-                dist.send(wire(local.contiguous()), dst=peer(0), group=group)
+                _send(local.contiguous(), peer(0), group)
             return None
         pieces = []
         for r, m in enumerate(metas):
@@ -281,19 +392,19 @@ def _gather_time(parts, group, world, device, to="all"):
                 pieces.append(local)
                 continue
             buf = torch.empty(tuple(int(v) for v in m), dtype=torch.bfloat16, device=device)
-            dist.recv(wire(buf), src=peer(r), group=group)
+            _recv(buf, peer(r), group)
             pieces.append(buf)
         return torch.cat(pieces, dim=0)
     shape = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
     mine = torch.tensor(list(local.shape) if local is not None else [0, 0, 0, 0], dtype=torch.int64, device=device)
-    dist.all_gather(shape, mine, group=group)
+    _all_gather(shape, mine, group)
     tail = next(tuple(int(v) for v in s[1:]) for s in shape if int(s[0]) > 0)
     tmax = max(int(s[0]) for s in shape)
     pad = torch.zeros((tmax,) + tail[:-1] + (tail[-1] * 2,), dtype=torch.uint8, device=device)   # bf16 as bytes on the wire
     if local is not None:
         pad[: local.shape[0]] = local.contiguous().view(torch.uint8)
     bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
+    _all_gather(bufs, pad, group)
     return torch.cat([b[: int(s[0])] for b, s in zip(bufs, shape)], dim=0).view(torch.bfloat16)
 
 
@@ -301,7 +412,9 @@ def _bcast_from_first(t, group):
     """Every rank ends up with rank 0's tensor (bf16 moves as bytes: gloo has no bf16 wire type)."""
     src = dist.get_global_rank(group, 0) if group else 0
     wire = t.contiguous()
-    dist.broadcast(wire.view(torch.uint8) if wire.dtype == torch.bfloat16 else wire, src=src, group=group)
+    if dist.get_rank(group) != 0 and wire.data_ptr() == t.data_ptr():
+        wire = wire.clone()                     # the caller's tensor (e.g. its posterior_noise) is not overwritten with rank 0's
+    _broadcast(wire, src, group)
     return wire
 
 
@@ -353,7 +466,7 @@ def encode_sharded(vae, x, group=None):
         enc = vae._encoder
     outs, cache = _run_sharded(vae, x_cl, frame_batches(x_cl.shape[0], vae.enc_batch), world, rank, group, enc)
     moments = _gather_time(outs, group, world, vae.device)
-    vae.last_halo_bytes = cache.bytes_sent
+    vae.last_halo_bytes = vae.last_halo_bytes_encode = cache.bytes_sent
     return _SharedPosterior([moments], vae.lat, vae.dtype, group)
 
 
@@ -375,7 +488,7 @@ def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0, gather="al
         outs = [torch.nn.functional.pad(ops.conv_out_gather(o, cc, vae.conv_out_bias, torch.bfloat16).permute(1, 2, 3, 0), (0, 4 - cc)).contiguous()
                 for o in outs]
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
-    vae.last_halo_bytes = cache.bytes_sent
+    vae.last_halo_bytes = vae.last_halo_bytes_decode = cache.bytes_sent
     if gather == "none":
         if not outs:
             return None
@@ -455,8 +568,7 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
         offs.append(offs[-1] + c * hloc * 64)
 
     def a2a(out, inp, out_splits, in_splits):
-        dist.all_to_all_single(out.view(torch.uint8), inp.view(torch.uint8), [2 * v for v in out_splits], [2 * v for v in in_splits],
-                               group=group)
+        _all_to_all(out, inp, out_splits, in_splits, group)
 
     def place(dst, got, transposed):
         # got = [source rank i][hloc][rows of i][64] (or [hloc][64][rows of i]); dst = [hloc][all rows][64] (or [hloc][64][all rows])
@@ -503,7 +615,7 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     pad = torch.zeros(vmax, width, dtype=torch.bfloat16, device=dev)
     pad[: o_loc.shape[0]] = o_loc
     bufs = [torch.empty(vmax, width * 2, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, pad.view(torch.uint8), group=group)
+    _all_gather(bufs, pad.view(torch.uint8), group)
     o = torch.cat([b[:c] for b, c in zip(bufs, vcounts)], dim=0).view(torch.bfloat16)
     return ops.unpatchify(o.contiguous(), T, Cc, H, W, pt, p, tr.dtype)
 

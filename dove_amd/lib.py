@@ -48,9 +48,9 @@ XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_
 # name -> argtypes; the symbol list doubles as the export check in tests/test_abi.py
 SIGNATURES = {
     "dove_conv_igemm_bf16": [C.POINTER(ConvDesc), _VP],
-    "dove_groupnorm_stats_bf16": [_VP, _LL, _I, _F, _VP, _I, _VP, _VP],
+    "dove_groupnorm_stats_bf16": [_VP, _LL, _LL, _I, _F, _VP, _I, _VP, _VP],
     "dove_groupnorm_finalize_partials": [_VP, _LL, C.c_double, _F, _VP, _VP, _VP],
-    "dove_groupnorm_sums_bf16": [_VP, _LL, _I, _VP, _I, _VP, _VP],
+    "dove_groupnorm_sums_bf16": [_VP, _LL, _LL, _I, _VP, _I, _VP, _VP],
     "dove_groupnorm_finalize_sums": [_VP, C.c_double, _F, _VP, _VP],
     "dove_groupnorm_sums_from_partials": [_VP, _LL, _VP, _VP, _VP],
     "dove_groupnorm_apply_bf16": [_VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, C.POINTER(C.c_int), _VP],

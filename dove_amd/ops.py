@@ -183,14 +183,20 @@ def linear(x: torch.Tensor, pc: PackedConv, **kw) -> torch.Tensor:
 
 
 _gn_ws: dict = {}
+GN_WS_ROWS = 4096        # partial rows of scratch: 9 frames x 256 blocks per frame at most (csrc/norm.hip gn_partial_launch)
 
 
 def _ws(device):
     # one scratch buffer per (device, stream): the two-stream VAE mode runs GroupNorm statistics concurrently
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
     if key not in _gn_ws:
-        _gn_ws[key] = torch.empty(2048 * 64, dtype=torch.float32, device=device)
+        _gn_ws[key] = torch.empty(GN_WS_ROWS * 64, dtype=torch.float32, device=device)
     return _gn_ws[key]
+
+
+def _frame_pix(x):
+    """H*W of a [T,H,W,C] frame-batch (0 = "one frame" for anything else): the statistics kernels sum per frame share."""
+    return x.shape[1] * x.shape[2] if x.dim() == 4 else 0
 
 
 def groupnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
@@ -200,7 +206,7 @@ def groupnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
     Cc = x.shape[-1]
     stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
     ws = _ws(x.device)
-    L.check(L.load().dove_groupnorm_stats_bf16(L.ptr(x), x.numel() // Cc, Cc, eps, L.ptr(ws), 2048, L.ptr(stats),
+    L.check(L.load().dove_groupnorm_stats_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, eps, L.ptr(ws), GN_WS_ROWS, L.ptr(stats),
                                                L.stream_ptr()), "dove_groupnorm_stats_bf16")
     return stats
 
@@ -211,7 +217,7 @@ def groupnorm_sums(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == torch.bfloat16
     Cc = x.shape[-1]
     sums = torch.empty(32, 2, dtype=torch.float64, device=x.device)
-    L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, Cc, L.ptr(_ws(x.device)), 2048, L.ptr(sums),
+    L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, L.ptr(_ws(x.device)), GN_WS_ROWS, L.ptr(sums),
                                               L.stream_ptr()), "dove_groupnorm_sums_bf16")
     return sums
 
@@ -228,11 +234,12 @@ def groupnorm_sums_of(x: torch.Tensor) -> torch.Tensor:
 
 
 def groupnorm_from_sums(sums: torch.Tensor, count: float, eps: float) -> torch.Tensor:
-    """stats [32,2] (mean, rstd) from summed fp64 (sum, sumsq) over ``count`` elements per group."""
+    """stats [32,2] (mean, rstd) from summed fp64 (sum, sumsq) over ``count`` elements per group.  ``count=None``: sums is the
+    65-double message of dove_amd.dist's pair exchange, whose last entry is the element count (read on the device)."""
     L.require_cuda(sums)
-    assert sums.dtype == torch.float64 and sums.shape == (32, 2)
+    assert sums.dtype == torch.float64 and (sums.shape == (32, 2) if count is not None else sums.numel() == 65)
     stats = torch.empty(32, 2, dtype=torch.float32, device=sums.device)
-    L.check(L.load().dove_groupnorm_finalize_sums(L.ptr(sums.contiguous()), float(count), eps, L.ptr(stats), L.stream_ptr()),
+    L.check(L.load().dove_groupnorm_finalize_sums(L.ptr(sums.contiguous()), 0.0 if count is None else float(count), eps, L.ptr(stats), L.stream_ptr()),
             "dove_groupnorm_finalize_sums")
     return stats
 

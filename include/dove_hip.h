@@ -76,20 +76,23 @@ const char* dove_conv_kernel_name(const dove_conv_desc* d);
  * dove_groupnorm_stats_bf16 on the output as before) */
 long long dove_conv_gn_partial_rows(const dove_conv_desc* d);
 /* stats [32][2] (mean, rstd) from partial [rows][32][2] (deterministic two-level fp64 combine).  count = elements per
- * group = npix * C/32; ws >= 256*64 floats of scratch. */
+ * group = npix * C/32; ws >= 256*64 DOUBLES (128 KiB, 8-byte aligned) of scratch: both levels are fp64. */
 int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws, float* stats,
                                      void* stream);
 
 /* nn.GroupNorm(32, C, eps) statistics over one frame-batch [npix, C] (diffusers CogVideoXResnetBlock3D norm1/norm2,
  * encoder.norm_out, and the norm_layer inside CogVideoXSpatialNorm3D).  stats = [32][2] (mean, rstd) fp32.
- * partial_ws: >= ws_blocks*64 floats of scratch. */
-int dove_groupnorm_stats_bf16(const void* x, long long npix, int C, float eps, void* partial_ws, int ws_blocks,
+ * frame_pix = H*W of one frame (npix = frames * frame_pix; 0: treat the tensor as one frame): partial sums are formed per
+ * (frame, fixed share of the frame), so a batch split into pieces of whole frames reduces to the same statistics.
+ * partial_ws: >= ws_blocks*64 floats of scratch; ws_blocks >= frames (4096 rows never constrain a 9-frame batch). */
+int dove_groupnorm_stats_bf16(const void* x, long long npix, long long frame_pix, int C, float eps, void* partial_ws, int ws_blocks,
                               float* stats, void* stream);
 /* Distributed form (dove_amd.dist, frame-batch split over a rank pair): raw per-group (sum, sum of squares) of one piece
  * as fp64 [32][2] - the ranks add their pieces' sums (and element counts) and call the finalize below, which is the same
  * fp64 mean / rstd arithmetic the single-call form ends with. */
-int dove_groupnorm_sums_bf16(const void* x, long long npix, int C, void* partial_ws, int ws_blocks, double* sums,
+int dove_groupnorm_sums_bf16(const void* x, long long npix, long long frame_pix, int C, void* partial_ws, int ws_blocks, double* sums,
                              void* stream);
+/* count <= 0: sums has 65 entries and sums[64] is the element count (the message two ranks of a split frame-batch exchange and add) */
 int dove_groupnorm_finalize_sums(const double* sums, double count, float eps, float* stats, void* stream);
 /* the same raw sums from the partial rows a conv epilogue wrote (dove_conv_desc.gn_partial): no pass over the tensor */
 int dove_groupnorm_sums_from_partials(const float* partial, long long rows, void* ws, double* sums, void* stream);

@@ -627,3 +627,164 @@ def test_linear_mxfp8(M, N, K, act, resid, gate):
         rel = float((got.float().cpu() - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt())
         print(f"[mxfp8 {M}x{N}x{K}] rms-rel vs the unquantised product {rel:.3e}")
         assert rel < 6e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Production shapes (BASELINE configs[1]: 33x720x1280) against torch-CPU fp32 on SAMPLED outputs.  The property tests above
+# (determinism, homogeneity, causality) cannot see a deterministic, homogeneous indexing bug that only appears with > 256
+# persistent tiles, 720-row frames or N = 18 226; these compare real values at the positions such a bug would hit: image
+# borders, tile seams, the first / last persistent round, the rows either side of the GEMM tail split.
+# Reference ops: the CogVideoXCausalConv3d / Upsample3D / Linear / SDPA calls behind /root/reference/inference_script.py:408,
+# 483-489, 500.  The reference value is computed here with plain F.conv3d / F.conv2d / matmul / softmax (not tests/emu_ops.py).
+# ------------------------------------------------------------------------------------------------------------------------
+def _bands(H, picks):
+    """[(r0, r1)] inclusive row bands around the picked rows (2 rows each), clipped to the image."""
+    return [(max(0, r), min(H - 1, r + 1)) for r in picks]
+
+
+def test_prodshape_conv3d_128_cache_resid_sampled():
+    """128 -> 128 3x3x3 causal conv on one 8 x 720 x 1280 frame-batch with a 2-frame conv cache and the residual epilogue (the
+    second conv of an encoder L0 / decoder L3 resnet: 36 of the clip's 268 halo4x launches have exactly this shape)."""
+    import torch.nn.functional as F
+    T, H, W, Cc = 8, 720, 1280, 128
+    g = torch.Generator(device="cuda").manual_seed(101)
+    gw = torch.Generator().manual_seed(102)
+    w = (torch.randn(Cc, Cc, 3, 3, 3, generator=gw) * (Cc * 27) ** -0.5).to(BF).float()
+    b = torch.randn(Cc, generator=gw) * 0.1
+    pc = ops.pack_conv(w, b, "cuda")
+    x = torch.randn(T, H, W, Cc, device="cuda", generator=g).to(BF)
+    cache = torch.randn(2, H, W, Cc, device="cuda", generator=g).to(BF)
+    resid = torch.randn(T, H, W, Cc, device="cuda", generator=g).to(BF)
+    y = ops.conv(x, pc, cache=cache, resid=resid)
+    assert ops.conv_kernel_name(x.shape, pc, resid=True) == "conv3x3_halo4x_kernel"
+    torch.cuda.synchronize()
+    xin = torch.cat([cache, x], dim=0)                            # frame t of the output reads xin[t : t + 3]
+    # rows: image top / bottom, the seams of the 16-row tiles (15|16, 351|352), the last full tile row (703|704); frames 0, 3, 7
+    for t in (0, 3, 7):
+        for r0, r1 in _bands(H, (0, 15, 351, 703, 718)):
+            rows = r1 - r0 + 1
+            slab = torch.zeros(3, rows + 2, W + 2, Cc, device="cuda")
+            a, bnd = max(r0 - 1, 0), min(r1 + 2, H)
+            slab[:, a - (r0 - 1): a - (r0 - 1) + (bnd - a), 1:W + 1] = xin[t:t + 3, a:bnd].float()
+            ref = F.conv3d(slab.cpu().permute(3, 0, 1, 2)[None], w, b)[0, :, 0].permute(1, 2, 0)      # [rows, W, Cc]
+            ref = (ref + resid[t, r0:r1 + 1].float().cpu()).to(BF)
+            close(f"prod_conv3d t{t} rows {r0}-{r1}", y[t, r0:r1 + 1], ref)
+
+
+@pytest.mark.parametrize("tmode,T_in,t_out", [(0, 8, 8), (1, 4, 8)])
+def test_prodshape_upsample_conv_256_sampled(tmode, T_in, t_out):
+    """Upsample-fused 256 -> 256 3x3 conv, 360 x 640 -> 720 x 1280 (CogVideoXUpsample3D of decoder up-block 2: the nearest x2
+    resize lives in the conv's addressing).  tmode 1 also doubles the frames (frame t reads input frame t >> 1)."""
+    import torch.nn.functional as F
+    H, W, Cc = 360, 640, 256
+    g = torch.Generator(device="cuda").manual_seed(111)
+    gw = torch.Generator().manual_seed(112)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=gw) * (Cc * 9) ** -0.5).to(BF).float()
+    b = torch.randn(Cc, generator=gw) * 0.1
+    pc = ops.pack_conv(w, b, "cuda")
+    x = torch.randn(T_in, H, W, Cc, device="cuda", generator=g).to(BF)
+    y = ops.conv(x, pc, up=1, pad=(1, 1), tmode=tmode, t_out=t_out)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == (t_out, 2 * H, 2 * W, Cc)
+    H2, W2 = 2 * H, 2 * W
+    cidx = torch.arange(-1, W2 + 1, device="cuda")
+    cval = ((cidx >= 0) & (cidx < W2)).float()
+    for t in (0, t_out // 2, t_out - 1):
+        src = x[E._frame_index(t, tmode)].float()
+        for r0, r1 in _bands(H2, (0, 15, 351, 703, 718)):
+            ridx = torch.arange(r0 - 1, r1 + 2, device="cuda")
+            rval = ((ridx >= 0) & (ridx < H2)).float()
+            slab = src[(ridx.clamp(0, H2 - 1) >> 1)][:, (cidx.clamp(0, W2 - 1) >> 1)] * rval[:, None, None] * cval[None, :, None]
+            ref = F.conv2d(slab.cpu().permute(2, 0, 1)[None], w, b)[0].permute(1, 2, 0).to(BF)           # [rows, W2, Cc]
+            close(f"prod_upconv tmode{tmode} t{t} rows {r0}-{r1}", y[t, r0:r1 + 1], ref)
+
+
+def test_prodshape_dit_linears_sampled():
+    """The DiT's two extreme linears at N = 18 226 rows: qkv (3072 -> 9216, + bias; 2592 tiles = 10 full rounds of gemm4x + a 50-row
+    tail on igemm_fast) and ff2 (12 288 -> 3072 with the gated in-place residual, text / video gate rows split at 226; 864 tiles =
+    16 384 rows on gemm4x + 1842 on the tail kernel).  Sampled rows: first / last, the 256-row tile seams, both sides of the gate's
+    row-class boundary and of each tail split."""
+    N = 18226
+    g = torch.Generator(device="cuda").manual_seed(121)
+    gw = torch.Generator().manual_seed(122)
+    rows = torch.tensor([0, 1, 225, 226, 227, 255, 256, 257, 4095, 4096, 9999, 16383, 16384, 16385, 18175, 18176, 18177, 18224, 18225])
+    # qkv
+    w = (torch.randn(9216, 3072, generator=gw) * 3072 ** -0.5).to(BF).float()
+    b = torch.randn(9216, generator=gw) * 0.1
+    pl = ops.pack_conv(w, b, "cuda")
+    x = torch.randn(N, 3072, device="cuda", generator=g).to(BF)
+    z = ops.linear(x, pl)
+    torch.cuda.synchronize()
+    ref = (x[rows.cuda()].float().cpu() @ w.t() + b).to(BF)
+    close("prod_linear_qkv", z[rows.cuda()], ref)
+    del z, pl, w
+    # ff2, gated residual in place
+    w = (torch.randn(3072, 12288, generator=gw) * 12288 ** -0.5).to(BF).float()
+    b = torch.randn(3072, generator=gw) * 0.1
+    pl = ops.pack_conv(w, b, "cuda")
+    x = torch.randn(N, 12288, device="cuda", generator=g).to(BF)
+    hs = torch.randn(N, 3072, device="cuda", generator=g).to(BF)
+    gate = torch.randn(2, 3072, generator=gw)
+    hs0 = hs[rows.cuda()].float().cpu()
+    out = ops.linear(x, pl, resid=hs, gate=gate.cuda().contiguous(), gate_split=226, out=hs)
+    torch.cuda.synchronize()
+    gsel = gate[(rows >= 226).long()]
+    ref = (hs0 + gsel * (x[rows.cuda()].float().cpu() @ w.t() + b)).to(BF)
+    close("prod_linear_ff2_gated", out[rows.cuda()], ref)
+
+
+def _sample_queries(N):
+    return torch.tensor([0, 1, 31, 32, 127, 128, 129, 4095, 4096, 9000, 9001, 18175, 18176, 18207, 18208, 18224, 18225])
+
+
+def test_prodshape_attention_18226_sampled():
+    """bf16 flash attention at the headline sequence length (285 KV tiles, ragged last tile of 50 keys, 143 query blocks of 128) on
+    2 heads, against the exact fp32 softmax attention of the same bf16 operands at sampled query rows."""
+    N, heads = 18226, 2
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator().manual_seed(131)
+    q = (torch.randn(heads, N, 64, generator=g) * 0.5).to(BF)          # Qh carries scale * log2(e): scores ~ N(0, 4) in base 2
+    k = torch.randn(heads, N, 64, generator=g).to(BF)
+    v = torch.randn(heads, 64, N, generator=g).to(BF)
+    Q = torch.zeros(heads, npad, 64, dtype=BF)
+    K = torch.zeros(heads, npad, 64, dtype=BF)
+    V = torch.zeros(heads, 64, npad, dtype=BF)
+    Q[:, :N], K[:, :N], V[:, :, :N] = q, k, v
+    E.vt_quad_swap(V)
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
+    torch.cuda.synchronize()
+    rows = _sample_queries(N)
+    p = torch.softmax(torch.einsum("hqd,hkd->hqk", q.float()[:, rows], k.float()) * math.log(2.0), dim=-1)
+    ref = torch.einsum("hqk,hdk->hqd", p, v.float()).permute(1, 0, 2).reshape(len(rows), heads * 64).to(BF)
+    close("prod_attention_18226", got[rows.cuda()], ref, rtol=3e-2, afrac=8e-3)
+
+
+def test_prodshape_attention_mx_18226_sampled():
+    """The MXFP8 attention of BASELINE configs[4] at N = 18 226 (its design argument - per-(query, tile) probability scales - is made
+    for this length): against the exact softmax attention over the DEQUANTISED fp8 operands, so that what is measured is the
+    kernel (P quantisation + accumulation), at sampled query rows; tolerance of test_attention_mx_spike_and_flat_tail."""
+    N, heads = 18226, 2
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator().manual_seed(141)
+    q = torch.randn(heads, N, 64, generator=g) * 0.5
+    k = torch.randn(heads, N, 64, generator=g)
+    v = torch.randn(heads, 64, N, generator=g)
+    Q8, K8, V8, Vs = _mx_bufs(heads, npad)
+    Q8[:, :N] = (q * 8).to(torch.float8_e4m3fn).view(torch.uint8)
+    K8[:, :N] = k.to(torch.float8_e4m3fn).view(torch.uint8)
+    vp = torch.zeros(heads * 64, npad)
+    vp[:, :N] = v.reshape(heads * 64, N)
+    vq, ve = E.mx_quant_ref(vp)
+    V8.copy_(E.v8_store_order(vq.view(torch.uint8).reshape(heads, 64, npad)))
+    Vs.copy_(ve.reshape(heads, 64, npad // 64, 2).permute(0, 2, 1, 3))
+    got = ops.attention_mx(Q8.cuda(), K8.cuda(), V8.cuda(), Vs.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
+    torch.cuda.synchronize()
+    rows = _sample_queries(N)
+    qd, kd = _fp8(Q8)[:, :N] * 0.125, _fp8(K8)[:, :N]
+    vd = E.mx_dequant(vq, ve).reshape(heads, 64, npad)[:, :, :N]
+    p = torch.softmax(torch.einsum("hqd,hkd->hqk", qd[:, rows], kd) * math.log(2.0), dim=-1)
+    exact = torch.einsum("hqk,hdk->hqd", p, vd).permute(1, 0, 2).reshape(len(rows), heads * 64)
+    close("prod_attention_mx_18226", got[rows.cuda()], exact.to(BF), rtol=4e-2, afrac=1.5e-2)
+    rel = float((got[rows.cuda()].float().cpu() - exact).pow(2).mean().sqrt() / exact.pow(2).mean().sqrt())
+    print(f"attention_mx N=18226 sampled rows: rel RMS error vs exact (dequantised operands) {rel:.4f}")
+    assert rel < 6e-2, rel

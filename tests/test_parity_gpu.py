@@ -128,6 +128,32 @@ def test_e2e_256_full_model_stagewise(full):
     assert p > 30.0, p
 
 
+def test_e2e_256_north_star_tolerance_vs_bf16_reference(full):
+    """BASELINE.json north_star: "PSNR within 0.05 dB of the reference".  The reference computes in bf16 (diffusers modules in
+    torch.bfloat16, ref :525/:613), so its own distance from exact arithmetic is the yardstick: the oracle re-run with
+    dtype=bfloat16 (every torch op in bf16, like diffusers) on the SAME clip, weights and noise - whole operator, 42 layers,
+    configs[0] size, un-saturated output.  Gates: PSNR(hip, fp32) >= PSNR(bf16 reference, fp32) - 0.05 dB, and every stage
+    (moments, latent, velocity, x0, decoded) at most 1.25 x the bf16 reference's own error (+1e-3 absolute)."""
+    pipe, (v, t, s), text, video, noise, ref, tr32 = (full[k] for k in ("pipe", "cfg", "text", "video", "noise", "ref", "tr32"))
+    t0 = time.time()
+    trbf = {}
+    refbf = odit.process_video(OracleVAE(v, full["wv"], torch.bfloat16), odit.OracleDiT(t, full["wt"].moved("cpu"), torch.bfloat16), s,
+                               video, text[None], noise, trace=trbf)
+    print(f"[tol] bf16-emulated oracle, whole operator 9x256x256 / 42 layers: {time.time() - t0:.1f} s")
+    st = hip_stages(pipe, video.cuda(), text, noise.cuda())
+    got = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda())
+    torch.cuda.synchronize()
+    p_hip, p_bf = psnr(got.float().cpu(), ref), psnr(refbf.float(), ref)
+    keys = ("moments", "latent", "v", "x0", "decoded")
+    eh = {k: rms_rel(st[k], tr32[k]) for k in keys}
+    eb = {k: rms_rel(trbf[k], tr32[k]) for k in keys}
+    print(f"[tol] PSNR vs fp32 oracle: hip {p_hip:.3f} dB, bf16 reference {p_bf:.3f} dB (hip - ref = {p_hip - p_bf:+.3f} dB)")
+    print("[tol] rms-rel vs fp32 oracle (hip | bf16 reference): " + "  ".join(f"{k}:{eh[k]:.2e}|{eb[k]:.2e}" for k in keys))
+    assert p_hip >= p_bf - 0.05, (p_hip, p_bf)
+    for k in keys:
+        assert eh[k] <= 1.25 * eb[k] + 1e-3, (k, eh[k], eb[k])
+
+
 def test_dit_42_layers_per_block(full):
     """DiT only, IDENTICAL input (the oracle's own latent), every block's residual stream compared with the fp32 oracle
     and with the reference's bf16 behaviour (oracle dtype=bfloat16) as the yardstick: error growth over the 42 gated
