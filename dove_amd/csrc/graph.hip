@@ -308,6 +308,7 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   else CHK(alloc_t(c, t_out, ho, wo, o.out_f32 ? 2 * ldo : ldo, &y));
   dove_conv_desc d;
   memset(&d, 0, sizeof(d));
+  d.struct_size = (unsigned)sizeof(d);
   d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
   d.t_in = x.T; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();

@@ -25,6 +25,16 @@
 #include "common.h"
 #include "../../include/dove_hip.h"
 
+// tools/*_timing.py hand a device buffer to the NEXT conv call (per-phase s_memtime logs / ablation operands).  It used to be a field
+// of dove_conv_desc; the product struct no longer carries it - the hook exists in libdove_hip_timing.so only.
+#ifdef DOVE_TIMING_BUILD
+static void* g_timing_debug_buf = nullptr;
+extern "C" int dove_timing_set_debug_buf(void* p) { g_timing_debug_buf = p; return 0; }
+#define DOVE_DBG_BUF g_timing_debug_buf
+#else
+#define DOVE_DBG_BUF ((void*)nullptr)
+#endif
+
 // Work-skipping ablation switches and s_memtime phase logs exist ONLY in a -DDOVE_TIMING_BUILD library (built by the
 // tools/*_timing.py helpers into a separate file); in the product build DOVE_DBG() is the constant 0, the branches fold
 // away, no timing instantiation is emitted and no environment variable can make a kernel skip work.
@@ -1932,7 +1942,14 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
 }
 
 /* name of the kernel a call would dispatch to (reporting: bench.py's per-kernel roofline; tests pin the production shapes) */
-extern "C" const char* dove_conv_kernel_name(const dove_conv_desc* d) { return d ? kKernelNames[select_kernel(d)] : ""; }
+static bool desc_size_ok(const dove_conv_desc* d, const char* who) {
+  if (d && d->struct_size == sizeof(dove_conv_desc) && d->reserved == 0) return true;
+  if (d) dove_set_error("%s: dove_conv_desc.struct_size is %u, this library (ABI %d) expects %zu - the caller's binding was written "
+                        "against another include/dove_hip.h", who, d->struct_size, DOVE_ABI_VERSION, sizeof(dove_conv_desc));
+  else dove_set_error("%s: null descriptor", who);
+  return false;
+}
+extern "C" const char* dove_conv_kernel_name(const dove_conv_desc* d) { return desc_size_ok(d, "conv_kernel_name") ? kKernelNames[select_kernel(d)] : ""; }
 
 template <int BN, int BK>
 static int launch_igemm(const IgemmArgs& a, unsigned grid, bool fast, hipStream_t s) {
@@ -1963,7 +1980,7 @@ static int cu_count() {
 }
 
 extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
-  if (!d) return 0;
+  if (!desc_size_ok(d, "conv_gn_partial_rows")) return 0;
   const ConvKernel k = select_kernel(d);
   if (k != K_HALO4X && k != K_HALO4X_UP) return 0;
   if (d->cout_store != 128 && d->cout_store != 256 && d->cout_store != 512) return 0;   // 4 / 8 / 16 channels per group
@@ -1996,7 +2013,8 @@ static bool gemm4x_tail_split(const dove_conv_desc* d, long long* rows_main) {
 }
 
 extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
-  DOVE_CHECK_ARG(d && d->x && d->w && d->out, "conv_igemm: null pointer");
+  if (!desc_size_ok(d, "conv_igemm")) return DOVE_EINVAL;
+  DOVE_CHECK_ARG(d->x && d->w && d->out, "conv_igemm: null pointer");
   DOVE_CHECK_ARG(d->cin % 32 == 0 && d->cin > 0, "conv_igemm: Cin (%d) must be a positive multiple of 32 (pad on pack)", d->cin);
   DOVE_CHECK_ARG(d->cout_pad % 32 == 0 && d->cout_pad > 0, "conv_igemm: Cout_pad (%d) must be a multiple of 32", d->cout_pad);
   DOVE_CHECK_ARG(d->cout_store % 4 == 0 && d->cout_store <= d->cout_pad && d->cout_store > 0, "conv_igemm: bad cout_store %d", d->cout_store);
@@ -2014,7 +2032,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(!d->out_f32 || (kern0 == K_IGEMM_FAST && !d->resid && d->act == 0),
                  "conv_igemm: out_f32 is only implemented for plain convs that dispatch to igemm_fast_kernel");
   long long rows_main = 0;
-  if (kern0 == K_GEMM4X && !d->debug_buf && gemm4x_tail_split(d, &rows_main)) {
+  if (kern0 == K_GEMM4X && !DOVE_DBG_BUF && gemm4x_tail_split(d, &rows_main)) {
     dove_conv_desc m = *d, t = *d;
     m.w_in = m.w_out = (int)rows_main;
     const long long tail = (long long)d->w_out - rows_main;
@@ -2026,7 +2044,11 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     const int rc = conv_dispatch(&m, stream, K_GEMM4X);
     return rc ? rc : conv_dispatch(&t, stream, K_IGEMM_FAST);
   }
-  return conv_dispatch(d, stream, kern0);
+  const int rc = conv_dispatch(d, stream, kern0);
+#ifdef DOVE_TIMING_BUILD
+  g_timing_debug_buf = nullptr;     // one call only
+#endif
+  return rc;
 }
 
 static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern) {
@@ -2067,13 +2089,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const int cus = cu_count();
       const unsigned grid4 = nt > cus ? (unsigned)cus : (unsigned)nt;
 #ifdef DOVE_TIMING_BUILD
-      if (d->debug_buf && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
+      if (DOVE_DBG_BUF && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
         static bool attrt = false;
         if (!attrt) {
           (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
           attrt = true;
         }
-        a.zero = (const bf16_t*)d->debug_buf;
+        a.zero = (const bf16_t*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
       } else
 #endif
@@ -2128,8 +2150,8 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const int cus = cu_count();                              // persistent: one workgroup per CU walks its share of the tiles
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
 #ifdef DOVE_TIMING_BUILD
-      if (d->debug_buf && kern == K_HALO4X) {                   // tools/halo4x_timing.py
-        a.gate = (const float*)d->debug_buf;
+      if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/halo4x_timing.py
+        a.gate = (const float*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif
@@ -2155,8 +2177,8 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
 #ifdef DOVE_TIMING_BUILD
-      if (d->debug_buf && kern == K_HALO8) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
-        a.gate = (const float*)d->debug_buf;
+      if (DOVE_DBG_BUF && kern == K_HALO8) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
+        a.gate = (const float*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
       } else
 #endif

@@ -15,16 +15,23 @@ F32, BF16 = 0, 1
 
 
 class ConvDesc(C.Structure):
+    """dove_conv_desc (include/dove_hip.h).  ``struct_size`` is filled in on construction: the library refuses a descriptor whose
+    size is not the one it was built with (a stale binding would otherwise have its missing tail fields read from stray memory)."""
     _fields_ = [
+        ("struct_size", C.c_uint), ("reserved", C.c_uint),
         ("x", C.c_void_p), ("cache", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p),
         ("resid", C.c_void_p), ("gate", C.c_void_p), ("out", C.c_void_p),
         ("t_in", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("cin", C.c_int),
         ("t_out", C.c_int), ("h_out", C.c_int), ("w_out", C.c_int), ("cout_pad", C.c_int), ("cout_store", C.c_int),
         ("kt", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad_h", C.c_int), ("pad_w", C.c_int),
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
-        ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong), ("debug_buf", C.c_void_p),
+        ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
         ("gn_partial", C.c_void_p), ("out_f32", C.c_int),
     ]
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(ConvDesc)
 
 
 class ModelConfig(C.Structure):

@@ -129,7 +129,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     d.ldo = ldo
     d.ldr = resid.shape[-1] if resid is not None else 0
     d.gate_split = gate_split
-    d.debug_buf = debug_buf.data_ptr() if debug_buf is not None else None
+    if debug_buf is not None:      # tools/*_timing.py only: exists in libdove_hip_timing.so, an AttributeError on the product library
+        L.load().dove_timing_set_debug_buf(C.c_void_p(debug_buf.data_ptr()))
     d.out_f32 = int(out_f32)
     if resid is not None:
         assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]

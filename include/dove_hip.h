@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 9
+#define DOVE_ABI_VERSION 10
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -46,6 +46,11 @@ int dove_device_info(int dev, char* name, int name_len, int* cu_count, long long
  *   epilogue: v = acc + bias; act==1: gelu(tanh); resid: v = resid + (gate ? gate[class][c] * v : v), where
  *   class = (flat output pixel index < gate_split) ? 0 : 1 and gate is [2][cout_pad] fp32 (AdaLN-Zero gates). */
 typedef struct dove_conv_desc {
+  /* = sizeof(dove_conv_desc) of the header the CALLER was built against.  The descriptor is caller-allocated and grows with the
+   * ABI (gn_partial at 2, out_f32 at 8): a binding written against an older header would hand over a shorter struct and the new
+   * fields would be read from whatever follows it.  Every entry point that takes a descriptor rejects a size other than its own. */
+  unsigned int struct_size;
+  unsigned int reserved; /* 0 */
   const void* x;
   const void* cache;
   const void* w;
@@ -57,7 +62,6 @@ typedef struct dove_conv_desc {
   int t_out, h_out, w_out, cout_pad, cout_store;
   int kt, kh, kw, stride, pad_h, pad_w, up, tmode, act;
   long long ldo, ldr, gate_split;
-  void* debug_buf; /* NULL in production; tools/halo8_timing.py passes a device buffer for the phase-timing build */
   /* optional fused GroupNorm(32) statistics of `out` (the nn.GroupNorm that consumes this conv's output in
    * CogVideoXResnetBlock3D / CogVideoXSpatialNorm3D): fp32 [dove_conv_gn_partial_rows(d)][32][2] partial (sum, sum of
    * squares) per group over the bf16-rounded stored values; reduce with dove_groupnorm_finalize_partials.  Only the

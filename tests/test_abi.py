@@ -35,10 +35,25 @@ def test_binding_covers_header():
 
 
 def test_version_and_error_channel(lib):
-    assert lib.dove_abi_version() == 9
+    assert lib.dove_abi_version() == 10
     # argument validation happens before any HIP call, so it is safe without a GPU
     rc = lib.dove_axpby(None, None, None, 0, 0, 1.0, 1.0, None)
     assert rc == -1 and b"axpby" in lib.dove_last_error()
+
+
+def test_conv_desc_struct_size_is_checked(lib):
+    """dove_conv_desc is caller-allocated and grows with the ABI: every entry point that takes one refuses a struct_size other than
+    its own sizeof (a binding written against an older header would have its missing tail fields read from stray memory)."""
+    import ctypes as C
+    d = L.ConvDesc()
+    assert d.struct_size == C.sizeof(L.ConvDesc) and C.sizeof(L.ConvDesc) % 8 == 0
+    d.x = d.w = d.out = 1
+    d.struct_size -= 8                                           # what a pre-ABI-8 binding (no out_f32) would have passed
+    assert lib.dove_conv_igemm_bf16(C.byref(d), None) == -1 and b"struct_size" in lib.dove_last_error()
+    assert lib.dove_conv_kernel_name(C.byref(d)) == b"" and int(lib.dove_conv_gn_partial_rows(C.byref(d))) == 0
+    d.struct_size = 0
+    assert lib.dove_conv_igemm_bf16(C.byref(d), None) == -1
+    assert not hasattr(L.ConvDesc, "debug_buf") and not hasattr(lib, "dove_timing_set_debug_buf")      # timing hook: timing library only
 
 
 def test_dispatch_rule_mirror(lib):
