@@ -163,10 +163,12 @@ struct Arena {
   }
 };
 
+struct PackedMx { uint8_t* q = nullptr; uint32_t* s = nullptr; float* bias = nullptr; int rows = 0, K = 0; };   // dove_mx_quant_bf16 layout
 struct DitBlock {
   bf16_t *mod1_w, *mod2_w; float *mod1_b, *mod2_b;      // norm1.linear / norm2.linear (M = 1 GEMV operands)
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *nq_g, *nq_b, *nk_g, *nk_b;
   Packed qkv, out, ff1, ff2;
+  PackedMx qkv8, out8, ff18, ff28;                      // DOVE_OPT_DIT_LINEAR_MXFP8: the same four linears in MXFP8 (bf16 copies freed)
   float *m1 = nullptr, *g1 = nullptr, *m2 = nullptr, *g2 = nullptr;   // per-timestep: mod [2][2][D], gate [2][D]
 };
 
@@ -203,6 +205,12 @@ struct dove_ctx {
   dove_xfer_fn send_fn = nullptr, recv_fn = nullptr; void* xfer_user = nullptr;
   void* rccl_lib = nullptr; void* rccl_comm = nullptr;
   bool halo_recv = false, halo_send = false;            // set by the batch loop around the rank's first / last batch
+  // options (dove_set_option)
+  bool opt_tiling = false, opt_linear_mx = false, opt_attn_mx = false;
+  int sample_h = 480, sample_w = 720;                   // vae/config.json sample_height / sample_width: tile geometry of enable_tiling()
+  bool direct_io_convs = false;                         // inside a spatial tile: conv_in / conv_out in their direct forms (dove_amd/vae.py)
+  uint8_t *Q8 = nullptr, *K8 = nullptr, *V8 = nullptr, *Vs8 = nullptr; long long attn8_n = 0;   // MXFP8 attention operands
+  int depth = 0;                                        // nesting of stage entry points (dove_sr_clip calls the others)
 };
 
 namespace {
@@ -276,6 +284,23 @@ int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<
     q.bias = (float*)bp;
   }
   *out = q;
+  return 0;
+}
+// nn.Linear weight [N][K] bf16 (a Packed of a 1x1x1 "conv") -> MXFP8 operand; the bf16 block is freed
+int to_mx(dove_ctx* c, Packed* pc, PackedMx* out) {
+  if (pc->cout_pad != pc->cout || pc->cin_pad != pc->cin || pc->cin % 256 || pc->cout % 256) {
+    dove_set_error("MXFP8 linear: weight [%d][%d] must have N and K multiples of 256", pc->cout, pc->cin);
+    return DOVE_EINVAL;
+  }
+  out->rows = pc->cout; out->K = pc->cin; out->bias = pc->bias;
+  void* q; void* sc;
+  CHK(dev_alloc(c, (size_t)out->rows * out->K, &q));
+  CHK(dev_alloc(c, (size_t)(out->K / 256) * out->rows * 2 * 4, &sc));
+  out->q = (uint8_t*)q; out->s = (uint32_t*)sc;
+  CHK(dove_mx_quant_bf16(pc->w, out->rows, out->K, out->q, out->s, nullptr));
+  HIPCHK(hipStreamSynchronize(nullptr));
+  for (auto it = c->owned.begin(); it != c->owned.end(); ++it)
+    if (*it == (void*)pc->w) { (void)hipFree(pc->w); c->owned.erase(it); pc->w = nullptr; break; }
   return 0;
 }
 bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
@@ -486,11 +511,22 @@ int resnet(dove_ctx* c, Tensor* x, float** xstats, const std::string& name, cons
   *x = y; *xstats = ys;
   return 0;
 }
+void clear_caches(dove_ctx* c);
+// Every top-level stage call starts from an empty arena: a stage that returned early on an error (e.g. "workspace exhausted") used to
+// leave its blocks live for good - the workspace shrank for every later call and a library-owned arena could never be regrown.
+struct StageGuard {
+  dove_ctx* c;
+  explicit StageGuard(dove_ctx* ctx) : c(ctx) {
+    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; }
+  }
+  ~StageGuard() { if (c) --c->depth; }
+};
+
 int encoder(dove_ctx* c, const Tensor& x, Tensor* out, void* stream) {
   const auto& cf = c->cfg;
   Tensor h; float* hs = nullptr;
   Tensor xin = x;
-  CHK(cconv(c, xin, false, c->pc.count("encoder.conv_in.taps") ? "encoder.conv_in.taps" : "encoder.conv_in", ConvOpt(), &h, stream));
+  CHK(cconv(c, xin, false, (!c->direct_io_convs && c->pc.count("encoder.conv_in.taps")) ? "encoder.conv_in.taps" : "encoder.conv_in", ConvOpt(), &h, stream));
   char nm[128];
   int n_tdown = 0;
   for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
@@ -545,7 +581,7 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
   Tensor n;
   CHK(norm_silu(c, h, hs, "decoder.norm_out", &z, &n, stream));
   free_t(c, h);
-  if (c->conv_out_bias) {                                      // tap-split conv_out: fp32 partial planes for dove_conv_out_gather
+  if (c->conv_out_bias && !c->direct_io_convs) {               // tap-split conv_out: fp32 partial planes for dove_conv_out_gather
     ConvOpt ot; ot.out_f32 = true;
     CHK(cconv(c, n, true, "decoder.conv_out.taps", ot, out, stream));
   } else {
@@ -654,6 +690,7 @@ extern "C" void dove_destroy(dove_ctx* c) {
   for (void* p : c->owned) (void)hipFree(p);
   if (c->rope_dev) (void)hipFree(c->rope_dev);
   if (c->Qh) { (void)hipFree(c->Qh); (void)hipFree(c->Kh); (void)hipFree(c->Vt); }
+  if (c->Q8) { (void)hipFree(c->Q8); (void)hipFree(c->K8); (void)hipFree(c->V8); (void)hipFree(c->Vs8); }
   if (c->arena.owned && c->arena.base) (void)hipFree(c->arena.base);
   delete c;
 }
@@ -756,6 +793,43 @@ extern "C" int dove_shard_frames(dove_ctx* c, int stage, int n, int* first, int*
   return DOVE_OK;
 }
 
+extern "C" int dove_comm_useful_ranks(dove_ctx* c, int stage, int n) {
+  if (!c || n < 1 || (stage != 0 && stage != 1)) return 0;
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(n, stage == 0 ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch, &fb);
+  return (int)fb.size();
+}
+
+extern "C" int dove_set_option(dove_ctx* c, int option, long long value) {
+  DOVE_CHECK_ARG(c, "dove_set_option: null context");
+  switch (option) {
+    case DOVE_OPT_VAE_TILING: c->opt_tiling = value != 0; return DOVE_OK;
+    case DOVE_OPT_VAE_SAMPLE_HEIGHT:
+    case DOVE_OPT_VAE_SAMPLE_WIDTH:
+      DOVE_CHECK_ARG(value >= 32 && value % 16 == 0 && value <= (1 << 16), "dove_set_option: sample size %lld must be a multiple of 16 in [32, 65536]", value);
+      (option == DOVE_OPT_VAE_SAMPLE_HEIGHT ? c->sample_h : c->sample_w) = (int)value;
+      return DOVE_OK;
+    case DOVE_OPT_DIT_LINEAR_MXFP8:
+      DOVE_CHECK_ARG(!c->finalized || (value != 0) == c->opt_linear_mx,
+                     "dove_set_option: DOVE_OPT_DIT_LINEAR_MXFP8 must be chosen before dove_finalize_weights (the weights are quantised there)");
+      c->opt_linear_mx = value != 0; return DOVE_OK;
+    case DOVE_OPT_DIT_ATTN_MXFP8: c->opt_attn_mx = value != 0; return DOVE_OK;
+    default: break;
+  }
+  dove_set_error("dove_set_option: unknown option %d", option);
+  return DOVE_EINVAL;
+}
+extern "C" long long dove_get_option(dove_ctx* c, int option) {
+  if (!c) return -1;
+  switch (option) {
+    case DOVE_OPT_VAE_TILING: return c->opt_tiling;
+    case DOVE_OPT_VAE_SAMPLE_HEIGHT: return c->sample_h;
+    case DOVE_OPT_VAE_SAMPLE_WIDTH: return c->sample_w;
+    case DOVE_OPT_DIT_LINEAR_MXFP8: return c->opt_linear_mx;
+    case DOVE_OPT_DIT_ATTN_MXFP8: return c->opt_attn_mx;
+    default: return -1;
+  }
+}
 extern "C" int dove_set_weight(dove_ctx* c, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype) {
   DOVE_CHECK_ARG(c && name && dev_ptr && shape && ndim >= 1 && ndim <= 5, "dove_set_weight: bad argument");
   DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "dove_set_weight: dtype must be DOVE_F32 or DOVE_BF16");
@@ -841,6 +915,9 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
     CHK(pack(c, {p + "attn1.to_out.0.weight"}, {p + "attn1.to_out.0.bias"}, &k.out));
     CHK(pack(c, {p + "ff.net.0.proj.weight"}, {p + "ff.net.0.proj.bias"}, &k.ff1));
     CHK(pack(c, {p + "ff.net.2.weight"}, {p + "ff.net.2.bias"}, &k.ff2));
+    if (c->opt_linear_mx) {          // dove_amd.ops.pack_linear_mx: the bf16-rounded weight quantised on the GPU; the bf16 copy is dropped
+      CHK(to_mx(c, &k.qkv, &k.qkv8)); CHK(to_mx(c, &k.out, &k.out8)); CHK(to_mx(c, &k.ff1, &k.ff18)); CHK(to_mx(c, &k.ff2, &k.ff28));
+    }
     void* m;
     CHK(dev_alloc(c, (size_t)4 * D * 4, &m)); k.m1 = (float*)m; CHK(dev_alloc(c, (size_t)2 * D * 4, &m)); k.g1 = (float*)m;
     CHK(dev_alloc(c, (size_t)4 * D * 4, &m)); k.m2 = (float*)m; CHK(dev_alloc(c, (size_t)2 * D * 4, &m)); k.g2 = (float*)m;
@@ -893,6 +970,111 @@ extern "C" int dove_set_workspace(dove_ctx* c, void* dev_ptr, size_t bytes) {
 }
 extern "C" size_t dove_workspace_high_water(dove_ctx* c) { return c ? c->arena.high : 0; }
 
+
+// ---- diffusers spatial tiling (AutoencoderKLCogVideoX.enable_tiling / tiled_encode / tiled_decode; ref :643-645 `--is_vae_st`;
+// dove_amd/vae.py _tiled): every tile runs the whole frame-batched network with its own conv caches and its own GroupNorm scope,
+// tiles are cross-faded IN PLACE with their already blended upper / left neighbours, cropped and concatenated. ----
+struct TileGeom { int tile_h, tile_w, stride_h, stride_w, blend_h, blend_w, lim_h, lim_w; };
+static void tiling_geometry(const dove_ctx* c, bool enc, TileGeom* g) {
+  const int down = 1 << (c->cfg.vae_num_blocks - 1);
+  const int smin_h = c->sample_h / 2, smin_w = c->sample_w / 2;
+  const int lmin_h = (int)((double)smin_h / down), lmin_w = (int)((double)smin_w / down);
+  const double of_h = 1.0 / 6.0, of_w = 1.0 / 5.0;                       // tile_overlap_factor_height / _width
+  if (enc) {
+    g->tile_h = smin_h; g->tile_w = smin_w;
+    g->stride_h = (int)(smin_h * (1.0 - of_h)); g->stride_w = (int)(smin_w * (1.0 - of_w));
+    g->blend_h = (int)(lmin_h * of_h); g->blend_w = (int)(lmin_w * of_w);
+    g->lim_h = lmin_h - g->blend_h; g->lim_w = lmin_w - g->blend_w;
+  } else {
+    g->tile_h = lmin_h; g->tile_w = lmin_w;
+    g->stride_h = (int)(lmin_h * (1.0 - of_h)); g->stride_w = (int)(lmin_w * (1.0 - of_w));
+    g->blend_h = (int)(smin_h * of_h); g->blend_w = (int)(smin_w * of_w);
+    g->lim_h = smin_h - g->blend_h; g->lim_w = smin_w - g->blend_w;
+  }
+}
+static bool wants_tiling(const dove_ctx* c, bool enc, int H, int W) {
+  if (!c->opt_tiling) return false;
+  TileGeom g; tiling_geometry(c, enc, &g);
+  return W > g.tile_w || H > g.tile_h;
+}
+// x [T][H][W][C] channels-last -> *out [T'][H'][W'][ld] (arena block of the caller's)
+static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stream) {
+  TileGeom g; tiling_geometry(c, enc, &g);
+  DOVE_CHECK_ARG(g.stride_h > 0 && g.stride_w > 0 && g.lim_h > 0 && g.lim_w > 0, "vae tiling: degenerate tile geometry (sample size %d x %d)", c->sample_h, c->sample_w);
+  hipStream_t s = (hipStream_t)stream;
+  const int batch = enc ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch;
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(x.T, batch, &fb);
+  std::vector<std::vector<Tensor>> rows;
+  c->direct_io_convs = true;
+  int rc = 0;
+  for (int i = 0; i < x.H && !rc; i += g.stride_h) {
+    rows.emplace_back();
+    for (int j = 0; j < x.W && !rc; j += g.stride_w) {
+      const int th = std::min(g.tile_h, x.H - i), tw = std::min(g.tile_w, x.W - j);
+      Tensor xt;
+      if ((rc = alloc_t(c, x.T, th, tw, x.C, &xt))) break;
+      for (int t = 0; t < x.T && !rc; ++t)
+        rc = copy2d(xt.p + (long long)t * th * tw * x.C, (size_t)tw * x.C * 2, x.p + (((long long)t * x.H + i) * x.W + j) * x.C, (size_t)x.W * x.C * 2,
+                    (size_t)tw * x.C * 2, th, s);
+      clear_caches(c);
+      Tensor tile;                                              // [sum of the batches' frames][oh][ow][ld], allocated once the first batch says oh, ow, ld
+      int t_done = 0, t_total = 0;
+      for (auto& se : fb) t_total += enc ? enc_batch_frames(c, se.second - se.first) : dec_batch_frames(c, se.second - se.first);
+      for (auto& se : fb) {
+        if (rc) break;
+        Tensor xb = xt; xb.p = xt.p + (long long)se.first * th * tw * x.C; xb.T = se.second - se.first;
+        Tensor o;
+        if ((rc = enc ? encoder(c, xb, &o, stream) : decoder(c, xb, &o, stream))) break;
+        if (!tile.p) {
+          tile.T = t_total; tile.H = o.H; tile.W = o.W; tile.C = o.C;
+          tile.p = (bf16_t*)c->arena.alloc(tile.bytes(), true);
+          if (!tile.p) { dove_set_error("workspace exhausted (vae tile output: %zu bytes)", tile.bytes()); rc = DOVE_EINVAL; free_t(c, o); break; }
+        }
+        if (hipMemcpyAsync(tile.p + (long long)t_done * o.H * o.W * o.C, o.p, o.bytes(), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = DOVE_ELAUNCH;
+        t_done += o.T;
+        free_t(c, o);
+      }
+      clear_caches(c);
+      free_t(c, xt);
+      if (!rc && t_done != t_total) { dove_set_error("vae tiling: a tile produced %d frames, expected %d", t_done, t_total); rc = DOVE_EINVAL; }
+      rows.back().push_back(tile);
+    }
+  }
+  c->direct_io_convs = false;
+  int Ho = 0, Wo = 0;
+  if (!rc) {
+    for (size_t i = 0; i < rows.size() && !rc; ++i)
+      for (size_t j = 0; j < rows[i].size() && !rc; ++j) {
+        Tensor& t = rows[i][j];
+        if (i > 0) { const Tensor& a = rows[i - 1][j]; rc = dove_blend_edge_bf16(a.p, t.p, t.T, a.H, a.W, t.H, t.W, t.C, std::min(std::min(a.H, t.H), g.blend_h), 0, stream); }
+        if (!rc && j > 0) { const Tensor& a = rows[i][j - 1]; rc = dove_blend_edge_bf16(a.p, t.p, t.T, a.H, a.W, t.H, t.W, t.C, std::min(std::min(a.W, t.W), g.blend_w), 1, stream); }
+      }
+    for (auto& r : rows) Ho += std::min(r[0].H, g.lim_h);
+    for (auto& t : rows[0]) Wo += std::min(t.W, g.lim_w);
+  }
+  if (!rc) {
+    const Tensor& t0 = rows[0][0];
+    rc = alloc_t(c, t0.T, Ho, Wo, t0.C, out);
+    int y0 = 0;
+    for (size_t i = 0; i < rows.size() && !rc; ++i) {
+      int x0 = 0;
+      const int ch = std::min(rows[i][0].H, g.lim_h);
+      for (size_t j = 0; j < rows[i].size() && !rc; ++j) {
+        const Tensor& t = rows[i][j];
+        const int cw = std::min(t.W, g.lim_w);
+        for (int f = 0; f < t.T && !rc; ++f)
+          rc = copy2d(out->p + (((long long)f * Ho + y0) * Wo + x0) * t.C, (size_t)Wo * t.C * 2, t.p + (long long)f * t.H * t.W * t.C, (size_t)t.W * t.C * 2,
+                      (size_t)cw * t.C * 2, ch, s);
+        x0 += cw;
+      }
+      y0 += ch;
+    }
+  }
+  for (auto& r : rows) for (auto& t : r) c->arena.release(t.p);
+  return rc;
+}
+
 static int ensure_ws(dove_ctx* c, int F, int H, int W) {
   DOVE_CHECK_ARG(c && c->finalized, "context is not finalized (dove_finalize_weights)");
   HIPCHK(hipSetDevice(c->device));
@@ -908,6 +1090,19 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   const auto& cf = c->cfg;
   Tensor xcl;
   CHK(alloc_t(c, F, H, W, c->pc.at("encoder.conv_in").cin_pad, &xcl));
+  if (wants_tiling(c, true, H, W)) {
+    DOVE_CHECK_ARG(c->nranks == 1, "vae tiling is not combined with the multi-rank halo exchange");
+    CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+    int rc = tiled(c, xcl, true, moments, stream);
+    free_t(c, xcl);
+    clear_caches(c);
+    if (!rc && (moments->T != 1 + (F - 1) / cf.vae_temporal_compression || moments->H != H / 8 || moments->W != W / 8)) {
+      dove_set_error("vae tiling: stitched moments are %d x %d x %d for a %d x %d x %d clip", moments->T, moments->H, moments->W, F, H, W);
+      free_t(c, *moments);
+      rc = DOVE_EINVAL;
+    }
+    return rc;
+  }
   if (c->pc.count("encoder.conv_in.taps")) {
     CHK(dove_cl_im2col3x3_from_ncthw(x, dtype, cf.vae_in_channels, F, H, W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
   } else {
@@ -945,6 +1140,7 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
 extern "C" int dove_vae_encode(dove_ctx* c, const void* x, int dtype, int F, int H, int W, void* moments_out, int out_dtype, void* stream) {
   DOVE_CHECK_ARG(x && moments_out, "dove_vae_encode: null pointer");
   DOVE_CHECK_ARG(F >= 1 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8, "dove_vae_encode: H and W must be multiples of 8");
+  StageGuard guard(c);
   CHK(ensure_ws(c, F, H, W));
   Tensor m;
   CHK(vae_encode_cl(c, x, dtype, F, H, W, &m, stream));
@@ -993,10 +1189,28 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   DOVE_CHECK_ARG(z && video_out && T >= 1 && h >= 1 && w >= 1, "dove_vae_decode: bad argument");
   const auto& cf = c->cfg;
   const int F = dove_vae_decode_num_frames(c, T), H = 8 * h, W = 8 * w;
+  StageGuard guard(c);
   CHK(ensure_ws(c, F, H, W));
   Tensor zcl;
   CHK(alloc_t(c, T, h, w, c->pc.at("decoder.conv_in").cin_pad, &zcl));
   CHK(dove_cl_from_ncthw(z, dtype, cf.vae_latent_channels, (long long)T * h * w, zcl.C, prescale, 0.0f, zcl.p, stream));
+  if (wants_tiling(c, false, h, w)) {
+    DOVE_CHECK_ARG(c->nranks == 1, "vae tiling is not combined with the multi-rank halo exchange");
+    Tensor full;
+    int rc = tiled(c, zcl, false, &full, stream);
+    free_t(c, zcl);
+    clear_caches(c);
+    CHK(rc);
+    if (full.T != F || full.H != H || full.W != W) {
+      dove_set_error("vae tiling: stitched output is %d x %d x %d, expected %d x %d x %d", full.T, full.H, full.W, F, H, W);
+      free_t(c, full);
+      return DOVE_EINVAL;
+    }
+    rc = dove_ncthw_from_cl(full.p, full.C, cf.vae_out_channels, (long long)F * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
+                            range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, video_out, out_dtype, stream);
+    free_t(c, full);
+    return rc;
+  }
   std::vector<std::pair<int, int>> fb;
   frame_batches(T, cf.vae_dec_batch, &fb);
   clear_caches(c);
@@ -1046,6 +1260,7 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
   const auto& cf = c->cfg;
   const int p = cf.dit_patch, pt = cf.dit_patch_t, Cc = cf.dit_in_channels, D = cf.dit_heads * cf.dit_head_dim, Hh = cf.dit_heads;
   DOVE_CHECK_ARG(T % pt == 0 && h % p == 0 && w % p == 0 && L >= 1, "dove_dit_forward: T / h / w must be multiples of the patch sizes");
+  StageGuard guard(c);
   CHK(ensure_ws(c, 1 + 4 * (T - 1), 8 * h, 8 * w));
   const long long nv = (long long)(T / pt) * (h / p) * (w / p), N = L + nv, npad = ru(N, 128);
   const float *cosp, *sinp;
@@ -1072,21 +1287,50 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
   o = ConvOpt(); o.out = hs + (size_t)L * D; CHK(linear(c, tok, nv, c->pe_proj, o, &dummy, stream));
   c->arena.release(tok);
   const float qscale = (1.0f / sqrtf((float)cf.dit_head_dim)) * 1.4426950408889634f;
+  if (c->opt_attn_mx && c->attn8_n != N) {                      // e4m3 operands of dove_attention_fwd_mxfp8 (every padded row is rewritten per call)
+    if (c->Q8) { (void)hipFree(c->Q8); (void)hipFree(c->K8); (void)hipFree(c->V8); (void)hipFree(c->Vs8); }
+    const size_t b8 = (size_t)Hh * npad * 64;
+    HIPCHK(hipMalloc((void**)&c->Q8, b8)); HIPCHK(hipMalloc((void**)&c->K8, b8)); HIPCHK(hipMalloc((void**)&c->V8, b8));
+    HIPCHK(hipMalloc((void**)&c->Vs8, (size_t)Hh * (npad / 64) * 64 * 2));
+    HIPCHK(hipMemsetAsync(c->Q8, 0, b8, (hipStream_t)stream)); HIPCHK(hipMemsetAsync(c->K8, 0, b8, (hipStream_t)stream));
+    HIPCHK(hipMemsetAsync(c->V8, 0, b8, (hipStream_t)stream)); HIPCHK(hipMemsetAsync(c->Vs8, 0, (size_t)Hh * (npad / 64) * 64 * 2, (hipStream_t)stream));
+    c->attn8_n = N;
+  }
+  // one of the block's four big linears: bf16 implicit GEMM, or (DOVE_OPT_DIT_LINEAR_MXFP8) activation quantised per call + block-scaled MFMA
+  auto big = [&](const bf16_t* x, const Packed& pc, const PackedMx& p8, ConvOpt oo, bf16_t** out) -> int {
+    if (!c->opt_linear_mx) return linear(c, x, N, pc, oo, out, stream);
+    const int K = p8.K, Nn = p8.rows;
+    uint8_t* xq = (uint8_t*)c->arena.alloc((size_t)N * K);
+    uint32_t* xs = (uint32_t*)c->arena.alloc((size_t)(K / 256) * N * 2 * 4);
+    bf16_t* y = oo.out ? oo.out : (bf16_t*)c->arena.alloc((size_t)N * Nn * 2);
+    if (!xq || !xs || !y) { dove_set_error("workspace exhausted (MXFP8 linear)"); return DOVE_EINVAL; }
+    CHK(dove_mx_quant_bf16(x, N, K, xq, xs, stream));
+    CHK(dove_linear_mxfp8(xq, xs, p8.q, p8.s, p8.bias, oo.resid, oo.gate, y, N, Nn, K, Nn, oo.ldr, oo.gate_split, oo.act, stream));
+    c->arena.release(xq); c->arena.release(xs);
+    *out = y;
+    return 0;
+  };
   for (auto& b : c->blocks) {
     CHK(dove_layernorm_modulate_bf16(hs, n1, N, D, cf.dit_norm_eps, b.ln1_g, b.ln1_b, b.m1, L, stream));
     bf16_t* qkv;
-    CHK(linear(c, n1, N, b.qkv, ConvOpt(), &qkv, stream));
-    CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, /*v_order=*/1, stream));
-    c->arena.release(qkv);
-    CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, stream));      // attention output reuses n1
+    CHK(big(n1, b.qkv, b.qkv8, ConvOpt(), &qkv));
+    if (c->opt_attn_mx) {
+      CHK(dove_qkv_post_mxfp8(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Q8, c->K8, c->V8, c->Vs8, stream));
+      c->arena.release(qkv);
+      CHK(dove_attention_fwd_mxfp8(c->Q8, c->K8, c->V8, c->Vs8, n1, N, npad, Hh, 64, D, stream));
+    } else {
+      CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, /*v_order=*/1, stream));
+      c->arena.release(qkv);
+      CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, stream));      // attention output reuses n1
+    }
     o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g1; o.gate_split = L; o.out = hs;
-    CHK(linear(c, n1, N, b.out, o, &dummy, stream));
+    CHK(big(n1, b.out, b.out8, o, &dummy));
     CHK(dove_layernorm_modulate_bf16(hs, n1, N, D, cf.dit_norm_eps, b.ln2_g, b.ln2_b, b.m2, L, stream));
     bf16_t* f1;
     o = ConvOpt(); o.act = 1;
-    CHK(linear(c, n1, N, b.ff1, o, &f1, stream));
+    CHK(big(n1, b.ff1, b.ff18, o, &f1));
     o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g2; o.gate_split = L; o.out = hs;
-    CHK(linear(c, f1, N, b.ff2, o, &dummy, stream));
+    CHK(big(f1, b.ff2, b.ff28, o, &dummy));
     c->arena.release(f1);
   }
   bf16_t* xv = hs + (size_t)L * D;
@@ -1105,8 +1349,10 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
 // text [Ltxt][text_dim] bf16, timestep t with sqrt(alpha_t), sqrt(1 - alpha_t) of the scheduler -> video_out [3][F][H][W] in [0,1].
 extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F, int H, int W, const void* noise, int noise_dtype,
                             const void* text, int Ltxt, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux,
-                            void* video_out, int out_dtype, void* stream) {
+                            const dove_pre_noise* pre, void* video_out, int out_dtype, void* stream) {
   DOVE_CHECK_ARG(video_in && noise && text && video_out, "dove_sr_clip: null pointer");
+  DOVE_CHECK_ARG(!pre || pre->eps, "dove_sr_clip: pre_noise without eps");
+  StageGuard guard(c);
   DOVE_CHECK_ARG(c->nranks == 1, "dove_sr_clip: a multi-rank context runs the VAE stages only (dove_vae_encode / dove_vae_decode + the caller's gather)");
   DOVE_CHECK_ARG(F >= 1 && H % 16 == 0 && W % 16 == 0, "dove_sr_clip: H and W must be multiples of 16 (8x VAE, 2x patch)");
   CHK(ensure_ws(c, F, H, W));
@@ -1132,6 +1378,21 @@ extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F,
     CHK(copy2d(lat + (long long)t * Lc * fsz, (size_t)fsz * 2, scaled + (long long)ts * fsz, (size_t)T * fsz * 2, (size_t)fsz * 2, Lc, s));
   }
   c->arena.release(samp); c->arena.release(scaled);
+  if (pre) {       // --noise_step (ref :449-457): latent <- sqrt(a_n) * latent + sqrt(1 - a_n) * eps, eps [Td][L][h][w] like the latent
+    bf16_t* noisy = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);
+    DOVE_CHECK_ARG(noisy, "workspace exhausted");
+    const void* eps = pre->eps;
+    bf16_t* eps16 = nullptr;
+    if (pre->eps_dtype != DOVE_BF16) {                          // axpby takes both operands in one dtype: round eps like `.to(latent.dtype)`
+      eps16 = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);
+      DOVE_CHECK_ARG(eps16, "workspace exhausted");
+      hipLaunchKernelGGL(to_bf16_kernel, dim3(256), dim3(256), 0, s, pre->eps, pre->eps_dtype, (long long)Td * Lc * fsz, eps16);
+      eps = eps16;
+    }
+    CHK(dove_axpby(lat, eps, noisy, DOVE_BF16, (long long)Td * Lc * fsz, pre->sqrt_alpha, pre->sqrt_one_minus_alpha, stream));
+    c->arena.release(lat); c->arena.release(eps16);
+    lat = noisy;
+  }
   bf16_t* vel = (bf16_t*)c->arena.alloc((size_t)Td * Lc * fsz * 2);
   DOVE_CHECK_ARG(vel, "workspace exhausted");
   CHK(dove_dit_forward(c, lat, DOVE_BF16, Td, h, w, text, Ltxt, timestep, aux, vel, DOVE_BF16, stream));

@@ -34,12 +34,18 @@ def model_config(vae_cfg: dict, dit_cfg: dict) -> "L.ModelConfig":
 
 
 class GraphContext:
-    def __init__(self, vae_cfg: dict, dit_cfg: dict, vae_sd, dit_sd, device="cuda"):
+    def __init__(self, vae_cfg: dict, dit_cfg: dict, vae_sd, dit_sd, device="cuda", dit_linear_precision="bf16", dit_attention_precision="bf16"):
+        """``dit_linear_precision`` / ``dit_attention_precision`` = "mxfp8": BASELINE configs[4] (DOVE_OPT_DIT_LINEAR_MXFP8 is chosen before
+        the weights are finalized: they are quantised there)."""
         self.device = torch.device(device if ":" in str(device) else f"{device}:{torch.cuda.current_device()}")
         self._h = C.c_void_p()
         cfg = model_config(vae_cfg, dit_cfg)
         L.check(L.load().dove_create(self.device.index, C.byref(cfg), C.byref(self._h)), "dove_create")
         self.vae_cfg, self.dit_cfg = vae_cfg, dit_cfg
+        self.set_option(L.OPT_VAE_SAMPLE_HEIGHT, vae_cfg.get("sample_height", 480))
+        self.set_option(L.OPT_VAE_SAMPLE_WIDTH, vae_cfg.get("sample_width", 720))
+        self.set_option(L.OPT_DIT_LINEAR_MXFP8, int(dit_linear_precision == "mxfp8"))
+        self.set_option(L.OPT_DIT_ATTN_MXFP8, int(dit_attention_precision == "mxfp8"))
         keep = []
         for sd in (vae_sd, dit_sd):
             for name in sd.keys():
@@ -59,6 +65,19 @@ class GraphContext:
                 self._h = C.c_void_p()
         except Exception:
             pass
+
+    def set_option(self, option: int, value: int):
+        L.check(L.load().dove_set_option(self._h, int(option), int(value)), f"dove_set_option({option})")
+
+    def get_option(self, option: int) -> int:
+        return int(L.load().dove_get_option(self._h, int(option)))
+
+    def enable_tiling(self, on: bool = True):
+        """pipe.vae.enable_tiling() (`--is_vae_st`, ref :643-645) for vae_encode / vae_decode / sr_clip."""
+        self.set_option(L.OPT_VAE_TILING, int(on))
+
+    def useful_ranks(self, stage: int, n: int) -> int:
+        return int(L.load().dove_comm_useful_ranks(self._h, stage, n))
 
     # ---- one clip on several ranks (halo-exact VAE; include/dove_hip.h "one clip on several GPUs") ----
     def comm_init_rccl(self, unique_id: bytes, rank: int, nranks: int):
@@ -143,13 +162,20 @@ class GraphContext:
         return out
 
     def sr_clip(self, video: torch.Tensor, noise: torch.Tensor, text: torch.Tensor, timestep: int, sqrt_alpha: float,
-                sqrt_one_minus_alpha: float, rope=None, timestep_proj=None) -> torch.Tensor:
-        """process_video on device buffers: video [3,F,H,W] in [-1,1], noise [L,T,h,w], text [Lt, text_dim] bf16 -> [3,F,H,W] in [0,1]."""
+                sqrt_one_minus_alpha: float, rope=None, timestep_proj=None, pre_noise=None) -> torch.Tensor:
+        """process_video on device buffers: video [3,F,H,W] in [-1,1], noise [L,T,h,w], text [Lt, text_dim] bf16 -> [3,F,H,W] in [0,1].
+        ``pre_noise`` = (eps [T',L,h,w], sqrt_alpha_n, sqrt_one_minus_alpha_n): the `--noise_step` pre-noising (ref :449-457)."""
         L.require_cuda(video, noise, text)
         _, F, H, W = video.shape
         out = torch.empty(3, F, H, W, dtype=torch.bfloat16, device=video.device)
         aux, keep = self._aux(rope, timestep_proj)
+        pre = None
+        if pre_noise is not None:
+            eps, sa, sb = pre_noise
+            L.require_cuda(eps)
+            eps = eps.contiguous()
+            pre = L.PreNoise(eps.data_ptr(), L.dt_code(eps), float(sa), float(sb))
         L.check(L.load().dove_sr_clip(self._h, L.ptr(video), L.dt_code(video), F, H, W, L.ptr(noise), L.dt_code(noise), L.ptr(text), text.shape[0],
-                                      int(timestep), sqrt_alpha, sqrt_one_minus_alpha, C.byref(aux) if aux is not None else None, L.ptr(out),
-                                      L.BF16, L.stream_ptr()), "dove_sr_clip")
+                                      int(timestep), sqrt_alpha, sqrt_one_minus_alpha, C.byref(aux) if aux is not None else None,
+                                      C.byref(pre) if pre is not None else None, L.ptr(out), L.BF16, L.stream_ptr()), "dove_sr_clip")
         return out

@@ -49,6 +49,15 @@ class DitAux(C.Structure):
     _fields_ = [("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("timestep_proj", C.c_void_p)]
 
 
+class PreNoise(C.Structure):
+    """dove_pre_noise: `--noise_step` of the graph-level dove_sr_clip."""
+    _fields_ = [("eps", C.c_void_p), ("eps_dtype", C.c_int), ("sqrt_alpha", C.c_float), ("sqrt_one_minus_alpha", C.c_float)]
+
+
+# dove_set_option keys (include/dove_hip.h)
+OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP8, OPT_DIT_ATTN_MXFP8 = 1, 2, 3, 4, 5
+
+
 _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)   # dove_xfer_fn
 
@@ -91,7 +100,8 @@ SIGNATURES = {
     "dove_vae_encode": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP],
     "dove_dit_forward": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _I, C.POINTER(DitAux), _VP, _I, _VP],
     "dove_vae_decode": [_VP, _VP, _I, _I, _I, _I, _F, _I, _VP, _I, _VP],
-    "dove_sr_clip": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _I, _I, _F, _F, C.POINTER(DitAux), _VP, _I, _VP],
+    "dove_sr_clip": [_VP, _VP, _I, _I, _I, _I, _VP, _I, _VP, _I, _I, _F, _F, C.POINTER(DitAux), C.POINTER(PreNoise), _VP, _I, _VP],
+    "dove_set_option": [_VP, _I, _LL],
     "dove_comm_unique_id": [_VP],
     "dove_comm_init": [_VP, _VP, _I, _I],
     "dove_comm_init_custom": [_VP, _I, _I, XFER_FN, XFER_FN, _VP],
@@ -104,6 +114,8 @@ PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
          "dove_destroy": (None, [_VP]),
          "dove_vae_decode_num_frames": (C.c_int, [_VP, _I]),
+         "dove_get_option": (C.c_longlong, [_VP, _I]),
+         "dove_comm_useful_ranks": (C.c_int, [_VP, _I, _I]),
          "dove_workspace_bytes": (C.c_size_t, [_VP, _I, _I, _I]),
          "dove_workspace_high_water": (C.c_size_t, [_VP])}
 

@@ -242,7 +242,9 @@ int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
  * last kt-1 input frames the previous batch would have left) from rank-1, and sends its own to rank+1 after the rank's last
  * batch - point-to-point, in layer order, on the caller's stream.  Results are bit-identical to the single-GPU call.  Only the
  * frames dove_shard_frames reports are written to the output buffer; gathering them is the caller's (an all-gather of
- * [channels][own frames][H][W] pieces).  dove_dit_forward is not sharded at this level and dove_sr_clip refuses a multi-rank
+ * [channels][own frames][H][W] pieces).  RANK LIMIT: frame-batches are never split at this level, so ranks beyond the number of
+ * frame-batches (dove_comm_useful_ranks: 4 for a 33-frame clip) get no work; the paired-piece split that lets 8 ranks share 4
+ * batches (BASELINE's "frame-chunk = 4": GroupNorm sums combined across a rank pair) lives in the Python host, dove_amd.dist.  dove_dit_forward is not sharded at this level and dove_sr_clip refuses a multi-rank
  * context (the Python host shards the DiT by sequence / heads, dove_amd.dist).
  * dove_comm_init: RCCL transport (librccl opened at run time; the 128-byte id from dove_comm_unique_id on rank 0, distributed by
  * the host).  dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`, ordered on `stream`. */
@@ -253,7 +255,27 @@ int dove_comm_init_custom(dove_ctx* ctx, int rank, int nranks, dove_xfer_fn send
 void dove_comm_destroy(dove_ctx* ctx);
 /* stage 0 = dove_vae_encode (n = pixel frames F -> latent frames), stage 1 = dove_vae_decode (n = latent frames T -> pixel frames) */
 int dove_shard_frames(dove_ctx* ctx, int stage, int n, int* first, int* count);
+/* number of ranks that get work for this stage and clip length = its number of frame-batches */
+int dove_comm_useful_ranks(dove_ctx* ctx, int stage, int n);
 void dove_destroy(dove_ctx* ctx);
+/* ---- options of the graph level: the reference's switches that change what a stage computes ----
+ * DOVE_OPT_VAE_TILING (value 0 / 1): pipe.vae.enable_tiling() (`--is_vae_st`, /root/reference/inference_script.py:643-645; every
+ *   published number of the reference ran with it): dove_vae_encode / dove_vae_decode / dove_sr_clip run diffusers' spatial tiling
+ *   whenever the clip is larger than one tile - tile = sample/2 px (sample/16 latents), strides 5/6 and 4/5 of it, linear
+ *   cross-fade of the overlaps, every tile with its own GroupNorm scope and conv caches.  Not combined with a multi-rank context.
+ * DOVE_OPT_VAE_SAMPLE_HEIGHT / _WIDTH (px): vae/config.json sample_height / sample_width (defaults 480 / 720).
+ * DOVE_OPT_DIT_LINEAR_MXFP8 (0 / 1; BASELINE configs[4], not a reference option; never the headline dtype): attn1.to_q/k/v,
+ *   attn1.to_out.0, ff.net.0.proj and ff.net.2 of every block in MXFP8.  Choose BEFORE dove_finalize_weights: the weights are
+ *   quantised there and their bf16 copies dropped.
+ * DOVE_OPT_DIT_ATTN_MXFP8 (0 / 1; same variant): attention on dove_qkv_post_mxfp8 / dove_attention_fwd_mxfp8; any time.
+ * Stage results with an option set are bit-identical to the Python facade with the same switch (tests/test_graph_gpu.py). */
+#define DOVE_OPT_VAE_TILING 1
+#define DOVE_OPT_VAE_SAMPLE_HEIGHT 2
+#define DOVE_OPT_VAE_SAMPLE_WIDTH 3
+#define DOVE_OPT_DIT_LINEAR_MXFP8 4
+#define DOVE_OPT_DIT_ATTN_MXFP8 5
+int dove_set_option(dove_ctx* ctx, int option, long long value);
+long long dove_get_option(dove_ctx* ctx, int option); /* -1: unknown option */
 int dove_set_weight(dove_ctx* ctx, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype);
 int dove_finalize_weights(dove_ctx* ctx);
 /* arena bytes a [3,F,H,W] clip needs (upper bound); dove_set_workspace(ctx, NULL, n) lets the library allocate, a non-NULL pointer
@@ -271,11 +293,15 @@ int dove_dit_forward(dove_ctx* ctx, const void* hidden, int dtype, int T, int h,
 int dove_vae_decode_num_frames(dove_ctx* ctx, int T);
 int dove_vae_decode(dove_ctx* ctx, const void* z, int dtype, int T, int h, int w, float prescale, int range01, void* video_out,
                     int out_dtype, void* stream);
+/* `--noise_step n` (ref :449-457; 0 = off = NULL): the latent handed to the DiT is first noised,
+ * latent <- sqrt_alpha * latent + sqrt_one_minus_alpha * eps with the scheduler's alpha_n (cast to the latent dtype first, like
+ * diffusers' add_noise) and eps [T'][L][h][w] (the DiT's input layout, T' = T + T % patch_t) drawn by the caller. */
+typedef struct dove_pre_noise { const void* eps; int eps_dtype; float sqrt_alpha, sqrt_one_minus_alpha; } dove_pre_noise;
 /* process_video (ref :394-503) with the posterior noise injected and the scheduler's sqrt(alpha_t), sqrt(1 - alpha_t) (alpha cast
- * to bf16 first, like diffusers): video_in [3][F][H][W] in [-1,1] -> video_out [3][F][H][W] in [0,1] */
+ * to bf16 first, like diffusers): video_in [3][F][H][W] in [-1,1] -> video_out [3][F][H][W] in [0,1]; pre_noise may be NULL */
 int dove_sr_clip(dove_ctx* ctx, const void* video_in, int dtype, int F, int H, int W, const void* noise, int noise_dtype, const void* text,
-                 int text_len, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux, void* video_out,
-                 int out_dtype, void* stream);
+                 int text_len, int timestep, float sqrt_alpha, float sqrt_one_minus_alpha, const dove_dit_aux* aux,
+                 const dove_pre_noise* pre_noise, void* video_out, int out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

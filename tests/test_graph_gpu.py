@@ -24,7 +24,7 @@ def both():
     wt = weights.random_state_dict(weights.dit_param_shapes(t), seed)
     pipe = CogVideoXPipeline.from_config(v, t, s, seed=seed, device="cuda")
     ctx = GraphContext(v, t, wv, wt, "cuda")
-    return pipe, ctx, (v, t, s)
+    return pipe, ctx, (v, t, s, wv, wt)
 
 
 def rope_for(pipe, T, h, w):
@@ -82,6 +82,125 @@ def test_sr_clip_equals_process_video(both):
     own = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1)
     d = (own.float() - want.float()).abs()                     # libm vs torch in the sinusoid / RoPE tables: a last-bit change of a few
     assert float(d.max()) < 0.1 and float(d.mean()) < 5e-3, (float(d.max()), float(d.mean()))   # table entries, amplified by random weights
+
+
+def _clip_inputs(F, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    video = (torch.rand(1, 3, F, H, W, generator=g) * 2 - 1).to(BF).cuda()
+    T = 1 + (F - 1) // 4
+    noise = torch.randn(1, 16, T, H // 8, W // 8, generator=g).cuda()
+    text = (torch.randn(226, 4096, generator=g) * 0.15).to(BF).cuda()
+    return video, noise, text, T
+
+
+def test_option_vae_tiling_bit_exact(both):
+    """DOVE_OPT_VAE_TILING = pipe.vae.enable_tiling() (`--is_vae_st`, ref :643-645): encode, decode and the whole clip through the C
+    graph == the Python facade with the same switch, bit for bit; 3 x 3 tiles in both directions (sample size 96 x 160 -> 48 x 80 px
+    tiles on a 9 x 112 x 192 clip), ragged last tiles."""
+    from dove_amd import lib as L
+    pipe, ctx, _ = both
+    F, H, W = 9, 112, 192
+    video, noise, text, T = _clip_inputs(F, H, W, 5)
+    cfg = pipe.vae.config
+    old = (cfg["sample_height"], cfg["sample_width"], pipe.vae.use_tiling)
+    try:
+        plain = ctx.vae_encode(video[0].contiguous())
+        cfg["sample_height"], cfg["sample_width"] = 96, 160
+        ctx.set_option(L.OPT_VAE_SAMPLE_HEIGHT, 96)
+        ctx.set_option(L.OPT_VAE_SAMPLE_WIDTH, 160)
+        pipe.vae.enable_tiling()
+        ctx.enable_tiling()
+        assert ctx.get_option(L.OPT_VAE_TILING) == 1 and ctx.get_option(L.OPT_VAE_SAMPLE_WIDTH) == 160
+        m_py = pipe.vae.encode(video).latent_dist.parameters[0]
+        m_c = ctx.vae_encode(video[0].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(m_c, m_py), f"tiled encode differs: {float((m_c.float() - m_py.float()).abs().max())}"
+        assert not torch.equal(m_c, plain), "the option did not switch the tiled path on"
+        z = torch.randn(16, T, H // 8, W // 8, generator=torch.Generator().manual_seed(6)).to(BF).cuda()
+        d_py = pipe.vae.decode(z[None], _range01=True, _prescale=1 / 0.7).sample[0]
+        d_c = ctx.vae_decode(z, prescale=1 / 0.7, range01=True)
+        torch.cuda.synchronize()
+        assert torch.equal(d_c, d_py), f"tiled decode differs: {float((d_c.float() - d_py.float()).abs().max())}"
+        want = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)[0]
+        sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+        got = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, rope=rope_for(pipe, T + T % 2, H // 8, W // 8),
+                          timestep_proj=pipe.transformer.timestep_projection(399))
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"tiled sr_clip differs: {float((got.float() - want.float()).abs().max())}"
+    finally:
+        cfg["sample_height"], cfg["sample_width"], pipe.vae.use_tiling = old
+        ctx.set_option(L.OPT_VAE_SAMPLE_HEIGHT, old[0])
+        ctx.set_option(L.OPT_VAE_SAMPLE_WIDTH, old[1])
+        ctx.enable_tiling(False)
+
+
+def test_option_noise_step_bit_exact(both):
+    """`--noise_step` (ref :449-457) through dove_sr_clip's pre_noise argument == process_video(noise_step=200) with the same eps."""
+    pipe, ctx, _ = both
+    F, H, W = 9, 64, 96
+    video, noise, text, T = _clip_inputs(F, H, W, 8)
+    torch.manual_seed(4242)
+    want = process_video(pipe, video, noise_step=200, empty_prompt_embedding=text, posterior_noise=noise)[0]
+    torch.manual_seed(4242)
+    Td = T + T % 2
+    eps = torch.randn(1, Td, 16, H // 8, W // 8, device="cuda", dtype=BF)         # the one draw process_video makes (randn_like(latent))
+    sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+    na, n1 = pipe.scheduler._coeffs(torch.tensor([200]), BF)
+    kw = dict(rope=rope_for(pipe, Td, H // 8, W // 8), timestep_proj=pipe.transformer.timestep_projection(399))
+    got = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, pre_noise=(eps[0], na, n1), **kw)
+    base = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), f"pre-noised sr_clip differs: {float((got.float() - want.float()).abs().max())}"
+    assert not torch.equal(got, base)
+    got32 = ctx.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, pre_noise=(eps[0].float(), na, n1), **kw)
+    assert torch.equal(got32, want), "fp32 eps must be rounded to the latent dtype first"
+
+
+def test_option_mxfp8_bit_exact(both):
+    """DOVE_OPT_DIT_LINEAR_MXFP8 + DOVE_OPT_DIT_ATTN_MXFP8 (BASELINE configs[4]) through the C graph == the facade's mxfp8 variant."""
+    from dove_amd import lib as L
+    from dove_amd.transformer import CogVideoXTransformer3DModel
+    pipe, _, (v, t, s, wv, wt) = both
+    tr8 = CogVideoXTransformer3DModel(t, wt, "cuda", linear_precision="mxfp8", attention_precision="mxfp8")
+    pipe8 = CogVideoXPipeline(pipe.vae, tr8, pipe.scheduler)
+    ctx8 = GraphContext(v, t, wv, wt, "cuda", dit_linear_precision="mxfp8", dit_attention_precision="mxfp8")
+    assert ctx8.get_option(L.OPT_DIT_LINEAR_MXFP8) == 1 and ctx8.get_option(L.OPT_DIT_ATTN_MXFP8) == 1
+    with pytest.raises(RuntimeError, match="before dove_finalize_weights"):
+        ctx8.set_option(L.OPT_DIT_LINEAR_MXFP8, 0)
+    F, H, W = 9, 64, 96
+    video, noise, text, T = _clip_inputs(F, H, W, 9)
+    Td = T + T % 2
+    g = torch.Generator().manual_seed(10)
+    hidden = torch.randn(Td, 16, H // 8, W // 8, generator=g).to(BF).cuda()
+    rope = rope_for(pipe, Td, H // 8, W // 8)
+    ts = torch.tensor([399], device="cuda")
+    v_py = tr8(hidden_states=hidden[None], encoder_hidden_states=text[None], timestep=ts, image_rotary_emb=rope, return_dict=False)[0][0]
+    v_c = ctx8.dit_forward(hidden, text, 399, rope=rope, timestep_proj=tr8.timestep_projection(399))
+    v_16 = pipe.transformer(hidden_states=hidden[None], encoder_hidden_states=text[None], timestep=ts, image_rotary_emb=rope, return_dict=False)[0][0]
+    torch.cuda.synchronize()
+    assert torch.equal(v_c, v_py), f"mxfp8 DiT differs: {float((v_c.float() - v_py.float()).abs().max())}"
+    assert not torch.equal(v_c, v_16)
+    want = process_video(pipe8, video, empty_prompt_embedding=text, posterior_noise=noise)[0]
+    sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+    got = ctx8.sr_clip(video[0].contiguous(), noise[0].contiguous(), text, 399, sa, s1, rope=rope, timestep_proj=tr8.timestep_projection(399))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), f"mxfp8 sr_clip differs: {float((got.float() - want.float()).abs().max())}"
+
+
+def test_failed_stage_does_not_leak_the_arena(both):
+    """A stage that returns early on an error used to leave its arena blocks live for ever (the workspace shrank for every later
+    call); now every top-level call starts from an empty arena: an exhausted call followed by a regrown workspace succeeds."""
+    pipe, ctx, _ = both
+    F, H, W = 9, 64, 64
+    video = (torch.rand(3, F, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(BF).cuda()
+    want = ctx.vae_encode(video)
+    ctx.set_workspace(1 << 20)                                  # far too small: the stage must fail cleanly ...
+    with pytest.raises(RuntimeError, match="workspace exhausted"):
+        ctx.vae_encode(video)
+    ctx.set_workspace(ctx.workspace_bytes(F, H, W))             # ... and leave nothing behind that blocks a regrown arena
+    got = ctx.vae_encode(video)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
 
 
 def test_sr_clip_full_size_timing():
