@@ -111,8 +111,14 @@ class GraphContext:
     def workspace_high_water(self) -> int:
         return int(L.load().dove_workspace_high_water(self._h))
 
-    def set_workspace(self, nbytes: int):
-        L.check(L.load().dove_set_workspace(self._h, None, nbytes), "dove_set_workspace")
+    def set_workspace(self, nbytes: int, buffer: torch.Tensor | None = None):
+        """Library-owned arena of ``nbytes`` (regrown on demand), or - with ``buffer`` - caller memory the library uses as is (kept alive
+        here; a stage that needs more fails with "workspace exhausted")."""
+        if buffer is not None:
+            L.require_cuda(buffer)
+            assert buffer.is_contiguous() and buffer.numel() * buffer.element_size() >= nbytes
+        self._ws_keep = buffer
+        L.check(L.load().dove_set_workspace(self._h, L.ptr(buffer) if buffer is not None else None, nbytes), "dove_set_workspace")
 
     @staticmethod
     def _aux(rope=None, timestep_proj=None):

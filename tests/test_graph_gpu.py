@@ -194,13 +194,19 @@ def test_failed_stage_does_not_leak_the_arena(both):
     F, H, W = 9, 64, 64
     video = (torch.rand(3, F, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(BF).cuda()
     want = ctx.vae_encode(video)
-    ctx.set_workspace(1 << 20)                                  # far too small: the stage must fail cleanly ...
-    with pytest.raises(RuntimeError, match="workspace exhausted"):
-        ctx.vae_encode(video)
-    ctx.set_workspace(ctx.workspace_bytes(F, H, W))             # ... and leave nothing behind that blocks a regrown arena
+    small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    ctx.set_workspace(small.numel(), buffer=small)              # lent memory, far too small: the stage must fail cleanly ...
+    for _ in range(3):                                          # ... every time, without consuming what little there is
+        with pytest.raises(RuntimeError, match="workspace exhausted"):
+            ctx.vae_encode(video)
+    need = ctx.workspace_bytes(F, H, W)
+    big = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ctx.set_workspace(need, buffer=big)                         # the same context on enough lent memory: nothing stale blocks it
     got = ctx.vae_encode(video)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+    ctx.set_workspace(1 << 20)                                  # a library-owned arena that is too small is regrown, not an error
+    assert torch.equal(ctx.vae_encode(video), want)
 
 
 def test_sr_clip_full_size_timing():
