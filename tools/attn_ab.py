@@ -17,12 +17,28 @@ exp.attn_exp.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong, C.c_longlo
 exp.attn_exp2.argtypes = exp.attn_exp.argtypes
 pipe = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn_pipe_exp.so"))      # variants 30+: software-pipelined kernel
 pipe.attn_exp3.argtypes = exp.attn_exp.argtypes
+g2 = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn2g_exp.so"))          # variants 40+: two wave groups one barrier phase apart
+g2.attn_exp4.argtypes = exp.attn_exp.argtypes
 BF = torch.bfloat16
+_swapped = {}
+
+
+def vswap(V):
+    """V^T in the quad-swapped key order (the product kernel's and variants 40+'s contract), converted once per tensor - not inside
+    the timed loop."""
+    k = V.data_ptr()
+    if k not in _swapped:
+        _swapped[k] = (V, ops.vt_quad_swap(V.clone()))
+    return _swapped[k][1]
 
 
 def run(variant, Q, K, V, N, npad, heads, out):
     if variant < 0:                                # the product kernel reads V^T in the quad-swapped key order
-        return ops.attention(Q, K, ops.vt_quad_swap(V.clone()), N, npad, heads, out)
+        return ops.attention(Q, K, vswap(V), N, npad, heads, out)
+    if variant >= 40:
+        rc = g2.attn_exp4(variant, Q.data_ptr(), K.data_ptr(), vswap(V).data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
+        assert rc == 0, rc
+        return out
     fn = pipe.attn_exp3 if variant >= 30 else (exp.attn_exp2 if variant >= 20 else exp.attn_exp)
     rc = fn(variant, Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
     assert rc == 0, rc
@@ -56,11 +72,16 @@ K[:, 700] = (Q[:, 7].float() * 40).to(BF)
 K[:, 3] = (Q[:, 300].float() * 30).to(BF)
 Q[:, 500:520] *= 8.0
 ref = reference(Q, K, V, N)
+prod = None
 for v in [-1] + variants:
     out = torch.zeros(N, heads * 64, dtype=BF, device="cuda")
     run(v, Q, K, V, N, npad, heads, out)
     torch.cuda.synchronize()
     err = (out.float() - ref).abs()
+    if v == -1:
+        prod = out.clone()
+    elif v >= 40:
+        print(f"variant {v:3d}: bit-identical to the product kernel: {bool(torch.equal(out, prod))}", flush=True)
     print(f"variant {v:3d}: max err {float(err.max()):.4f}  rms-rel {float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()):.2e}  "
           f"finite {bool(torch.isfinite(out.float()).all())}", flush=True)
 # ---- speed at the headline shape ----
@@ -68,6 +89,13 @@ N, heads = 18226, 48
 Q, K, V, npad = make(N, heads, 2)
 out = torch.zeros(N, heads * 64, dtype=BF, device="cuda")
 flop = 4.0 * heads * N * N * 64
+base = run(-1, Q, K, V, N, npad, heads, torch.zeros_like(out)).clone()
+for v in variants:
+    if v >= 40:
+        o2 = run(v, Q, K, V, N, npad, heads, torch.zeros_like(out))
+        torch.cuda.synchronize()
+        print(f"variant {v:3d} at N = {N}: bit-identical to the product kernel: {bool(torch.equal(o2, base))}  "
+              f"max |diff| {float((o2.float() - base.float()).abs().max()):.3g}", flush=True)
 times = {v: [] for v in [-1] + variants}
 for rnd in range(4):
     for v in times:
