@@ -264,9 +264,6 @@ def main():
             return fl, ms
         DOM = "conv3x3_halo4x_kernel"
         dom = [r for r in records if r[4] == DOM]
-        if not dom:                                   # DOVE_CONV_HALO4X=0 fallback build of the same path
-            DOM = "conv3x3_halo8_kernel"
-            dom = [r for r in records if r[4] == DOM]
         dom_fl, dom_ms = agg(dom)
         tot_fl, tot_ms = agg(records)
         by = {}

@@ -241,10 +241,9 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
   constexpr int LDS = 4 * 16384;
   constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   dim3 grid((unsigned)((Npad + NW * 32 - 1) / (NW * 32)), heads);
   hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
@@ -258,12 +257,11 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
 extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads,
                                           long long ldo, int nw, void* stream) {
   constexpr int LDS = 4 * 16384;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
   }
   dim3 grid((unsigned)((Npad + nw * 32 - 1) / (nw * 32)), heads);
   if (nw == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);

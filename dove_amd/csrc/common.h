@@ -33,6 +33,20 @@ extern "C" void dove_set_error(const char* fmt, ...);
     }                                                                     \
   } while (0)
 
+// hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device: one flag per call site AND device, so a process that
+// drives several GPUs (dove_create(device) invites it) raises the limit on each of them
+struct PerDeviceOnce {
+  bool done[32] = {};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (d < 0 || d >= 32) return true;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved (same rounding as torch's float->bfloat16)

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
 //   * halo of group g+1: 5 rounds issued during steps 0..4 of group g into the other halo buffer, whose last
 //     reader (group B, last step of group g-1) finished one barrier earlier.
 // ------------------------------------------------------------------------------------------------
-namespace halo8 {
+namespace halo8 {   // tile geometry / LDS image of the halo kernels (the name is historical: the 8-wave kernel that introduced it is gone)
 constexpr int TH = 16, TW = 32, HWID = TW + 2, HHGT = TH + 2, HPIX = HWID * HHGT;   // 612 halo pixels
 constexpr int BK = 32, ROWB = 64;
 // Halo rows are PADDED to 80 bytes (5 x 16 B, last slot unused) instead of XOR-swizzled: slot index 5*row + chunk is
@@ -537,287 +537,6 @@ constexpr int BN = 128, B_BYTES = BN * ROWB;                                    
 constexpr int B_RING = 4;                                                             // weights run 3 steps ahead
 constexpr int LDS_BYTES = 2 * A_BYTES + B_RING * B_BYTES;                             // 131072
 }  // namespace halo8
-
-// UP = true: the conv reads a nearest-x2 upsampled input (Upsample3D, kt == 1): the halo is the (16/2+2) x (32/2+2) INPUT
-// patch, output pixel (oh, ow) tap (dh, dw) reads input ((oh+dh-1)>>1, (ow+dw-1)>>1); per-lane column bases for the three
-// dw values + compile-time row immediates keep the fragment reads VALU-free; lanes 2k, 2k+1 read the same row (broadcast).
-template <bool kTiming, bool kUp>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo8_kernel(const IgemmArgs a) {
-  constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;     // 18 x 10 input halo when kUp
-  constexpr int NROUNDS = kUp ? (UHW * UHH * 5 + 511) / 512 : halo8::A_ROUNDS;
-  using namespace halo8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 8);
-  const int grp = wave >> 2;                   // 0: rows 0-7 (leads), 1: rows 8-15 (one phase behind)
-  const int wm = (wave >> 1) & 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  // tile order: cout tile fastest, then the OUTPUT FRAME, then space.  The three temporal taps make input frame f
-  // the operand of output frames f, f+1, f+2: with t fast those blocks run back-to-back on one XCD and the re-reads
-  // hit L2 / Infinity Cache instead of HBM (with t slowest FETCH_SIZE was 3x the input tensor).
-  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
-  int t, twi, thi;
-  if (DOVE_DBG(a) & 64) {          // A/B switch: old order (frame slowest)
-    twi = rest % a.tiles_w; rest /= a.tiles_w;
-    thi = rest % a.tiles_h;
-    t = rest / a.tiles_h;
-  } else {
-    t = rest % a.T_out; rest /= a.T_out;
-    twi = rest % a.tiles_w;
-    thi = rest / a.tiles_w;
-  }
-  const int n0 = tn * BN;
-  const int oh0 = thi * TH, ow0 = twi * TW;
-
-  unsigned voffA[halo8::A_ROUNDS];          // (kUp uses only the first NROUNDS entries)
-#pragma unroll
-  for (int r = 0; r < halo8::A_ROUNDS; ++r) {
-    const int s = r * 512 + tid;
-    const int px = s / 5, c = s - px * 5;            // padded rows: 5 slots per pixel, slot 4 is padding
-    int ih, iw;
-    bool inb;
-    if (kUp) {
-      const int hh = px / UHW, hw = px - hh * UHW;
-      ih = (oh0 >> 1) - 1 + hh; iw = (ow0 >> 1) - 1 + hw;
-      inb = px < UHW * UHH;
-    } else {
-      const int hh = px / HWID, hw = px - hh * HWID;
-      ih = oh0 - 1 + hh; iw = ow0 - 1 + hw;
-      inb = px < HPIX;
-    }
-    const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
-    voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
-  }
-  unsigned voffB;
-  {
-    const int row = tid >> 2;
-    const int c = (tid & 3) ^ ((row >> 2) & 3);
-    voffB = (unsigned)((row * a.Cin + c * 8) * 2);
-  }
-  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
-  const unsigned frame_bytes = (unsigned)(frame_elems * 2);
-  const unsigned wtap_bytes = (unsigned)((long long)BN * a.Cin * 2);
-  const long long wtap_stride = (long long)a.Cout_pad * a.Cin;
-  const int kcn = a.Cin / BK;
-  const int ngroups = a.kt * kcn;
-  const int nk = ngroups * 9;
-
-  auto frame_ptr = [&](int dt) -> const bf16_t* {
-    if (a.kt > 1) {
-      const int fv = t + dt - (a.kt - 1);
-      if (fv >= 0) return a.x + fv * frame_elems;
-      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
-      return a.x;
-    }
-    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-    return a.x + (long long)tin * frame_elems;
-  };
-
-  int h_dt = 0, h_kc = 0;
-  auto stage_halo_round = [&](auto rc, int buf) {
-    constexpr int r = decltype(rc)::value;
-    if (DOVE_DBG(a) & 1) return;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)frame_ptr(h_dt), (short)0, (int)frame_bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + buf * A_BYTES + (r * 512 + wave * 64) * 16), 16, voffA[r],
-                                             h_kc * ROWB, 0, 0);
-  };
-  int b_tap = 0, b_dt = 0, b_kc = 0;
-  int b_slot = 0;                          // ring slot the next staged weight tile goes to
-  auto stage_b = [&]() {
-    const int buf = b_slot;
-    b_slot = (b_slot + 1 == B_RING) ? 0 : b_slot + 1;
-    const bf16_t* wp = a.w + (long long)(b_dt * 9 + b_tap) * wtap_stride + (long long)n0 * a.Cin;
-    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)wp, (short)0, (int)wtap_bytes, 0x00020000);
-    if (!(DOVE_DBG(a) & 2))
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 2 * A_BYTES + buf * B_BYTES + wave * 64 * 16), 16, voffB,
-                                               b_kc * ROWB, 0, 0);
-    if (++b_tap == 9) {
-      b_tap = 0;
-      if (++b_kc == kcn) { b_kc = 0; ++b_dt; }
-    }
-  };
-
-  int boff[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wn * 64 + i * 32 + l31;
-      boff[i][kk] = 2 * A_BYTES + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
-    }
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-
-  auto barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- prologue: halo of group 0, weight tiles of steps 0 and 1 ----
-  stage_halo_round(std::integral_constant<int, 0>{}, 0);
-  stage_halo_round(std::integral_constant<int, 1>{}, 0);
-  if (!kUp) {   // plain `if`: a dependent `if constexpr` inside these nested generic lambdas makes hipcc silently drop the host stub
-    stage_halo_round(std::integral_constant<int, 2>{}, 0);
-    stage_halo_round(std::integral_constant<int, 3>{}, 0);
-    stage_halo_round(std::integral_constant<int, 4>{}, 0);
-    stage_halo_round(std::integral_constant<int, 5>{}, 0);
-  }
-  static_assert(halo8::A_ROUNDS == 6 && (!kUp || NROUNDS == 2), "prologue is written for 6 (2 when kUp) halo rounds");
-  if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
-  stage_b();
-  if (nk > 1) stage_b();
-  if (nk > 2) stage_b();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  barrier();
-  if (grp == 1) barrier();                      // stagger: group B runs one phase behind group A
-  if ((DOVE_DBG(a) & 32) && grp == 1) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger group
-
-  const int abase0 = ((8 * grp + 4 * wm) * HWID + l31) * APITCH + hi * 16;   // byte address of (tile row 4wm, col l31), chunk hi
-  // kUp: input halo row of output row (8grp+4wm+p) tap dh = 4grp + 2wm + 1 + ((p+dh-1)>>1); the "-1" case is folded into
-  // the base (one row lower) so every immediate is >= 0.  Column of lane l31 tap dw = 1 + ((l31+dw-1)>>1).
-  int abaseU[3];
-#pragma unroll
-  for (int dw = 0; dw < 3; ++dw)
-    abaseU[dw] = ((4 * grp + 2 * wm) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
-
-  // kTiming build only: lane 0 of waves 0 and 4 of one workgroup logs s_memtime at 5 points of steps 18..53
-  unsigned long long* tlog = nullptr;
-  if (kTiming && blockIdx.x == 4001 && (wave & 3) == 0 && lane == 0) tlog = (unsigned long long*)a.gate + (wave >> 2) * 36 * 5;
-  int tstep = 0;
-  int rd_slot = 0, issued_prev = 0;        // ring slot read by the current step; loads issued in the previous step
-  auto stamp = [&](int k) {
-    if (kTiming && tlog && tstep >= 18 && tstep < 54) tlog[(tstep - 18) * 5 + k] = __builtin_readcyclecounter();
-  };
-
-  auto step = [&](auto tapc, int g, int R0g, bool more_groups) {
-    constexpr int tap = decltype(tapc)::value;
-    const int gbuf = (g & 1) * A_BYTES;
-    constexpr int dh = tap / 3, dw = tap % 3;
-    stamp(0);
-    // ---------------- phase 1: staging for step s+2, fragment reads for step s ----------------
-    // LDS-DMA issue -> landed is ~1.1 us (longer than a step): weight tiles are staged THREE steps ahead (4-slot ring),
-    // halo rounds of the next group at taps 0..4.
-    int issued = 0;                                    // loads this wave issues in this phase (wave-uniform)
-    if (tap < 6 || more_groups) { stage_b(); ++issued; }
-    if (tap < NROUNDS) {
-      if (more_groups) { stage_halo_round(std::integral_constant<int, tap>{}, (g + 1) & 1); ++issued; }
-    }
-    bf16x8 xf[2][4], wf[2][2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if (kUp) {
-        const int rowimm = (((p + dh + 1) >> 1)) * UHW * APITCH;          // ((p+dh-1)>>1) + 1 rows above the folded base (immediate after unrolling)
-        xf[0][p] = *(const bf16x8*)(smem + abaseU[dw] + gbuf + rowimm);
-        xf[1][p] = *(const bf16x8*)(smem + abaseU[dw] + gbuf + rowimm + 32);
-      } else {
-        xf[0][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH);        // immediate offsets only
-        xf[1][p] = *(const bf16x8*)(smem + R0g + ((p + dh) * HWID + dw) * APITCH + 32);
-      }
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) wf[kk][i] = *(const bf16x8*)(smem + rd_slot * B_BYTES + boff[i][kk]);
-    // Drain everything issued two or more steps ago; the loads of this step AND of the previous one stay in flight.
-    // Loads retire in order, so a counted wait is exact.  Waiting here, in the memory phase, never delays MFMAs.
-    {
-      const int pend = issued + issued_prev;                     // two steps of loads stay in flight
-      if (pend >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else if (pend == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-      else if (pend == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-      else if (pend == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      issued_prev = issued;
-    }
-    stamp(1);
-    barrier();
-    stamp(2);
-    // ---------------- phase 2: MFMAs from registers ----------------
-    if (DOVE_DBG(a) & 4) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { asm volatile("" ::"v"(wf[kk][p & 1]), "v"(xf[kk][p])); }
-    } else {
-    if (!(DOVE_DBG(a) & 8)) __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
-    if (!(DOVE_DBG(a) & 8)) __builtin_amdgcn_s_setprio(0);
-    }
-    stamp(3);
-    barrier();
-    stamp(4);
-    ++tstep;
-    rd_slot = (rd_slot + 1 == B_RING) ? 0 : rd_slot + 1;
-  };
-
-  for (int g = 0; g < ngroups; ++g) {
-    const int R0g = abase0 + (g & 1) * A_BYTES;         // per-lane byte base into this group's halo buffer
-    const bool more = g + 1 < ngroups;
-    step(std::integral_constant<int, 0>{}, g, R0g, more);
-    step(std::integral_constant<int, 1>{}, g, R0g, more);
-    step(std::integral_constant<int, 2>{}, g, R0g, more);
-    step(std::integral_constant<int, 3>{}, g, R0g, more);
-    step(std::integral_constant<int, 4>{}, g, R0g, more);
-    step(std::integral_constant<int, 5>{}, g, R0g, more);
-    step(std::integral_constant<int, 6>{}, g, R0g, more);
-    step(std::integral_constant<int, 7>{}, g, R0g, more);
-    step(std::integral_constant<int, 8>{}, g, R0g, more);
-    if (++h_kc == kcn) { h_kc = 0; ++h_dt; }
-  }
-  if (grp == 0) barrier();                      // balance the stagger barrier of group B
-
-  // ---- epilogue ----
-  const int ow = ow0 + l31;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int oh = oh0 + 8 * grp + 4 * wm + p;
-    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
-    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int cb = n0 + wn * 64 + i * 32 + 8 * gq + 4 * hi;
-        if (cb >= a.Cout_st) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][gq * 4 + e];
-        if (a.bias) {
-          const f32x4 b = *(const f32x4*)(a.bias + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-        if (a.resid) {
-          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-        }
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(a.out + pix * a.ldo + cb) = o;
-      }
-    }
-  }
-}
-
-
 
 // ------------------------------------------------------------------------------------------------
 // conv3x3_halo4x: the same 16 x 32 pixel x 128 channel workgroup tile and LDS image as conv3x3_halo8, but ONE wave per
@@ -1651,173 +1370,6 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// gemm8: the ping-pong structure of conv3x3_halo8 for plain GEMMs (every Linear of the DiT, 1x1x1 convs):
-// 512 rows x 128 output channels per 8-wave workgroup, K-step 32, 3-deep LDS rings for both operands
-// (105 FLOP per staged byte vs 64 in igemm_fast), two 4-wave groups one barrier phase apart.
-// Rows beyond M need no mask: the A descriptor's num_records ends at the last valid row -> zeros.
-// ------------------------------------------------------------------------------------------------
-namespace gemm8 {
-constexpr int BM = 512, BN = 128, BK = 32, ROWB = 64;
-constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;          // 32768, 8192
-constexpr int LDS_BYTES = 3 * (A_BYTES + B_BYTES);                // 122880
-}  // namespace gemm8
-
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(const IgemmArgs a, long long M) {
-  using namespace gemm8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 8);
-  const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = rest % a.tiles_n;
-  const long long m0 = (long long)(rest / a.tiles_n) * BM;
-  const int n0 = tn * BN;
-  const int K = a.Cin;
-  const int nk = K / BK;
-
-  const long long rows_here = (M - m0) < BM ? (M - m0) : BM;
-  const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), (short)0, (int)(rows_here * K * 2), 0x00020000);
-  const auto srd_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)n0 * K), (short)0, (int)((long long)BN * K * 2), 0x00020000);
-  unsigned voffA[4], voffB;
-  {
-    const int rsub = tid >> 2;
-    const int c = (tid & 3) ^ ((rsub >> 2) & 3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) voffA[j] = (unsigned)((((long long)(j * 128 + rsub)) * K + c * 8) * 2);
-    voffB = (unsigned)(((long long)rsub * K + c * 8) * 2);
-  }
-  int s_k = 0;   // next K-step to stage
-  auto stage = [&](auto slotc) {
-    constexpr int SLOT = decltype(slotc)::value;
-    const int soff = s_k * (BK * 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + SLOT * A_BYTES + (j * 512 + wave * 64) * 16), 16, voffA[j], soff, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_b, (lds_ptr_t)(smem + 3 * A_BYTES + SLOT * B_BYTES + wave * 64 * 16), 16, voffB, soff, 0, 0);
-    ++s_k;
-  };
-
-  int aoff[4], boff[2];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = grp * 256 + wm * 128 + p * 32 + l31;
-    aoff[p] = row * ROWB + ((hi ^ ((row >> 2) & 3)) << 4);          // kk = 0; kk = 1 is ^32
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = wn * 64 + i * 32 + l31;
-    boff[i] = 3 * A_BYTES + row * ROWB + ((hi ^ ((row >> 2) & 3)) << 4);
-  }
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-
-  auto barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  stage(std::integral_constant<int, 0>{});
-  if (nk > 1) stage(std::integral_constant<int, 1>{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  barrier();
-  if (grp == 1) barrier();
-
-  auto step = [&](auto slotc, bool stage_next) {
-    constexpr int SLOT = decltype(slotc)::value;
-    if (stage_next) stage(std::integral_constant<int, (SLOT + 2) % 3>{});
-    bf16x8 xf[2][4], wf[2][2];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      xf[0][p] = *(const bf16x8*)(smem + SLOT * A_BYTES + aoff[p]);
-      xf[1][p] = *(const bf16x8*)(smem + SLOT * A_BYTES + (aoff[p] ^ 32));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      wf[0][i] = *(const bf16x8*)(smem + SLOT * B_BYTES + boff[i]);
-      wf[1][i] = *(const bf16x8*)(smem + SLOT * B_BYTES + (boff[i] ^ 32));
-    }
-    if (stage_next) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    barrier();
-    __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i][p], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    barrier();
-  };
-
-  int s = 0;
-  for (; s + 3 <= nk; s += 3) {
-    step(std::integral_constant<int, 0>{}, s + 2 < nk);
-    step(std::integral_constant<int, 1>{}, s + 3 < nk);
-    step(std::integral_constant<int, 2>{}, s + 4 < nk);
-  }
-  if (nk - s >= 1) step(std::integral_constant<int, 0>{}, s + 2 < nk);
-  if (nk - s == 2) step(std::integral_constant<int, 1>{}, false);
-  if (grp == 0) barrier();
-
-  // ---- epilogue (bias, GELU, residual, AdaLN gate) ----
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const long long pix = m0 + grp * 256 + wm * 128 + p * 32 + l31;
-    if (pix >= M) continue;
-    const float* gate = a.gate ? (a.gate + (pix < a.gate_split ? 0 : a.Cout_pad)) : nullptr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cb = n0 + wn * 64 + i * 32 + 8 * g + 4 * hi;
-        if (cb >= a.Cout_st) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][g * 4 + e];
-        if (a.bias) {
-          const f32x4 b = *(const f32x4*)(a.bias + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-        if (a.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-        }
-        if (a.resid) {
-          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
-          float r[4] = {__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u),
-                        __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
-          if (gate) {
-            const f32x4 gg = *(const f32x4*)(gate + cb);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r[e] + gg[e] * v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          }
-        }
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(a.out + pix * a.ldo + cb) = o;
-      }
-    }
-  }
-}
-
 // ---- host side -------------------------------------------------------------------------------
 static bf16_t* g_zero_page[16] = {nullptr};
 
@@ -1838,12 +1390,14 @@ static const bf16_t* zero_page() {
 // environment switches.  Which shapes of the 33x720x1280 clip reach which kernel:
 //   conv3x3_halo4x  3x3(x3) stride-1 convs with Cin % 64 == 0, Cout % 128 == 0, H, W >= 16 (every VAE resnet conv) and the
 //                   upsample-fused 3x3 convs (Upsample3D)                                       268 + 12 launches, 55 % of the step
-//   conv3x3_halo8   the same convs with Cin_pad == 32: encoder.conv_in (3 -> 128), decoder.conv_in (16 -> 512)        8 launches
 //   gemm4x          plain GEMMs with M >= 4096, Cout % 256 == 0, Cin % 128 == 0, Cin >= 256 (DiT qkv / out / ff)    168 launches
-//   gemm8           other plain GEMMs with M >= 4096, Cout % 128 == 0: SpatialNorm conv_y||conv_b (Cin 32), 1x1x1 shortcuts  158
-//   igemm_fast      everything else without upsampling: stride-2 downsample convs, decoder.conv_out (128 -> 3),
-//                   encoder.conv_out, patch / text embedding, proj_out, 3x3 convs of small clips (H or W < 16)            33
-//   igemm (v1)      upsample-fused convs too small for the halo tile, frames above the 31-bit buffer range                0
+//   smallk          pointwise convs with Cin_pad == 32: SpatialNorm conv_y||conv_b on the latent grid                    158 launches
+//   igemm_fast      everything else without upsampling: stride-2 downsample convs, the (3,1,1) forms of encoder.conv_in / decoder.conv_out,
+//                   decoder.conv_in (16 -> 512), the 1x1x1 shortcuts, encoder.conv_out, patch / text embedding, proj_out, the row
+//                   tails of the gemm4x GEMMs, 3x3 convs of small clips (H or W < 16)
+//   igemm (v1)      upsample-fused convs too small for the halo tile (test-sized clips), frames above the 31-bit buffer range     0
+// (The 8-wave ping-pong generations conv3x3_halo8 / gemm8 are gone: every production shape they still carried - 8 + ~10 launches
+// per clip - runs on igemm_fast within noise of its old time.)
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------------------------
 // smallk: out [M][ldo] = x [M][32] w^T [Cout][32] + bias for the 1x1x1 convs with (padded) Cin = 32 - CogVideoXSpatialNorm3D's
@@ -1906,9 +1460,9 @@ __global__ __launch_bounds__(256) void smallk_kernel(const bf16_t* __restrict__ 
   }
 }
 
-enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO8, K_HALO8_UP, K_HALO4X, K_HALO4X_UP, K_GEMM8, K_GEMM4X, K_SMALLK };
-static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo8_kernel", "conv3x3_halo8_kernel",
-                                           "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel", "gemm4x_kernel", "smallk_kernel"};
+enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM4X, K_SMALLK };
+static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm4x_kernel",
+                                           "smallk_kernel"};
 
 static ConvKernel select_kernel(const dove_conv_desc* d) {
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
@@ -1923,9 +1477,6 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
     if (d->cout_pad % 256 == 0 && d->cout_store % 256 == 0 && d->cin % 128 == 0 && d->cin >= 256 && (long long)256 * d->cin * 2 < (1ll << 31) &&
         d->ldo < (1 << 20) && d->ldr < (1 << 20) && (d->act == 0 || d->act == 1))
       return K_GEMM4X;
-    // few, very deep tiles (K > 4096 with < 1024 tiles) run better on the 2-blocks-per-CU igemm_fast
-    const long long g8_tiles = ((M + 511) / 512) * (d->cout_pad / 128);
-    if (g8_tiles >= 1024 || d->cin <= 4096) return K_GEMM8;
   }
   const bool conv3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
                      d->cout_pad % 128 == 0 && frame_fits;
@@ -1933,8 +1484,8 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
     const bool same = d->up == 0 && d->tmode == 0 && d->h_out == d->h_in && d->w_out == d->w_in && d->w_out >= 16 && d->h_out >= 16;
     const bool ups = d->up == 1 && d->kt == 1 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in && d->h_out >= 16 && d->w_out >= 32;
     const bool h4 = d->cout_store % 128 == 0 && d->cin % 64 == 0 && d->ldo < (1 << 20) && (!d->resid || d->ldr < (1 << 20));
-    if (same) return h4 ? K_HALO4X : K_HALO8;
-    if (ups) return h4 ? K_HALO4X_UP : K_HALO8_UP;
+    if (same && h4) return K_HALO4X;
+    if (ups && h4) return K_HALO4X_UP;
   }
   const int BN = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
   const bool fits = frame_fits && (long long)BN * d->cin * 2 < (1ll << 31);
@@ -1954,11 +1505,10 @@ extern "C" const char* dove_conv_kernel_name(const dove_conv_desc* d) { return d
 template <int BN, int BK>
 static int launch_igemm(const IgemmArgs& a, unsigned grid, bool fast, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceOnce attr_set;
+  if (attr_set.first()) {
     (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
   }
   if (fast) hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
@@ -2076,12 +1626,11 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
   switch (kern) {
     case K_GEMM4X: {
-      static bool attr4g = false;
-      if (!attr4g) {
+      static PerDeviceOnce attr4g;
+      if (attr4g.first()) {
         (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-        attr4g = true;
       }
       a.tiles_n = d->cout_pad / 256;
       const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
@@ -2090,10 +1639,9 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const unsigned grid4 = nt > cus ? (unsigned)cus : (unsigned)nt;
 #ifdef DOVE_TIMING_BUILD
       if (DOVE_DBG_BUF && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
-        static bool attrt = false;
-        if (!attrt) {
+        static PerDeviceOnce attrt;
+        if (attrt.first()) {
           (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          attrt = true;
         }
         a.zero = (const bf16_t*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
@@ -2116,19 +1664,6 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(smallk)");
       return DOVE_OK;
     }
-    case K_GEMM8: {
-      static bool attrg = false;
-      if (!attrg) {
-        (void)hipFuncSetAttribute((const void*)gemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8::LDS_BYTES);
-        attrg = true;
-      }
-      a.tiles_n = d->cout_pad / 128;
-      const long long gridg = ((M + gemm8::BM - 1) / gemm8::BM) * a.tiles_n;
-      DOVE_CHECK_ARG(gridg > 0 && gridg < (1ll << 31), "conv_igemm: grid too large");
-      hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)gridg), dim3(512), gemm8::LDS_BYTES, s, a, M);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8)");
-      return DOVE_OK;
-    }
     case K_HALO4X:
     case K_HALO4X_UP: {
       a.gn_partial = d->gn_partial;
@@ -2138,14 +1673,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       a.tiles_n = d->cout_pad / 128;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
-      static bool attr4 = false;
-      if (!attr4) {
+      static PerDeviceOnce attr4;
+      if (attr4.first()) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #endif
-        attr4 = true;
       }
       const int cus = cu_count();                              // persistent: one workgroup per CU walks its share of the tiles
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
@@ -2158,33 +1692,6 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
-      return DOVE_OK;
-    }
-    case K_HALO8:
-    case K_HALO8_UP: {
-      static bool attr8 = false;
-      if (!attr8) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-#ifdef DOVE_TIMING_BUILD
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, halo8::LDS_BYTES);
-#endif
-        attr8 = true;
-      }
-      a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
-      a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
-      a.tiles_n = d->cout_pad / 128;
-      const long long g3 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
-      DOVE_CHECK_ARG(g3 > 0 && g3 < (1ll << 31), "conv_igemm: grid too large");
-#ifdef DOVE_TIMING_BUILD
-      if (DOVE_DBG_BUF && kern == K_HALO8) {   // per-phase s_memtime log of one workgroup (tools/halo8_timing.py)
-        a.gate = (const float*)DOVE_DBG_BUF;
-        hipLaunchKernelGGL((conv3x3_halo8_kernel<true, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
-      } else
-#endif
-      if (kern == K_HALO8_UP) hipLaunchKernelGGL((conv3x3_halo8_kernel<false, true>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
-      else hipLaunchKernelGGL((conv3x3_halo8_kernel<false, false>), dim3((unsigned)g3), dim3(512), halo8::LDS_BYTES, s, a);
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo8)");
       return DOVE_OK;
     }
     default: break;

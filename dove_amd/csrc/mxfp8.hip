@@ -484,12 +484,11 @@ extern "C" int dove_linear_mxfp8(const void* xq, const void* xs, const void* wq,
   a.x = (const unsigned char*)xq; a.w = (const unsigned char*)wq; a.xs = (const unsigned*)xs; a.ws = (const unsigned*)ws;
   a.bias = bias; a.resid = (const bf16_t*)resid; a.gate = gate; a.out = (bf16_t*)out;
   a.M = M; a.ldo = ldo; a.ldr = ldr; a.gate_split = gate_split; a.N = N; a.K = K; a.tiles_n = N / 256;
-  static bool attr = false;
-  if (!attr) {
+  static PerDeviceOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);
-    attr = true;
   }
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);

@@ -27,6 +27,29 @@ class _Unavailable:
     __getattr__ = lambda self, n: self.__call__()   # noqa: E731
 
 
+class _Lazy:
+    """``pipe.text_encoder`` / ``pipe.tokenizer`` of a loaded checkpoint: the object is built by ``loader()`` on first use (call or
+    attribute access) and kept."""
+
+    def __init__(self, what, loader):
+        self.__dict__.update(_what=what, _loader=loader, _obj=None)
+
+    def _get(self):
+        if self._obj is None:
+            self.__dict__["_obj"] = self._loader()
+        return self._obj
+
+    @property
+    def loaded(self):
+        return self._obj is not None
+
+    def __call__(self, *a, **k):
+        return self._get()(*a, **k)
+
+    def __getattr__(self, n):
+        return getattr(self._get(), n)
+
+
 class CogVideoXPipeline:
     def __init__(self, vae, transformer, scheduler, text_encoder=None, tokenizer=None):
         self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
@@ -45,14 +68,24 @@ class CogVideoXPipeline:
         tcfg, tsd = W.load_component(os.path.join(model_path, "transformer"), W.dit_param_shapes)
         with open(os.path.join(model_path, "scheduler", "scheduler_config.json")) as f:
             scfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        # The documented runs use the cached empty-prompt embedding (ref :423-428): the T5-XXL encoder (~9.5 GB packed) and
+        # transformers' tokenizer are constructed on the first non-empty prompt, not here
         text_encoder = tokenizer = None
-        if os.path.isdir(os.path.join(model_path, "text_encoder")):
-            from .t5 import T5EncoderModel
-            text_encoder = T5EncoderModel.from_pretrained(os.path.join(model_path, "text_encoder"), device, torch_dtype)
-        if os.path.isdir(os.path.join(model_path, "tokenizer")):
-            # host-side text processing: transformers' own T5 tokenizer, exactly what the reference's pipeline holds
-            from transformers import AutoTokenizer
-            tokenizer = AutoTokenizer.from_pretrained(os.path.join(model_path, "tokenizer"))
+        te_dir, tok_dir = os.path.join(model_path, "text_encoder"), os.path.join(model_path, "tokenizer")
+        if os.path.isdir(te_dir):
+            def _load_te(te_dir=te_dir):
+                from .t5 import T5EncoderModel
+                return T5EncoderModel.from_pretrained(te_dir, device, torch_dtype)
+            text_encoder = _Lazy("text_encoder (T5)", _load_te)
+        if os.path.isdir(tok_dir):
+            def _load_tok(tok_dir=tok_dir):
+                try:      # host-side text processing: transformers' own T5 tokenizer, exactly what the reference's pipeline holds
+                    from transformers import AutoTokenizer
+                except ImportError as e:
+                    raise NotImplementedError("a non-empty prompt needs the `transformers` package for the T5 tokenizer "
+                                              "(the empty prompt uses the shipped embedding and needs neither)") from e
+                return AutoTokenizer.from_pretrained(tok_dir)
+            tokenizer = _Lazy("tokenizer", _load_tok)
         return cls(AutoencoderKLCogVideoX(vcfg, vsd, device, torch_dtype),
                    CogVideoXTransformer3DModel(tcfg, tsd, device, torch_dtype, dit_linear_precision, dit_attention_precision), CogVideoXDPMScheduler(**scfg),
                    text_encoder, tokenizer)

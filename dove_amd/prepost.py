@@ -13,13 +13,33 @@ import torch
 from . import ops, tiling
 
 
-def preprocess_frames(frames_u8: torch.Tensor, upscale: int = 4, dtype=torch.bfloat16, device="cuda"):
-    """[F,H,W,3] uint8 -> ([1,3,F',H',W'] in [-1,1] on the GPU, pad_f, pad_h, pad_w, original_shape)."""
+def preprocess_frames(frames_u8: torch.Tensor, upscale: int = 4, dtype=torch.bfloat16, device="cuda", upscale_mode: str = "bilinear"):
+    """[F,H,W,3] uint8 -> ([1,3,F',H',W'] in [-1,1] on the GPU, pad_f, pad_h, pad_w, original_shape).
+
+    ``upscale_mode`` is the reference's ``--upscale_mode`` (ref :672: ``F.interpolate(video, size, mode=..., align_corners=False)``).
+    "bilinear" (the default of every documented run) is the fused HIP kernel ``dove_preprocess_u8``; any other mode torch accepts with
+    ``align_corners=False`` ("bicubic") runs the same three script steps - pad, ``F.interpolate``, ``/255*2-1`` - with torch on
+    the device: script-level pre-processing, not part of the accelerated operator."""
     F, H, W, C = frames_u8.shape
     assert C == 3 and frames_u8.dtype == torch.uint8
     pad_f, pad_h, pad_w = tiling.match_padding(F, H, W)
-    video = ops.preprocess_u8(frames_u8.to(device).contiguous(), pad_f, pad_h, pad_w, upscale, dtype)
+    if upscale_mode == "bilinear":
+        video = ops.preprocess_u8(frames_u8.to(device).contiguous(), pad_f, pad_h, pad_w, upscale, dtype)
+    else:
+        video = preprocess_frames_torch(frames_u8.to(device), pad_f, pad_h, pad_w, upscale, upscale_mode, dtype)
     return video[None], pad_f, pad_h, pad_w, (F, H, W, C)
+
+
+def preprocess_frames_torch(frames_u8, pad_f, pad_h, pad_w, upscale, upscale_mode, dtype):
+    """The reference's own three steps (``preprocess_video_match`` padding :220-233, ``F.interpolate`` :672, normalise :673-676):
+    [F,H,W,3] uint8 -> [3,F',H',W'] in [-1,1]."""
+    v = frames_u8.permute(0, 3, 1, 2).float()                               # [F,C,H,W] like decord + permute (ref :206)
+    if pad_f:
+        v = torch.cat([v, v[-1:].repeat(pad_f, 1, 1, 1)], dim=0)            # repeat the last frame (ref :222-224)
+    if pad_h or pad_w:
+        v = torch.nn.functional.pad(v, (0, pad_w, 0, pad_h))                # zeros, bottom / right (ref :232)
+    v = torch.nn.functional.interpolate(v, size=(v.shape[2] * upscale, v.shape[3] * upscale), mode=upscale_mode, align_corners=False)
+    return (v / 255.0 * 2.0 - 1.0).permute(1, 0, 2, 3).contiguous().to(dtype)
 
 
 def postprocess_frames(video: torch.Tensor, pad_f: int, pad_h: int, pad_w: int, crop_scale: int = 4) -> torch.Tensor:

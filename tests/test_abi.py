@@ -88,7 +88,7 @@ def test_dispatch_rule_mirror(lib):
         (512, 512, (3, 3, 3), 2, 90, 160, 0, 1, True),
         (256, 256, (3, 3), 4, 360, 640, 1, 1, True),         # upsample-fused conv
         (128, 128, (3, 3), 8, 720, 1280, 0, 2, False),       # stride-2 downsample: generic kernel, separate stats pass
-        (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1, False),     # conv_in (Cin padded 3 -> 32): 8-wave kernel
+        (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1, False),     # direct conv_in (Cin padded 3 -> 32; tiled path only): generic kernel
         (128, 32, (3, 3, 3), 8, 720, 1280, 0, 1, False),     # conv_out (Cout 3 -> 32)
         (512, 512, (3, 3, 3), 2, 8, 32, 0, 1, False),        # H < 16: 4-wave halo kernel
         (3072, 9216, (1, 1, 1), 1, 1, 18226, 0, 1, False),   # a DiT linear
@@ -105,7 +105,7 @@ def test_dispatch_rule_mirror(lib):
     names = {  # production shape -> kernel (cin, cout, k, T, H, W, up, stride)
         (32, 1024, (1, 1, 1), 2, 90, 160, 0, 1): "smallk_kernel",           # SpatialNorm conv_y || conv_b on the latent grid
         (3072, 9216, (1, 1, 1), 1, 1, 18226, 0, 1): "gemm4x_kernel",
-        (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1): "conv3x3_halo8_kernel",
+        (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1): "igemm_fast_kernel",
         (128, 32, (3, 3, 3), 8, 720, 1280, 0, 1): "igemm_fast_kernel",
         (128, 128, (3, 3), 8, 720, 1280, 0, 2): "igemm_fast_kernel",
     }
@@ -159,14 +159,14 @@ def test_kernel_dispatch_table():
         "resnet conv 128->128 @ 9x720x1280": (name((9, 720, 1280), 128, 128, (3, 3, 3), resid=True), "conv3x3_halo4x_kernel"),
         "resnet conv 512->512 @ 3x90x160": (name((3, 90, 160), 512, 512, (3, 3, 3)), "conv3x3_halo4x_kernel"),
         "upsample conv 256->256 @ 360x640 -> 720x1280": (name((8, 360, 640), 256, 256, (3, 3), up=1, pad=(1, 1)), "conv3x3_halo4x_kernel"),
-        "encoder.conv_in 3->128": (name((9, 720, 1280), 128, 3, (3, 3, 3)), "conv3x3_halo8_kernel"),
-        "decoder.conv_in 16->512": (name((3, 90, 160), 512, 16, (3, 3, 3)), "conv3x3_halo8_kernel"),
+        "encoder.conv_in 3->128 (direct form: tiled VAE only)": (name((9, 720, 1280), 128, 3, (3, 3, 3)), "igemm_fast_kernel"),
+        "decoder.conv_in 16->512": (name((3, 90, 160), 512, 16, (3, 3, 3)), "igemm_fast_kernel"),
         "decoder.conv_out 128->3": (name((9, 720, 1280), 3, 128, (3, 3, 3)), "igemm_fast_kernel"),
         "downsample conv stride 2": (name((9, 720, 1280), 128, 128, (3, 3), stride=2, pad=(0, 0)), "igemm_fast_kernel"),
         "DiT qkv 3072->9216": (name((1, 1, 18226), 9216, 3072, ()), "gemm4x_kernel"),
         "DiT ff2 12288->3072 gated": (name((1, 1, 18226), 3072, 12288, (), gated=True), "gemm4x_kernel"),
         "SpatialNorm conv_y||conv_b 16->256": (name((3, 90, 160), 256, 16, (1, 1, 1)), "smallk_kernel"),
-        "resnet shortcut 256->128 @ 720p": (name((9, 720, 1280), 128, 256, (1, 1, 1)), "gemm8_kernel"),
+        "resnet shortcut 256->128 @ 720p": (name((9, 720, 1280), 128, 256, (1, 1, 1)), "igemm_fast_kernel"),
         "text embedding 4096->3072 (226 rows)": (name((1, 1, 226), 3072, 4096, ()), "igemm_fast_kernel"),
     }
     for what, (got, want) in prod.items():
@@ -178,5 +178,5 @@ def test_kernel_dispatch_table():
         covered.add(name((Tt, H, W), cout, cin, k, resid=resid, **kw))
     for cname, N, cin, cout, kw in T.LIN_CASES:
         covered.add(name((1, 1, N), cout, cin, (), act=kw.get("act", 0), gated=kw.get("gate", False), resid=kw.get("resid_only", False)))
-    assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo8_kernel", "conv3x3_halo4x_kernel", "gemm8_kernel",
-                       "gemm4x_kernel", "smallk_kernel"}, covered
+    # the superseded 8-wave generations (conv3x3_halo8, gemm8) no longer exist: five kernels carry every shape
+    assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "gemm4x_kernel", "smallk_kernel"}, covered

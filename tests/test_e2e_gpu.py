@@ -404,3 +404,19 @@ def test_cli_random_init_npy_and_png(golden_dir, tmp_path):
     assert res.shape == (7, 80, 112, 3) and res.dtype == np.uint8 and res.std() > 0
     cli.main(common + ["--output_path", str(out), "--png_save"])
     assert len(list((out / "clip0").glob("*.png"))) == 7
+    # the rest of the reference's parser (ref :507-554): accepted with the reference's meaning
+    out2 = tmp_path / "out2"
+    cli.main(common + ["--output_path", str(out2), "--upscale_mode", "bicubic", "--is_cpu_offload", "--fps", "24", "--save_format", "yuv420p",
+                       "--gt_dir", str(out), "--eval_metrics", "psnr"])
+    res2 = np.load(out2 / "clip0.npy")
+    assert res2.shape == res.shape and not np.array_equal(res2, res)          # bicubic input differs from bilinear input
+    with pytest.raises(ValueError, match="bfloat16"):
+        cli.main(common + ["--output_path", str(out2), "--dtype", "float16"])
+    with pytest.raises(NotImplementedError, match="pyiqa"):
+        cli.main(common + ["--output_path", str(out2), "--eval_metrics", "psnr,lpips", "--gt_dir", str(out)])
+    # the torch route of --upscale_mode (pad, F.interpolate, normalise) agrees with the fused HIP kernel on its own mode
+    from dove_amd import prepost
+    fr = torch.from_numpy(clip)
+    a = prepost.preprocess_frames(fr, 4)[0]
+    b = prepost.preprocess_frames_torch(fr.cuda(), 2, 12, 4, 4, "bilinear", torch.bfloat16)[None]
+    assert a.shape == b.shape and float((a.float() - b.float()).abs().max()) <= 2 ** -7

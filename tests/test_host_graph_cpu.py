@@ -173,6 +173,15 @@ def test_prepost_roundtrip_cpu(monkeypatch, tmp_path):
     assert video.shape == (1, 3, 9, 192, 320) and float(video.min()) >= -1 and float(video.max()) <= 1
     out = prepost.postprocess_frames((video * 0.5 + 0.5), pf, ph, pw)
     assert out.shape == (8, 180, 320, 3) and out.dtype == torch.uint8
+    # --upscale_mode: the torch route (the reference's own pad / F.interpolate / normalise, ref :220-233, :672-676) == the operator on
+    # "bilinear"; "bicubic" is the other mode the reference's `align_corners=False` call accepts
+    alt = prepost.preprocess_frames_torch(loaded, pf, ph, pw, 4, "bilinear", torch.float32)[None]
+    assert alt.shape == video.shape and float((alt - video).abs().max()) < 1e-5
+    cub, a1, b1, c1, _ = prepost.preprocess_frames(loaded, upscale=4, dtype=torch.float32, device="cpu", upscale_mode="bicubic")
+    assert cub.shape == video.shape and (a1, b1, c1) == (pf, ph, pw) and float((cub - video).abs().max()) > 1e-3
+    assert torch.equal(cub[0, :, 8], cub[0, :, 7])                 # frame padding repeats the last frame before the resize
+    with pytest.raises(ValueError):
+        prepost.preprocess_frames(loaded, upscale=4, dtype=torch.float32, device="cpu", upscale_mode="nearest")   # as in the reference: align_corners
     # identity check at the LR sample positions is not exact (bilinear), but constant frames must survive exactly
     const = torch.full((3, 16, 16, 3), 200, dtype=torch.uint8)
     v, a, b, c, _ = prepost.preprocess_frames(const, upscale=2, dtype=torch.float32, device="cpu")
@@ -219,6 +228,14 @@ def test_from_pretrained_and_lora_fuse(monkeypatch, tmp_path):
     assert torch.equal(pipe.transformer.blocks[1]["qkv"].w, ref.transformer.blocks[1]["qkv"].w)
     assert torch.equal(pipe.vae.pc["decoder.conv_in"].w, ref.vae.pc["decoder.conv_in"].w)
     assert abs(float(pipe.scheduler.alphas_cumprod[399]) - 0.3935440575) < 1e-6
+    # text_encoder/ and tokenizer/ are only opened by the first non-empty prompt (the documented runs use the shipped empty-prompt
+    # embedding): a checkpoint whose T5 directory is unreadable still loads, and says what is wrong when a prompt needs it
+    os.makedirs(tmp_path / "ckpt" / "text_encoder")
+    os.makedirs(tmp_path / "ckpt" / "tokenizer")
+    lazy = CogVideoXPipeline.from_pretrained(str(tmp_path / "ckpt"), torch_dtype=torch.bfloat16, device="cpu")
+    assert not lazy.text_encoder.loaded and not lazy.tokenizer.loaded
+    with pytest.raises(Exception):
+        lazy.tokenizer("a prompt", return_tensors="pt")
     # strictness: a checkpoint with a missing tensor or a wrong shape must fail loudly
     import json
     wt_bad = {k: x for k, x in wt.items() if k != "proj_out.bias"}

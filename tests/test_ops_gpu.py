@@ -54,7 +54,7 @@ CONV_CASES = [
     ("c3d_96_64", 96, 64, (3, 3, 3), 2, 8, 8, {}),
     ("c111_128_256", 128, 256, (1, 1, 1), 3, 9, 11, {}),
     ("c111_16_1024", 16, 1024, (1, 1, 1), 3, 4, 6, {}),
-    ("c111_gemm8", 128, 256, (1, 1, 1), 2, 48, 64, {}),
+    ("c111_M6144", 128, 256, (1, 1, 1), 2, 48, 64, {}),            # a plain GEMM that misses gemm4x's shape rules: igemm_fast
     # smallk_kernel: CogVideoXSpatialNorm3D's conv_y || conv_b on the 16-channel latent (Cin_pad 32), ragged last row block
     ("c111_smallk_spatialnorm", 16, 512, (1, 1, 1), 2, 45, 81, {}),
     ("c2d_down_even", 128, 128, (3, 3), 3, 16, 20, {"stride": 2, "pad": (0, 0)}),
@@ -69,9 +69,9 @@ CONV_CASES = [
     ("c3d_halo_resid", 128, 128, (3, 3, 3), 2, 17, 33, {"resid": True, "cache": True}),
     ("c3d_halo_cin3", 3, 128, (3, 3, 3), 4, 12, 48, {}),
     ("c3d_halo_512", 512, 512, (3, 3, 3), 2, 8, 32, {}),
-    # 8-wave ping-pong halo kernel (H >= 16): 3 x 3 tiles of 16x32 with ragged edges, 2 cout tiles
-    ("c3d_halo8_tiles", 64, 256, (3, 3, 3), 2, 40, 70, {"cache": True, "resid": True}),
-    ("c3d_halo8_512", 512, 128, (3, 3, 3), 1, 16, 32, {}),
+    # 3 x 3 tiles of 16x32 with ragged edges, 2 cout tiles (the shapes that used to pin the 8-wave ping-pong kernel)
+    ("c3d_tiles_ragged", 64, 256, (3, 3, 3), 2, 40, 70, {"cache": True, "resid": True}),
+    ("c3d_512_128_T1", 512, 128, (3, 3, 3), 1, 16, 32, {}),
     # upsample-fused conv on the ping-pong halo kernel (UP variant): ragged tiles, both temporal maps
     ("c2d_up8", 128, 128, (3, 3), 2, 20, 40, {"up": 1, "pad": (1, 1)}),
     ("c2d_up8_t2", 64, 256, (3, 3), 3, 9, 17, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
@@ -80,9 +80,9 @@ CONV_CASES = [
     # so the staging streams cross a tile boundary every 18 steps) with more tiles than workgroups, and a kt = 1 conv
     ("c2d_halo4x_k64_many", 64, 128, (3, 3), 20, 64, 128, {}),
     ("c2d_halo4x_kt1_resid", 128, 256, (3, 3), 2, 24, 40, {"resid": True}),
-    # conv3x3_halo8 at its production roles: Cin_pad == 32 convs with H, W >= 16 (encoder.conv_in 3 -> 128, decoder.conv_in 16 -> 512)
-    ("c3d_halo8_conv_in_enc", 3, 128, (3, 3, 3), 3, 40, 48, {"cache": True}),
-    ("c3d_halo8_conv_in_dec", 16, 512, (3, 3, 3), 2, 18, 34, {}),
+    # Cin_pad == 32 convs with H, W >= 16 (direct encoder.conv_in 3 -> 128 of the tiled VAE, decoder.conv_in 16 -> 512): igemm_fast
+    ("c3d_conv_in_enc", 3, 128, (3, 3, 3), 3, 40, 48, {"cache": True}),
+    ("c3d_conv_in_dec", 16, 512, (3, 3, 3), 2, 18, 34, {}),
 ]
 
 
@@ -117,7 +117,7 @@ LIN_CASES = [
     ("lin_12288_3072_gate_inplace", 270, 12288, 3072, {"gate": True, "inplace": True}),
     ("lin_M1", 1, 256, 256, {}),
     ("lin_M129", 129, 256, 64, {}),
-    # gemm8 ping-pong kernel (M >= 4096): ragged M tail, every K-loop tail length (nk = 1, 2, 3, 4, 96), epilogues
+    # plain GEMMs with M >= 4096 that miss gemm4x's shape rules (were gemm8, now igemm_fast): ragged M tail, every K-loop tail length (nk = 1, 2, 3, 4, 96), epilogues
     ("lin8_basic", 4700, 3072, 256, {}),
     ("lin8_gelu", 4096, 256, 1024, {"act": 1}),
     ("lin8_gate_inplace", 5000, 1024, 128, {"gate": True, "inplace": True}),
