@@ -250,10 +250,7 @@ def test_vae_sharded_halo_exchange_c_level(both, R):
     satisfies every receive.  Gathered frames must equal the single-context result bit for bit (encode: 33 frames = 4 batches,
     decode: 9 latent frames = 4 batches; with R = 3 one rank owns two batches)."""
     import ctypes as C
-    pipe, ctx0, (v, t, s) = both
-    seed = 31
-    wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
-    wt = weights.random_state_dict(weights.dit_param_shapes(t), seed)
+    pipe, ctx0, (v, t, s, wv, wt) = both
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     box = {}                                                   # (src, dst) -> list of uint8 tensors in send order
@@ -320,7 +317,7 @@ def test_vae_sharded_halo_exchange_c_level(both, R):
 def test_comm_init_rccl_single_rank(both):
     """The RCCL transport binding (librccl opened at run time, ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy) on the one GPU a
     test box has: a 1-rank communicator must come up, leave the stages unchanged and go away again."""
-    pipe, ctx0, (v, t, s) = both
+    pipe, ctx0, (v, t, s, _wv, _wt) = both
     g = torch.Generator().manual_seed(5)
     video = (torch.rand(3, 17, 32, 48, generator=g) * 2 - 1).to(BF).cuda()
     ref = ctx0.vae_encode(video)
