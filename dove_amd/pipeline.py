@@ -107,8 +107,8 @@ class CogVideoXPipeline:
     @staticmethod
     def _check_dtype(dt):
         if dt != torch.bfloat16:
-            raise NotImplementedError("the HIP path computes in bf16 (fp32 accumulation); pass torch_dtype=torch.bfloat16 "
-                                      "(the reference's default, ref :525)")
+            raise NotImplementedError(f"torch_dtype={dt}: the HIP path computes in bf16 (fp32 accumulation); pass torch_dtype=torch.bfloat16, "
+                                      "the reference's default (ref :525); float16 / float32 are not implemented (INTEGRATION.md, 'dtype')")
 
     # ---- reference surface ------------------------------------------------------------------------
     @property
