@@ -19,6 +19,8 @@ pipe = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn_pipe_exp.so"))      # 
 pipe.attn_exp3.argtypes = exp.attn_exp.argtypes
 g2 = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn2g_exp.so"))          # variants 40+: two wave groups one barrier phase apart
 g2.attn_exp4.argtypes = exp.attn_exp.argtypes
+qb2 = C.CDLL(os.path.join(ROOT, "tools", "exp", "libattn_qb2_exp.so"))        # variants 50+: two query blocks per wave, skewed
+qb2.attn_exp5.argtypes = exp.attn_exp.argtypes
 BF = torch.bfloat16
 _swapped = {}
 
@@ -35,6 +37,10 @@ def vswap(V):
 def run(variant, Q, K, V, N, npad, heads, out):
     if variant < 0:                                # the product kernel reads V^T in the quad-swapped key order
         return ops.attention(Q, K, vswap(V), N, npad, heads, out)
+    if variant >= 50:
+        rc = qb2.attn_exp5(variant, Q.data_ptr(), K.data_ptr(), vswap(V).data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
+        assert rc == 0, rc
+        return out
     if variant >= 40:
         rc = g2.attn_exp4(variant, Q.data_ptr(), K.data_ptr(), vswap(V).data_ptr(), out.data_ptr(), N, npad, heads, out.shape[1], L.stream_ptr())
         assert rc == 0, rc

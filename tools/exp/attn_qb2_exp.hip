@@ -1,3 +1,11 @@
+// OUTCOME (profiles/r03_attn_qb2.log): NOT usable as written.  (i) 360 registers: hipcc keeps S / P in AGPRs and moves them through
+// ~350 v_accvgpr_read/write per iteration (VALU cannot address AGPRs): 8.6 ms vs 4.3 ms for the product kernel; (ii) the results are
+// WRONG (max err 5.8): with both query blocks' MFMA chains and VALU in one scheduling region the compiler places a VALU reader of the
+// inline-asm MFMA's result inside its 12-wait-state window - the hazard of an asm statement it cannot see (guide 5.7 item 2; the
+// product kernel is pinned against this by tests/test_isa_checks.py).  A working version needs every MFMA in asm with explicit
+// "a" / "v" register classes and a hand-placed 1 MFMA : 5 VALU interleave; tools/coissue.py bounds what that could gain at ~13 %
+// of the attention time (478 ns per 16 MFMA + softmax mix against 540 ns now).  Kept as the record of the attempt.
+//
 // EXPERIMENT (tools/attn_ab.py variants 50+; never loaded by dove_amd): flash attention forward, head_dim 64, ONE wave per SIMD,
 // TWO query blocks per wave, skewed by half a tile so that every block of 16 MFMAs has the softmax VALU of the OTHER query block to
 // interleave with IN THE SAME WAVE.
