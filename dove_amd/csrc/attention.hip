@@ -19,13 +19,14 @@
 // exceeds it by THR = 2^6; then O, l, the current tile's S and the -m registers are rescaled once, BEFORE the tile's
 // P is exponentiated (the safe order of T13).  P <= 64 in bf16 keeps its 8-bit relative precision and O / l accumulate
 // in fp32, so the result matches the exact-max formulation to rounding (tests: spiked keys early / late, full tensor).
-// Measured on MI355X at N = 18226, 48 heads (tools/attn_ab.py, within-run A/B; profiles/r02_attn_ab.log): 0.93-0.95 PF vs
-// 0.89-0.91 for the round-1 kernel.  What did NOT pay (same harness): row sum on the matrix pipe (ones x P^T, -2 %), four
-// partial sums / v_pk_add (0 %), the shift as a fifth K slice (+1 % but 2x the rounding error), two query blocks per
-// wave (+3 % only with the fifth slice; 248 registers).  An instruction-rate microbenchmark (tools/ubench.py) puts a
-// wave64 v_exp_f32 / v_permlane32_swap at ~9 cycles per SIMD, v_max3 / v_cvt_pk at ~4.4, v_add at ~2.4, and a dense
-// random-data 32x32x16 MFMA storm at 27 ns per instruction per SIMD (1.24 PF: the chip is power-limited there), so at
-// head_dim 64 the kernel sits at ~75 % of what the matrix pipe sustains on this data.
+// Measured on MI355X at N = 18226, 48 heads (tools/attn_ab.py, within-run A/B; profiles/r02_attn_ab.log, r03_*): 0.93-0.99 PF by box
+// (round 1: 0.88-0.91).  What did NOT pay (same harness): row sum on the matrix pipe (ones x P^T, -2 %), four partial sums / v_pk_add
+// (0 %), the shift as a fifth K slice (+1 % but 2x the rounding error), two query blocks per wave, in-wave software pipelining (+3 %),
+// 6 / 8 waves per workgroup, and - round 3 - two wave groups one barrier phase apart (tools/exp/attn2g_exp.hip: 0.94-0.98x).
+// tools/coissue.py shows what bounds all of them: on gfx950 the MFMAs of one wave and the VALU of ANOTHER wave on the same SIMD
+// serialize completely (t = t_mfma + t_valu at any priority); only VALU instructions that follow an MFMA in the same wave's own
+// stream hide under it (about half of the softmax mix).  Per 32 x 64 wave-tile: 16 MFMAs = 290 ns on N(0,1)-like operands
+// (the pipes throttle with operand toggling: 1.9 PF sustained, tools/mfma_storm.py), softmax VALU = 311-353 ns, measured 540 ns.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -50,18 +51,30 @@ __device__ __forceinline__ f32x16 mfma_c_in(bf16x8 a, bf16x8 b, const f32x16& c)
   return d;
 }
 
-template <int NW>   // waves per workgroup: NW x 32 queries share every K / V^T tile (waves 0-3 stage them)
+// NW = waves per workgroup: NW x 32 queries share every K / V^T tile (waves 0-3 stage them).
+// XCD: 1-D grid of heads x query-blocks, remapped so that each XCD (= blockIdx % 8, its own L2) walks a CONTIGUOUS range of the
+// head-major tile list: the ~64 workgroups an XCD runs at a time then belong to one or two heads and stream the same K / V^T tiles
+// through one L2, instead of every XCD streaming every head (the 2-D grid puts consecutive query blocks of a head on 8 XCDs).
+template <int NW, bool XCD = true>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                          long long N, long long Npad, long long ldo) {
+                                                          long long N, long long Npad, long long ldo, int qblocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384, VOFF = 8192;
   constexpr float THR = 6.0f;                    // rescale when a score exceeds the running max by 2^6
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y;
-  const long long q0 = (long long)blockIdx.x * (NW * 32) + wave * 32;
+  int h, qb;
+  if (XCD) {
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    h = (int)(t / (unsigned)qblocks);
+    qb = (int)(t - (unsigned)h * (unsigned)qblocks);
+  } else {
+    h = blockIdx.y;
+    qb = blockIdx.x;
+  }
+  const long long q0 = (long long)qb * (NW * 32) + wave * 32;
 
   bf16x8 qf[4];
   {
@@ -243,31 +256,40 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
   static PerDeviceOnce attr_set;
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
-  dim3 grid((unsigned)((Npad + NW * 32 - 1) / (NW * 32)), heads);
-  hipLaunchKernelGGL(attn_fwd_kernel<NW>, grid, dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
-                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  const int qblocks = (int)((Npad + NW * 32 - 1) / (NW * 32));
+  DOVE_CHECK_ARG((long long)qblocks * heads < (1ll << 31), "attention_fwd: grid too large");
+  hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), dim3((unsigned)(qblocks * heads)), dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
+                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
 }
 
 #ifdef DOVE_TIMING_BUILD
-// tools/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS), within one run
+// tools/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS) on the 2-D grid, and
+// nw = 14: 4 waves with the XCD-contiguous 1-D grid (the product mapping), within one run
 extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads,
                                           long long ldo, int nw, void* stream) {
   constexpr int LDS = 4 * 16384;
   static PerDeviceOnce attr_set;
   if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
-  dim3 grid((unsigned)((Npad + nw * 32 - 1) / (nw * 32)), heads);
-  if (nw == 4) hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
-  else if (nw == 6) hipLaunchKernelGGL(attn_fwd_kernel<6>, grid, dim3(384), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
-  else if (nw == 8) hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(512), LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo);
+  const int w = nw == 14 ? 4 : nw;
+  const int qblocks = (int)((Npad + w * 32 - 1) / (w * 32));
+  dim3 grid((unsigned)qblocks, heads);
+  hipStream_t s = (hipStream_t)stream;
+#define ATTN_ARGS (const bf16_t*)Qh, (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks
+  if (nw == 4) hipLaunchKernelGGL((attn_fwd_kernel<4, false>), grid, dim3(256), LDS, s, ATTN_ARGS);
+  else if (nw == 6) hipLaunchKernelGGL((attn_fwd_kernel<6, false>), grid, dim3(384), LDS, s, ATTN_ARGS);
+  else if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<8, false>), grid, dim3(512), LDS, s, ATTN_ARGS);
+  else if (nw == 14) hipLaunchKernelGGL((attn_fwd_kernel<4, true>), dim3((unsigned)(qblocks * heads)), dim3(256), LDS, s, ATTN_ARGS);
   else return -1;
+#undef ATTN_ARGS
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16_nw");
   return DOVE_OK;
 }

@@ -180,15 +180,24 @@ extern "C" int dove_qkv_post_mxfp8(const void* qkv, long long N, long long Npad,
 template <int NW>   // waves per workgroup sharing each K / V^T tile (waves 0-3 stage)
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mx_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ K8,
                                                              const unsigned char* __restrict__ V8t, const unsigned char* __restrict__ Vs,
-                                                             bf16_t* __restrict__ O, long long N, long long Npad, long long ldo) {
+                                                             bf16_t* __restrict__ O, long long N, long long Npad, long long ldo, int qblocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 8192, VOFF = 4096;
   constexpr float THR = 6.0f;                    // rescale when a score exceeds the running max by 2^6
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const int h = blockIdx.y;
-  const long long q0 = (long long)blockIdx.x * (NW * 32) + wave * 32;
+  // qblocks > 0: 1-D grid, each XCD walks a contiguous range of the head-major tile list (see attention.hip); 0: 2-D grid
+  int h, qb;
+  if (qblocks > 0) {
+    const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+    h = (int)(t / (unsigned)qblocks);
+    qb = (int)(t - (unsigned)h * (unsigned)qblocks);
+  } else {
+    h = blockIdx.y;
+    qb = blockIdx.x;
+  }
+  const long long q0 = (long long)qb * (NW * 32) + wave * 32;
 
   v8i qf;
   {
@@ -366,9 +375,10 @@ extern "C" int dove_attention_fwd_mxfp8(const void* Q8, const void* K8, const vo
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd_mxfp8: bad ldo");
   constexpr int LDS = 4 * 8192;
   constexpr int NW = 4;
-  dim3 grid((unsigned)((Npad + NW * 32 - 1) / (NW * 32)), heads);
-  hipLaunchKernelGGL(attn_fwd_mx_kernel<NW>, grid, dim3(NW * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8,
-                     (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo);
+  const int qblocks = (int)((Npad + NW * 32 - 1) / (NW * 32));
+  DOVE_CHECK_ARG((long long)qblocks * heads < (1ll << 31), "attention_fwd_mxfp8: grid too large");
+  hipLaunchKernelGGL(attn_fwd_mx_kernel<NW>, dim3((unsigned)(qblocks * heads)), dim3(NW * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8,
+                     (const unsigned char*)K8, (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo, qblocks);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_mxfp8");
   return DOVE_OK;
 }
@@ -377,10 +387,14 @@ extern "C" int dove_attention_fwd_mxfp8(const void* Q8, const void* K8, const vo
 extern "C" int dove_attention_fwd_mxfp8_nw(const void* Q8, const void* K8, const void* V8t, const void* Vs, void* O, long long N, long long Npad,
                                            int heads, long long ldo, int nw, void* stream) {
   constexpr int LDS = 4 * 8192;
-  dim3 grid((unsigned)((Npad + nw * 32 - 1) / (nw * 32)), heads);
-#define MXL(W) hipLaunchKernelGGL(attn_fwd_mx_kernel<W>, grid, dim3(W * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8, \
-                                  (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo)
-  if (nw == 4) MXL(4); else if (nw == 6) MXL(6); else if (nw == 8) MXL(8); else return -1;
+  const int w = nw == 14 ? 4 : nw;
+  const int qb = (int)((Npad + w * 32 - 1) / (w * 32));
+  dim3 grid((unsigned)qb, heads);
+#define MXL(W, G, QB) hipLaunchKernelGGL(attn_fwd_mx_kernel<W>, G, dim3(W * 64), LDS, (hipStream_t)stream, (const unsigned char*)Q8, (const unsigned char*)K8, \
+                                         (const unsigned char*)V8t, (const unsigned char*)Vs, (bf16_t*)O, N, Npad, ldo, QB)
+  if (nw == 4) MXL(4, grid, 0); else if (nw == 6) MXL(6, grid, 0); else if (nw == 8) MXL(8, grid, 0);
+  else if (nw == 14) MXL(4, dim3((unsigned)(qb * heads)), qb);      // the product mapping: XCD-contiguous 1-D grid
+  else return -1;
   DOVE_CHECK_LAUNCH("dove_attention_fwd_mxfp8_nw");
   return DOVE_OK;
 }

@@ -21,7 +21,7 @@ V = torch.zeros(H, 64, npad, dtype=torch.bfloat16, device="cuda")
 Q[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 0.18 * 1.6).to(torch.bfloat16)
 K[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 1.6).to(torch.bfloat16)
 V[:, :, :N] = torch.randn(H, 64, N, device="cuda", generator=g).to(torch.bfloat16)
-outs = {nw: torch.zeros(N, H * 64, dtype=torch.bfloat16, device="cuda") for nw in (4, 6, 8)}
+outs = {nw: torch.zeros(N, H * 64, dtype=torch.bfloat16, device="cuda") for nw in (4, 14, 8)}     # 14 = 4 waves, XCD-contiguous 1-D grid
 t = {nw: [] for nw in outs}
 for rnd in range(5):
     for nw, o in outs.items():
