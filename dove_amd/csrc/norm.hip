@@ -537,3 +537,85 @@ extern "C" int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, 
   DOVE_CHECK_LAUNCH("dove_vt_quad_swap_bf16");
   return DOVE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Sequence/head-parallel (Ulysses) DiT, receive side of the Q' / K' / V^T all-to-all (dove_amd.dist.dit_forward_ulysses): the three
+// receive buffers hold, per source rank i, that rank's rows of MY heads - [hloc][c_i][64] for Q', K' and [hloc][64][c_i] (natural key
+// order) for V^T - and the attention kernel wants [hloc][Npad][64] / [hloc][64][Npad] with the V^T keys quad-swapped and the pad
+// columns zero.  One launch instead of 3 x world slice copies + a pad clear + an in-place swap per layer.
+// ------------------------------------------------------------------------------------------------------------------
+struct UlyPlaceArgs {
+  const bf16_t *rq, *rk, *rv;
+  bf16_t *Qh, *Kh, *Vt;
+  int world, hloc;
+  long long N, Npad;
+  long long bound[17];        // rows [bound[i], bound[i+1]) come from rank i
+  long long off[17];          // element offset of rank i's block in a receive buffer
+};
+__device__ __forceinline__ int uly_rank(const UlyPlaceArgs& a, long long n) {
+  int i = 0;
+  while (i + 1 < a.world && n >= a.bound[i + 1]) ++i;
+  return i;
+}
+__global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.y < 2) {                                         // Q', K': one 16-byte chunk (8 of the 64 d) of one row
+    const long long total = (long long)a.hloc * a.N * 8;
+    if (t >= total) return;
+    const int c = (int)(t & 7);
+    const long long n = (t >> 3) % a.N;
+    const int h = (int)((t >> 3) / a.N);
+    const int i = uly_rank(a, n);
+    const long long ci = a.bound[i + 1] - a.bound[i];
+    const bf16_t* src = (blockIdx.y == 0 ? a.rq : a.rk) + a.off[i] + ((long long)h * ci + (n - a.bound[i])) * 64 + c * 8;
+    bf16_t* dst = (blockIdx.y == 0 ? a.Qh : a.Kh) + ((long long)h * a.Npad + n) * 64 + c * 8;
+    *(uint4*)dst = *(const uint4*)src;
+  } else {                                                      // V^T: one quad (4 keys) of one (head, d) row, written at its swapped place
+    const long long quads = a.Npad >> 2, total = (long long)a.hloc * 64 * quads;
+    if (t >= total) return;
+    const long long qd = t % quads;
+    const long long row = t / quads;                            // h * 64 + d
+    const int h = (int)(row >> 6), d = (int)(row & 63);
+    bf16_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long n = qd * 4 + e;
+      v[e] = 0;
+      if (n < a.N) {
+        const int i = uly_rank(a, n);
+        const long long ci = a.bound[i + 1] - a.bound[i];
+        v[e] = a.rv[a.off[i] + ((long long)h * 64 + d) * ci + (n - a.bound[i])];
+      }
+    }
+    const int q = (int)(qd & 3);
+    const long long pq = (qd & ~3ll) | (q == 1 ? 2 : (q == 2 ? 1 : q));   // [q0 q1 q2 q3] -> [q0 q2 q1 q3] inside every 16 keys
+    uint2 w;
+    w.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16);
+    w.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    *(uint2*)(a.Vt + row * a.Npad + pq * 4) = w;
+  }
+}
+extern "C" int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, const long long* counts, int world, int hloc, long long N,
+                                       long long Npad, void* Qh, void* Kh, void* Vt, void* stream) {
+  DOVE_CHECK_ARG(rq && rk && rv && counts && Qh && Kh && Vt, "ulysses_place: null pointer");
+  DOVE_CHECK_ARG(world >= 1 && world <= 16 && hloc >= 1 && N > 0 && Npad >= N && Npad % 16 == 0, "ulysses_place: bad shape (world %d, hloc %d)", world, hloc);
+  UlyPlaceArgs a;
+  a.rq = (const bf16_t*)rq; a.rk = (const bf16_t*)rk; a.rv = (const bf16_t*)rv;
+  a.Qh = (bf16_t*)Qh; a.Kh = (bf16_t*)Kh; a.Vt = (bf16_t*)Vt;
+  a.world = world; a.hloc = hloc; a.N = N; a.Npad = Npad;
+  long long b = 0, o = 0;
+  for (int i = 0; i < 17; ++i) { a.bound[i] = N; a.off[i] = 0; }
+  for (int i = 0; i < world; ++i) {
+    DOVE_CHECK_ARG(counts[i] >= 0, "ulysses_place: negative row count");
+    a.bound[i] = b; a.off[i] = o;
+    b += counts[i]; o += counts[i] * hloc * 64;
+  }
+  a.bound[world] = b;
+  DOVE_CHECK_ARG(b == N, "ulysses_place: the ranks' row counts add up to %lld, not N = %lld", b, N);
+  const long long tq = (long long)hloc * N * 8, tv = (long long)hloc * 64 * (Npad >> 2);
+  const long long tmax = tq > tv ? tq : tv;
+  dim3 grid((unsigned)((tmax + 255) / 256), 3);
+  hipLaunchKernelGGL(ulysses_place_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  DOVE_CHECK_LAUNCH("dove_ulysses_place_bf16");
+  return DOVE_OK;
+}

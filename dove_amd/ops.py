@@ -293,6 +293,15 @@ def vt_quad_swap(Vt):
     return Vt
 
 
+def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
+    """Receive side of the Ulysses all-to-all (include/dove_hip.h dove_ulysses_place_bf16): per-source-rank blocks of my heads ->
+    the attention kernel's head-major operands (V^T quad-swapped, pad columns zero) in one launch."""
+    L.require_cuda(rq, rk, rv, Qh, Kh, Vt)
+    cnt = (C.c_longlong * len(counts))(*[int(c) for c in counts])
+    L.check(L.load().dove_ulysses_place_bf16(L.ptr(rq), L.ptr(rk), L.ptr(rv), cnt, len(counts), hloc, N, Npad, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt),
+                                             L.stream_ptr()), "dove_ulysses_place_bf16")
+
+
 def attention(Qh, Kh, Vt, N, Npad, heads, out):
     L.require_cuda(Qh, Kh, Vt, out)
     L.check(L.load().dove_attention_fwd_bf16(L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), L.ptr(out), N, Npad, heads, 64, out.shape[1],

@@ -123,6 +123,12 @@ int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, 
                        const float* gq, const float* bq, const float* gk, const float* bk, const float* cosT,
                        const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, int v_order, void* stream);
 int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, void* stream);
+/* Receive side of the Q' / K' / V^T all-to-all of the sequence/head-parallel DiT (dove_amd.dist; not in the reference: one clip over
+ * several GPUs): rq, rk = per source rank i the block [hloc][counts[i]][64], rv = [hloc][64][counts[i]] (natural key order), blocks in
+ * rank order -> Qh, Kh [hloc][Npad][64] and Vt [hloc][64][Npad] quad-swapped with zero pad columns: the operands of
+ * dove_attention_fwd_bf16 for this rank's hloc heads over all N = sum(counts) rows.  counts is a HOST array of `world` entries. */
+int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, const long long* counts, int world, int hloc, long long N,
+                            long long Npad, void* Qh, void* Kh, void* Vt, void* stream);
 
 /* F.scaled_dot_product_attention (no mask, non-causal) on the operands above, Vt in QUAD-SWAPPED key order; Qh carries
  * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64). */

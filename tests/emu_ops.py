@@ -214,6 +214,20 @@ def vt_quad_swap(Vt):
     return Vt
 
 
+def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
+    """dove_ulysses_place_bf16: blocks [rank i][hloc][c_i][64] / [hloc][64][c_i] -> [hloc][Npad][64] / [hloc][64][Npad] (quad-swapped, zero pad)."""
+    off = b = 0
+    Vt.zero_()
+    for c in counts:
+        n = c * hloc * 64
+        Qh[:, b:b + c] = rq[off:off + n].view(hloc, c, 64)
+        Kh[:, b:b + c] = rk[off:off + n].view(hloc, c, 64)
+        Vt[:, :, b:b + c] = rv[off:off + n].view(hloc, 64, c)
+        off += n
+        b += c
+    vt_quad_swap(Vt)
+
+
 def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1):
     D = heads * 64
     q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64) for i in range(3))
@@ -472,7 +486,7 @@ def attention_bias(qkv, bias, heads):
     return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
 
 
-ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "qkv_post_mx", "attention_mx",
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "ulysses_place", "qkv_post_mx", "attention_mx",
        "cl_from_ncthw", "cl_im2col3x3_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

@@ -300,6 +300,24 @@ def test_qkv_post_and_attention(N, heads, text_len):
     close(f"attention_{N}_{heads}", got, ref, rtol=3e-2, afrac=8e-3)
 
 
+@pytest.mark.parametrize("counts,hloc", [([37, 36, 40], 2), ([300], 3), ([1, 0, 130, 61], 1), ([2279, 2278, 2278, 2278, 2278, 2278, 2279, 2278], 6)])
+def test_ulysses_place(counts, hloc):
+    """dove_ulysses_place_bf16 (receive side of the sequence/head-parallel DiT's all-to-all): per-source-rank blocks -> the attention
+    kernel's operands in one launch; bit-exact (a copy), V^T quad-swapped, pad columns zero whatever the buffers held before."""
+    N = sum(counts)
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator().manual_seed(31)
+    rq, rk, rv = (torch.randn(N * hloc * 64, generator=g).to(BF) for _ in range(3))
+    ref = [torch.zeros(hloc, npad, 64, dtype=BF), torch.zeros(hloc, npad, 64, dtype=BF), torch.zeros(hloc, 64, npad, dtype=BF)]
+    E.ulysses_place(rq, rk, rv, counts, hloc, N, npad, *ref)
+    got = [torch.zeros(hloc, npad, 64, dtype=BF, device="cuda"), torch.zeros(hloc, npad, 64, dtype=BF, device="cuda"),
+           torch.full((hloc, 64, npad), 7.0, dtype=BF, device="cuda")]               # stale V^T contents must not survive in the pad
+    ops.ulysses_place(rq.cuda(), rk.cuda(), rv.cuda(), counts, hloc, N, npad, *got)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("Qh", "Kh", "Vt"), got, ref):
+        assert torch.equal(a.cpu(), b), f"{name} differs"
+
+
 def _mx_operands(N, heads, text_len, seed=15, spread=1.0):
     D = heads * 64
     npad = (N + 127) // 128 * 128
