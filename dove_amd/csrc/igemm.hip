@@ -655,7 +655,10 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
   h4_set_nxt(s, a, k);
 }
 
-template <bool kUp, bool kTiming>
+// kDma: where a step's 2-4 LDS-DMA instructions sit among its 32 MFMAs.  0: gaps 0..3 (one per MFMA right behind the barrier);
+// 1: gaps 0, 8, 16, 24 - the four waves of the workgroup run a step in lockstep, so a burst of 4 per wave is 16 KB through the CU's one
+// address path inside ~128 clocks (see gemm4x kSched).
+template <bool kUp, bool kTiming, int kDma = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = Halo4xCfg;
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-      if (i < 2 + NH) {
+      if (kDma == 0 ? i < 2 + NH : (i == 0 || i == 8)) {
         __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);              // <= 4 SALU (descriptor, m0)
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
       }
@@ -835,6 +838,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (kDma == 1 && ((i == 0 && NH >= 1) || (i == 8 && NH >= 2))) {
+        __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
       if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1092,7 +1099,16 @@ __device__ __forceinline__ void g4_advance(G4State& s, const IgemmArgs& a, const
   s.soff = s.n_k4 * (4 * gemm4x::ROWB);
 }
 
-template <bool kAct, bool kGate, bool kTiming = false>
+// kSched: where a K step's 8 LDS-DMA instructions sit among its 32 MFMAs.
+//   1 (product): eight FENCED groups of { 1 LDS-DMA, 2 fragment reads, 4 MFMAs } with a sched_barrier between groups.  The four waves of
+//      a workgroup run a step in lockstep, so a burst of 8 DMAs per wave is 32 KB through the CU's one address path (~16 clocks per
+//      1 KB instruction) inside ~256 clocks; one per 128 clocks and wave keeps that path at half load.  Fragment reads are ordered so
+//      that no MFMA waits for a read issued in the group right before it (all four x fragments first, then the w fragments in the
+//      order the MFMA rows use them).  +4.5-7 % on the DiT linears within a run (profiles/r03_gemm4x_sched.log).
+//   0 (round-2 order, kept for the A/B in the timing library): the DMAs asked for in gaps 8-15 by sched_group_barrier - which hipcc
+//      turns into a burst right behind the step barrier whatever pattern is requested (three patterns tried): only a sched_barrier
+//      fence keeps an LDS-DMA where the source puts it.
+template <bool kAct, bool kGate, bool kTiming = false, int kSched = 1>
 __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long long M) {
   using namespace gemm4x;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1209,6 +1225,43 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
     if (kTiming) { const unsigned long long tq2 = __builtin_amdgcn_s_memtime(); tm_wait += tq1 - tq0; tm_bar += tq2 - tq1; }
     __builtin_amdgcn_sched_barrier(0);
     // ---- from here to the end of the step: ONE basic block ----
+    if (kSched == 1) {
+      const bf16_t* sab = u == 0 ? ca_base : na_base;            // step 3 of this chunk / steps 0..2 of the next one
+      const bf16_t* swb = u == 0 ? cw_base : nw_base;
+      const int sanr = u == 0 ? ca_nrec : na_nrec, swnr = u == 0 ? cw_nrec : nw_nrec;
+      const int ssoff = u == 0 ? c_soff + 3 * ROWB : n_soff + (u - 1) * ROWB;
+      const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)sab, (short)0, sanr, 0x00020000);
+      const auto srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)swb, (short)0, swnr, 0x00020000);
+      constexpr int sslot = (u + 3) & 3, slot = u, nslot = (u + 1) & 3;
+#pragma unroll
+      for (int gq = 0; gq < 8; ++gq) {
+        const int i = gq & 3;
+        // this group's two fragment reads: groups 0, 1 (4, 5) all four x fragments of k-half 1 (of the next step's k-half 0), groups
+        // 2, 3 (6, 7) the w fragments; x / w of k-half 0 are dead after group 3
+        auto rd = [&](bf16x8 (&xf)[4], bf16x8 (&wf)[4], int kk, int sl) {
+          if (i < 2) {
+            xf[2 * i] = *(const bf16x8*)(smem + aoff[sl >> 1][2 * i][kk] + (sl & 1) * ST);
+            xf[2 * i + 1] = *(const bf16x8*)(smem + aoff[sl >> 1][2 * i + 1][kk] + (sl & 1) * ST);
+          } else {
+            wf[2 * i - 4] = *(const bf16x8*)(smem + boff[sl >> 1][2 * i - 4][kk] + (sl & 1) * ST);
+            wf[2 * i - 3] = *(const bf16x8*)(smem + boff[sl >> 1][2 * i - 3][kk] + (sl & 1) * ST);
+          }
+        };
+        if (gq < 4) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + sslot * ST + wave * 4096 + i * 1024), 16, voff[i], ssoff, 0, 0);
+          rd(xb, wb, 1, slot);
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) acc[i][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xa[pp], acc[i][pp], 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + sslot * ST + A_ST + wave * 4096 + i * 1024), 16, voff[i], ssoff, 0, 0);
+#pragma unroll
+          for (int pp = 0; pp < 4; ++pp) acc[i][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i], xb[pp], acc[i][pp], 0, 0, 0);
+          rd(xa, wa, 0, nslot);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     if (u == 0) stage(SSlot{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + 3 * ROWB);   // step 3 of this chunk
     else stage(SSlot{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + (u - 1) * ROWB);    // steps 0..2 of the next one
     load_a(I1{}, Slot{}, xb);
@@ -1217,20 +1270,22 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
     load_a(I0{}, NSlot{}, xa);
     load_b(I0{}, NSlot{}, wa);
     mma(wb, xb);
+    {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 ds_read (k-half 1 fragments)
-      else {
-        if (i == 8) __builtin_amdgcn_sched_group_barrier(0x004, 8, 0);  // SALU: descriptors before the first load,
-        else __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);         //       then only m0
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
+        if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 ds_read (k-half 1 fragments)
+        else {
+          if (i == 8) __builtin_amdgcn_sched_group_barrier(0x004, 8, 0);  // SALU: descriptors before the first load,
+          else __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);         //       then only m0
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
+        }
       }
-    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -1647,6 +1702,19 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
         hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
       } else
 #endif
+#ifdef DOVE_TIMING_BUILD
+      {
+        static int sched = -1;                                   // DOVE_GEMM4X_SCHED=0: the round-2 DMA order (tools/gemm4x_sched.py A/B)
+        if (sched < 0) { const char* e = getenv("DOVE_GEMM4X_SCHED"); sched = e ? atoi(e) : 1; }
+        if (sched == 0 && !d->gate && d->act == 0) {
+          static PerDeviceOnce attrs;
+          if (attrs.first()) (void)hipFuncSetAttribute((const void*)(gemm4x_kernel<false, false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+          hipLaunchKernelGGL((gemm4x_kernel<false, false, false, 0>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x sched 0)");
+          return DOVE_OK;
+        }
+      }
+#endif
       if (d->gate) {
         DOVE_CHECK_ARG(d->act == 0, "conv_igemm: gate with activation is not a path of the reference");
         hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
@@ -1688,6 +1756,19 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
         a.gate = (const float*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
+#endif
+#ifdef DOVE_TIMING_BUILD
+      {
+        static int hd = -1;                                      // A/B of the DMA placement (tools/halo4x_dma.py)
+        if (hd < 0) { const char* e = getenv("DOVE_HALO4X_DMA"); hd = e ? atoi(e) : 0; }
+        if (hd == 1 && kern == K_HALO4X) {
+          static PerDeviceOnce attrd;
+          if (attrd.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+          hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, 1>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x dma)");
+          return DOVE_OK;
+        }
+      }
 #endif
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
