@@ -655,10 +655,10 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
   h4_set_nxt(s, a, k);
 }
 
-// kDma: where a step's 2-4 LDS-DMA instructions sit among its 32 MFMAs.  0: gaps 0..3 (one per MFMA right behind the barrier);
-// 1: gaps 0, 8, 16, 24 - the four waves of the workgroup run a step in lockstep, so a burst of 4 per wave is 16 KB through the CU's one
-// address path inside ~128 clocks (see gemm4x kSched).
-template <bool kUp, bool kTiming, int kDma = 0>
+// (Round 3 tried two other placements of a step's 2-4 LDS-DMA instructions - spread by sched_group_barrier: -4 %, the compiler also
+// re-clusters the fragment reads; four sched_barrier-fenced quarters of {<= 1 DMA, 4 reads, 8 MFMAs}: +-0.3 % - profiles/r03_halo4x_dma.log.
+// Unlike gemm4x's eight DMAs per step, two to four do not back up the CU's address path; the pinned order below stays.)
+template <bool kUp, bool kTiming>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = Halo4xCfg;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-      if (kDma == 0 ? i < 2 + NH : (i == 0 || i == 8)) {
+      if (i < 2 + NH) {
         __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);              // <= 4 SALU (descriptor, m0)
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
       }
@@ -838,10 +838,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (kDma == 1 && ((i == 0 && NH >= 1) || (i == 8 && NH >= 2))) {
-        __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
       if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1756,19 +1752,6 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
         a.gate = (const float*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
-#endif
-#ifdef DOVE_TIMING_BUILD
-      {
-        static int hd = -1;                                      // A/B of the DMA placement (tools/halo4x_dma.py)
-        if (hd < 0) { const char* e = getenv("DOVE_HALO4X_DMA"); hd = e ? atoi(e) : 0; }
-        if (hd == 1 && kern == K_HALO4X) {
-          static PerDeviceOnce attrd;
-          if (attrd.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-          hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, 1>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x dma)");
-          return DOVE_OK;
-        }
-      }
 #endif
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
