@@ -55,6 +55,9 @@ __device__ __forceinline__ f32x16 mfma_c_in(bf16x8 a, bf16x8 b, const f32x16& c)
 // XCD: 1-D grid of heads x query-blocks, remapped so that each XCD (= blockIdx % 8, its own L2) walks a CONTIGUOUS range of the
 // head-major tile list: the ~64 workgroups an XCD runs at a time then belong to one or two heads and stream the same K / V^T tiles
 // through one L2, instead of every XCD streaming every head (the 2-D grid puts consecutive query blocks of a head on 8 XCDs).
+// The eight K / V^T LDS-DMA loads of a tile pair are issued as one burst behind the barrier.  Spreading them two at a time between the four
+// MFMA groups of the pair's first tile (fenced like gemm4x's groups, where that is worth +5-8 %) changes nothing here: 4.263 / 4.267 / 4.260 ms
+// (profiles/r03_attn_dma.log) - the second workgroup of the CU computes through the first one's burst.
 template <int NW, bool XCD = true>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,

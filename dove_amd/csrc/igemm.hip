@@ -1421,6 +1421,276 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm8p: gemm4x's GEMM (same 256 x 256 tile, same 4-stage K-32 operand ring and XOR-swizzled 64-B rows, same persistent tile walk and
+// supertile order, same arithmetic: results are bit-identical) run by EIGHT waves = two per SIMD in PING-PONG.  gemm4x's lone wave per
+// SIMD issues its 8 LDS-DMA instructions and 16 fragment reads inside its own MFMA stream; every DMA holds the wave's issue for longer
+// than one MFMA takes, so the matrix pipe drains 8 times per step.  Here a wave owns 128 tokens x 64 channels (128 accumulator registers
+// of its 256) and alternates two segments separated by workgroup barriers:
+//     LOAD(g):  12 fragment reads of step g (whole 128 x 64 x 32 operand set: 48 registers) + its 4 LDS-DMAs for step g + 3
+//     MFMA(g):  16 MFMAs, nothing else in the stream
+// and the waves 4-7 (token rows 128-255) run ONE barrier behind the waves 0-3, so on every SIMD one wave computes while its partner
+// loads; the pipe is handed over at each barrier with the last MFMA of one wave still executing.
+//   slot 2g:   waves 0-3 LOAD(g)      waves 4-7 MFMA(g-1)
+//   slot 2g+1: waves 0-3 MFMA(g)      waves 4-7 LOAD(g)
+// Ring safety (stage = step mod 4): step g + 3 overwrites step g - 1, last read in slot 2g - 1 (waves 4-7, who pass its closing barrier
+// after lgkmcnt(0)); it is read from slot 2g + 6 on, and every wave counts its own DMAs of that step down (vmcnt(8): two younger steps
+// may stay in flight) before the barrier that closes the ODD slot 2g + 5 - for the waves 0-3 that is the end of an MFMA segment, for the
+// waves 4-7 the end of a LOAD segment.
+namespace gemm8p {
+constexpr int EPI = gemm4x::NST * gemm4x::ST;                // epilogue staging: 8 waves x 32 rows x 128 B (XOR-swizzled)
+constexpr int LDS_BYTES = EPI + 8 * 4096;                    // 163840
+}  // namespace gemm8p
+template <bool kAct, bool kGate>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long long M) {
+  using namespace gemm4x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < 8);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int grp = wave >> 2, wc = wave & 3;                   // token half = phase group, 64-channel slab
+
+  G4Const kc;
+  kc.K = a.Cin;
+  kc.M = M;
+  kc.tiles_n = a.tiles_n;
+  kc.ntiles = (int)((M + BM - 1) / BM) * a.tiles_n;
+  kc.G = (int)gridDim.x;
+  kc.nk4 = a.Cin / (4 * BK);
+  const int ntiles = kc.ntiles, G = kc.G, nk4 = kc.nk4;
+
+  // staging: wave w moves rows 32w .. 32w+31 of either operand tile, 16 rows x 4 chunks per instruction (source chunk XOR-swizzled)
+  unsigned voff[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int row = (wave * 2 + jj) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    voff[jj] = (unsigned)((row * a.Cin + c * 8) * 2);
+  }
+  G4State st;
+  const bf16_t *ca_base = a.x, *cw_base = a.w, *na_base = a.x, *nw_base = a.w;
+  int ca_nrec = 0, cw_nrec = 0, c_soff = 0, na_nrec = 0, nw_nrec = 0, n_soff = 0;
+  auto publish = [&](const G4State& q) {                      // cur <- nxt, nxt <- q
+    ca_base = na_base; cw_base = nw_base; ca_nrec = na_nrec; cw_nrec = nw_nrec; c_soff = n_soff;
+    na_base = q.a_base; nw_base = q.w_base; na_nrec = q.a_nrec; nw_nrec = q.w_nrec; n_soff = q.soff;
+  };
+  auto stage = [&](auto slotc, const bf16_t* ab, int anrec, const bf16_t* wb, int wnrec, int soff) {
+    constexpr int slot = decltype(slotc)::value;
+    const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, anrec, 0x00020000);
+    const auto srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, wnrec, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + slot * ST + wave * 2048 + jj * 1024), 16, voff[jj], soff, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + slot * ST + A_ST + wave * 2048 + jj * 1024), 16, voff[jj], soff,
+                                               0, 0);
+  };
+
+  int aoff[2][4][2], boff[2][2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int ra = grp * 128 + p * 32 + l31;
+      aoff[0][p][kk] = ra * ROWB + (((kk * 2 + hi) ^ ((ra >> 2) & 3)) << 4);
+      aoff[1][p][kk] = aoff[0][p][kk] + 2 * ST;
+      asm volatile("" : "+v"(aoff[0][p][kk]), "+v"(aoff[1][p][kk]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = wc * 64 + i * 32 + l31;
+      boff[0][i][kk] = A_ST + rb * ROWB + (((kk * 2 + hi) ^ ((rb >> 2) & 3)) << 4);
+      boff[1][i][kk] = boff[0][i][kk] + 2 * ST;
+      asm volatile("" : "+v"(boff[0][i][kk]), "+v"(boff[1][i][kk]));
+    }
+  }
+  f32x16 acc[2][4];
+  bf16x8 xf[4][2], wf[2][2];
+
+  // ---- prologue (once per workgroup): K-steps 0, 1, 2 of the first tile ----
+  g4_open_tile(st, a, kc, (int)blockIdx.x);
+  publish(st);
+  stage(std::integral_constant<int, 0>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff);
+  stage(std::integral_constant<int, 1>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + ROWB);
+  stage(std::integral_constant<int, 2>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + 2 * ROWB);
+  g4_advance(st, a, kc);
+  publish(st);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp) {                                                  // the second group starts one slot later
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  auto step = [&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    using SSlot = std::integral_constant<int, (u + 3) & 3>;
+    // ---- LOAD ----
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) xf[p][kk] = *(const bf16x8*)(smem + aoff[u >> 1][p][kk] + (u & 1) * ST);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[i][kk] = *(const bf16x8*)(smem + boff[u >> 1][i][kk] + (u & 1) * ST);
+    }
+    if (u == 0) stage(SSlot{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + 3 * ROWB);   // step 3 of this chunk
+    else stage(SSlot{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + (u - 1) * ROWB);    // steps 0..2 of the next one
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- MFMA ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], xf[p][kk], acc[i][p], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!grp) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // epilogue-side lane role: 4 lanes x 8 columns cover the 32 columns (64 B) one accumulator block holds of an output row
+  const int e_px = lane >> 2, e_ch = lane & 3;
+  for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
+    const G4Tile c = g4_decode(kc, tile);
+    const int col0 = c.n0 + wc * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+
+    for (int kq = 0; kq < nk4; ++kq) {
+      step(std::integral_constant<int, 0>{});
+      step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{});
+      step(std::integral_constant<int, 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      g4_advance(st, a, kc);
+      publish(st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // bias / gate rows of the lane's 16 channels: loaded HERE, not before the K walk - 48 registers the walk does not have (2 waves per SIMD);
+    // they land under the first accumulator block's trip through LDS
+    asm volatile("" ::: "memory");
+    f32x4 bias_r[2][2], gate_r[2][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cb = col0 + h * 32 + e_ch * 8;
+      bias_r[h][0] = bias_r[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) { bias_r[h][0] = *(const f32x4*)(a.bias + cb); bias_r[h][1] = *(const f32x4*)(a.bias + cb + 4); }
+      if (kGate) {
+#pragma unroll
+        for (int cls = 0; cls < 2; ++cls) {
+          gate_r[cls][h][0] = *(const f32x4*)(a.gate + (long long)cls * a.Cout_pad + cb);
+          gate_r[cls][h][1] = *(const f32x4*)(a.gate + (long long)cls * a.Cout_pad + cb + 4);
+        }
+      }
+    }
+    // ---- epilogue: the wave's 128 x 64 result, one 32-row x 32-column accumulator block at a time through its own 4 KB LDS slice
+    // (fp32, XOR-swizzled 128-B rows), then 16-B stores with 4 lanes covering 64 contiguous bytes of a row ----
+    {
+      char* const eslice = smem + gemm8p::EPI + wave * 4096;
+      unsigned o_off[2], r_off[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int px = it * 16 + e_px;
+        o_off[it] = (unsigned)((px * (int)a.ldo + e_ch * 8) * 2);
+        r_off[it] = (unsigned)((px * (int)a.ldr + e_ch * 8) * 2);
+      }
+      auto emit = [&](auto has_resid) {
+        constexpr bool kRes = decltype(has_resid)::value;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const long long row0 = (long long)c.m0 + grp * 128 + p * 32;
+          const long long vl = M - row0;
+          const int rows = vl >= 32 ? 32 : (vl > 0 ? (int)vl : 0);     // rows past M: offset >= num_records -> dropped
+          const auto srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + row0 * a.ldo + col0), (short)0,
+                                                               rows * (int)a.ldo * 2, 0x00020000);
+          const auto srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.resid + row0 * a.ldr + col0 : a.out), (short)0,
+                                                               kRes ? rows * (int)a.ldr * 2 : 0, 0x00020000);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            u32x4 rr[2];
+            if (kRes) {
+#pragma unroll
+              for (int it = 0; it < 2; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 64, 0);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[h][p][gq * 4 + e];
+              const int ch = 2 * gq + hi;                            // 16-B chunk of the 128-B row
+              *(f32x4*)(eslice + l31 * 128 + ((ch ^ (l31 & 7)) << 4)) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private slice: no barrier needed
+            f32x4 lo[2], hi4[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              const int px = it * 16 + e_px;
+              lo[it] = *(const f32x4*)(eslice + px * 128 + (((2 * e_ch) ^ (px & 7)) << 4));
+              hi4[it] = *(const f32x4*)(eslice + px * 128 + (((2 * e_ch + 1) ^ (px & 7)) << 4));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
+              if (kAct) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x0[e] = gelu_tanh_f(x0[e]); x1[e] = gelu_tanh_f(x1[e]); }
+              }
+              if (kRes) {
+                const u32x4 r = rr[it];
+                const f32x4 r0 = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                                  __uint_as_float(r[1] & 0xffff0000u)};
+                const f32x4 r1 = {__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16),
+                                  __uint_as_float(r[3] & 0xffff0000u)};
+                if (kGate) {
+                  const bool vid = row0 + it * 16 + e_px >= a.gate_split;   // row class: text rows first
+                  const f32x4 g0 = vid ? gate_r[1][h][0] : gate_r[0][h][0];
+                  const f32x4 g1 = vid ? gate_r[1][h][1] : gate_r[0][h][1];
+                  x0 = r0 + g0 * x0;
+                  x1 = r1 + g1 * x1;
+                } else {
+                  x0 += r0;
+                  x1 += r1;
+                }
+              }
+              const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
+              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 64, 0);
+              __builtin_amdgcn_sched_barrier(0);                       // store-data hazard: see gemm4x
+              asm volatile("s_nop 3" ::: "memory");
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+      };
+      if (a.resid) emit(std::true_type{});
+      else emit(std::false_type{});
+    }
+    // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as a builtin: the compiler's own wait tracking sees the queue empty
+    asm volatile("" ::: "memory");
+  }
+  if (!grp) {                                                 // balance the second group's extra first barrier
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------
 static bf16_t* g_zero_page[16] = {nullptr};
 
@@ -1707,6 +1977,24 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
           if (attrs.first()) (void)hipFuncSetAttribute((const void*)(gemm4x_kernel<false, false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
           hipLaunchKernelGGL((gemm4x_kernel<false, false, false, 0>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
           DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x sched 0)");
+          return DOVE_OK;
+        }
+      }
+#endif
+#ifdef DOVE_TIMING_BUILD
+      {
+        const char* e8 = getenv("DOVE_GEMM8P");                  // tools/gemm8p_ab.py toggles it between calls
+        if (e8 && atoi(e8)) {
+          static PerDeviceOnce attr8;
+          if (attr8.first()) {
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+          }
+          if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          else hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p)");
           return DOVE_OK;
         }
       }
