@@ -1037,13 +1037,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm4x: plain GEMM  out[M][N] = x[M][K] * w[N][K]^T  (DiT linears, 1x1x1 convs over a contiguous channels-last tensor)
-// with the conv3x3_halo4x recipe: ONE wave per SIMD (512-register budget), 4 waves = 2 x 2 wave tiles of 128 x 128 ->
-// 256 x 256 workgroup tile (32 KB of operands per 32-deep K step: 131 FLOP per byte moved into LDS, 25 % less L2->LDS
-// traffic than gemm8's 512 x 128), 4-stage operand ring staged 3 steps ahead by LDS-DMA with counted vmcnt, fragments
-// register-pipelined across the single per-step barrier, pinned MFMA / VMEM / DS interleave, PERSISTENT workgroups whose
-// staging stream runs on into the next tile, and the LDS-transposed epilogue with buffer-addressed full-line stores
-// (bias, GELU(tanh), residual and AdaLN gate applied in fp32 on the read side).
+// Plain GEMM  out[M][N] = x[M][K] * w[N][K]^T  (DiT linears, 1x1x1 convs over a contiguous channels-last tensor): 256 x 256 workgroup
+// tiles walked by PERSISTENT workgroups in an XCD-aware supertile order (g4_* below), operands staged by LDS-DMA, the LDS-transposed epilogue
+// with buffer-addressed stores (bias, GELU(tanh), residual and AdaLN gate applied in fp32 on the read side).
+//   gemm8p_kernel (the product): eight waves in ping-pong over two K-64 buffers of full 128-B rows - see its header.
+//   gemm4x_kernel (round 2's kernel, TIMING build only, for the within-run A/B of tools/gemm8p_ab.py): ONE wave per SIMD (512-register
+//     budget), 4 waves = 2 x 2 wave tiles of 128 x 128, 4-stage K-32 ring staged 3 steps ahead with counted vmcnt, fragments
+//     register-pipelined across the single per-step barrier, pinned MFMA / VMEM / DS interleave.
 namespace gemm4x {
 constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64;
 constexpr int A_ST = BM * ROWB, ST = A_ST + BN * ROWB;      // 16384 + 16384 per stage
@@ -1095,6 +1095,7 @@ __device__ __forceinline__ void g4_advance(G4State& s, const IgemmArgs& a, const
   s.soff = s.n_k4 * (4 * gemm4x::ROWB);
 }
 
+#ifdef DOVE_TIMING_BUILD
 // kSched: where a K step's 8 LDS-DMA instructions sit among its 32 MFMAs.
 //   1 (product): eight FENCED groups of { 1 LDS-DMA, 2 fragment reads, 4 MFMAs } with a sched_barrier between groups.  The four waves of
 //      a workgroup run a step in lockstep, so a burst of 8 DMAs per wave is 32 KB through the CU's one address path (~16 clocks per
@@ -1421,29 +1422,38 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
   }
 }
 
+#endif  // DOVE_TIMING_BUILD (gemm4x_kernel)
+
 // ------------------------------------------------------------------------------------------------
-// gemm8p: gemm4x's GEMM (same 256 x 256 tile, same 4-stage K-32 operand ring and XOR-swizzled 64-B rows, same persistent tile walk and
-// supertile order, same arithmetic: results are bit-identical) run by EIGHT waves = two per SIMD in PING-PONG.  gemm4x's lone wave per
-// SIMD issues its 8 LDS-DMA instructions and 16 fragment reads inside its own MFMA stream; every DMA holds the wave's issue for longer
-// than one MFMA takes, so the matrix pipe drains 8 times per step.  Here a wave owns 128 tokens x 64 channels (128 accumulator registers
-// of its 256) and alternates two segments separated by workgroup barriers:
-//     LOAD(g):  12 fragment reads of step g (whole 128 x 64 x 32 operand set: 48 registers) + its 4 LDS-DMAs for step g + 3
-//     MFMA(g):  16 MFMAs, nothing else in the stream
-// and the waves 4-7 (token rows 128-255) run ONE barrier behind the waves 0-3, so on every SIMD one wave computes while its partner
-// loads; the pipe is handed over at each barrier with the last MFMA of one wave still executing.
-//   slot 2g:   waves 0-3 LOAD(g)      waves 4-7 MFMA(g-1)
-//   slot 2g+1: waves 0-3 MFMA(g)      waves 4-7 LOAD(g)
-// Ring safety (stage = step mod 4): step g + 3 overwrites step g - 1, last read in slot 2g - 1 (waves 4-7, who pass its closing barrier
-// after lgkmcnt(0)); it is read from slot 2g + 6 on, and every wave counts its own DMAs of that step down (vmcnt(8): two younger steps
-// may stay in flight) before the barrier that closes the ODD slot 2g + 5 - for the waves 0-3 that is the end of an MFMA segment, for the
-// waves 4-7 the end of a LOAD segment.
+// gemm8p: gemm4x's GEMM (same 256 x 256 tile, same persistent tile walk and supertile order, same arithmetic: results are bit-identical)
+// with the two changes the measurements of round 3 asked for.
+//  * FULL-LINE STAGING.  gemm4x's K-32 ring is filled by LDS-DMA instructions that fetch 16 rows x 64 B; a DMA-only kernel walking the same
+//    tiles (tools/stage_ab.py) stages at 11-14.5 TB/s that way - as long as the MFMA work itself takes - and 1.5-1.65x faster with 8 rows
+//    x 128 B per instruction (64-B requests run into the L2 request rate: 11 requests per clock and XCD of 16; TA busy 78 %), while the
+//    queue depth hardly matters (nothing in flight behind a 64 KB step: -9 %).  So the ring here is TWO K-64 buffers of 128-B rows
+//    (XOR-swizzled like attention's K tile), each refilled in one go as soon as its last reader is through.
+//  * PING-PONG.  Eight waves = two per SIMD; a wave owns 128 tokens x 64 channels (128 accumulator registers of its 256) and alternates
+//        LOAD(q):  12 fragment reads of K-32 phase q (48 registers) [+ on even q its 8 LDS-DMAs: the K-64 step after this one]
+//        MFMA(q):  16 MFMAs, nothing else in the stream
+//    between workgroup barriers, the waves 4-7 (token rows 128-255) ONE barrier behind the waves 0-3: on every SIMD one wave computes
+//    while its partner loads, and the pipe is handed over at each barrier with the last MFMA of one wave still executing.
+//        slot 2q:   waves 0-3 LOAD(q)      waves 4-7 MFMA(q-1)
+//        slot 2q+1: waves 0-3 MFMA(q)      waves 4-7 LOAD(q)
+//    Buffer safety: K-64 step t = phases 2t, 2t+1 lives in buffer t & 1.  Its last reads are LOAD(2t+1): slots 4t+2 / 4t+3, closed by
+//    barriers the readers pass after lgkmcnt(0).  Step t+2 is staged into it from LOAD(2t+2) = slots 4t+4 / 4t+5 on and first read in
+//    slot 4t+8; every wave waits for its own DMAs (vmcnt(0): nothing younger is in flight) before the barrier that closes slot 4t+7 - the
+//    end of MFMA(2t+3) for the waves 0-3, the end of LOAD(2t+3) for the waves 4-7.
 namespace gemm8p {
-constexpr int EPI = gemm4x::NST * gemm4x::ST;                // epilogue staging: 8 waves x 32 rows x 128 B (XOR-swizzled)
+constexpr int ROWB = 128;                                    // bytes of K per row and K-64 step
+constexpr int OPB = 256 * ROWB;                              // one operand of one step: 32 KB
+constexpr int XB = 0, WB = 2 * OPB;                          // x buffers at 0 / 32 KB (one address register + immediate reaches both), w at 64 / 96 KB
+constexpr int EPI = 4 * OPB;                                 // epilogue staging: 8 waves x 32 rows x 128 B (XOR-swizzled)
 constexpr int LDS_BYTES = EPI + 8 * 4096;                    // 163840
 }  // namespace gemm8p
-template <bool kAct, bool kGate>
+template <bool kAct, bool kGate, bool kTiming = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long long M) {
-  using namespace gemm4x;
+  using gemm4x::BM;
+  using namespace gemm8p;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1457,15 +1467,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
   kc.tiles_n = a.tiles_n;
   kc.ntiles = (int)((M + BM - 1) / BM) * a.tiles_n;
   kc.G = (int)gridDim.x;
-  kc.nk4 = a.Cin / (4 * BK);
+  kc.nk4 = a.Cin / 128;                                       // "chunk" of the g4_* walk = 128 of K = two K-64 steps
   const int ntiles = kc.ntiles, G = kc.G, nk4 = kc.nk4;
 
-  // staging: wave w moves rows 32w .. 32w+31 of either operand tile, 16 rows x 4 chunks per instruction (source chunk XOR-swizzled)
-  unsigned voff[2];
+  // staging: wave w moves rows 32w .. 32w+31 of either operand, 8 rows x 8 chunks (one full 128-B line per row) per instruction; the source
+  // chunk is XOR-swizzled with bits 1-3 of the row so that the fragment reads (32 rows, one chunk column) are bank-conflict free
+  unsigned voff[4];
 #pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int row = (wave * 2 + jj) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
+  for (int jj = 0; jj < 4; ++jj) {
+    const int row = (wave * 4 + jj) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     voff[jj] = (unsigned)((row * a.Cin + c * 8) * 2);
   }
   G4State st;
@@ -1475,48 +1486,41 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     ca_base = na_base; cw_base = nw_base; ca_nrec = na_nrec; cw_nrec = nw_nrec; c_soff = n_soff;
     na_base = q.a_base; nw_base = q.w_base; na_nrec = q.a_nrec; nw_nrec = q.w_nrec; n_soff = q.soff;
   };
-  auto stage = [&](auto slotc, const bf16_t* ab, int anrec, const bf16_t* wb, int wnrec, int soff) {
-    constexpr int slot = decltype(slotc)::value;
+  auto stage = [&](auto bufc, const bf16_t* ab, int anrec, const bf16_t* wb, int wnrec, int soff) {
+    constexpr int buf = decltype(bufc)::value;
     const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, anrec, 0x00020000);
     const auto srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, wnrec, 0x00020000);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + slot * ST + wave * 2048 + jj * 1024), 16, voff[jj], soff, 0, 0);
+    for (int jj = 0; jj < 4; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + XB + buf * OPB + wave * 4096 + jj * 1024), 16, voff[jj], soff, 0, 0);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + slot * ST + A_ST + wave * 2048 + jj * 1024), 16, voff[jj], soff,
-                                               0, 0);
+    for (int jj = 0; jj < 4; ++jj)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + WB + buf * OPB + wave * 4096 + jj * 1024), 16, voff[jj], soff, 0, 0);
   };
 
-  int aoff[2][4][2], boff[2][2][2];
+  // fragment addresses: one per (K-32 half, K-16 slice) and operand; row blocks (+32 rows: same swizzle) and the buffer are immediates
+  int aoff[2][2], boff[2][2];
+  {
+    const int ra = grp * 128 + l31, rb = wc * 64 + l31;
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int ra = grp * 128 + p * 32 + l31;
-      aoff[0][p][kk] = ra * ROWB + (((kk * 2 + hi) ^ ((ra >> 2) & 3)) << 4);
-      aoff[1][p][kk] = aoff[0][p][kk] + 2 * ST;
-      asm volatile("" : "+v"(aoff[0][p][kk]), "+v"(aoff[1][p][kk]));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rb = wc * 64 + i * 32 + l31;
-      boff[0][i][kk] = A_ST + rb * ROWB + (((kk * 2 + hi) ^ ((rb >> 2) & 3)) << 4);
-      boff[1][i][kk] = boff[0][i][kk] + 2 * ST;
-      asm volatile("" : "+v"(boff[0][i][kk]), "+v"(boff[1][i][kk]));
-    }
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = h * 4 + kk * 2 + hi;
+        aoff[h][kk] = XB + ra * ROWB + ((ch ^ ((ra >> 1) & 7)) << 4);
+        boff[h][kk] = WB + rb * ROWB + ((ch ^ ((rb >> 1) & 7)) << 4);
+        asm volatile("" : "+v"(aoff[h][kk]), "+v"(boff[h][kk]));
+      }
   }
   f32x16 acc[2][4];
   bf16x8 xf[4][2], wf[2][2];
 
-  // ---- prologue (once per workgroup): K-steps 0, 1, 2 of the first tile ----
+  // ---- prologue (once per workgroup): K-64 step 0 of the first tile ----
   g4_open_tile(st, a, kc, (int)blockIdx.x);
   publish(st);
   stage(std::integral_constant<int, 0>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff);
-  stage(std::integral_constant<int, 1>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + ROWB);
-  stage(std::integral_constant<int, 2>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + 2 * ROWB);
   g4_advance(st, a, kc);
-  publish(st);
+  publish(st);                                                // cur = chunk 0, nxt = its successor
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1526,26 +1530,31 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  auto step = [&](auto uc) {
+  unsigned long long tm_lb = 0, tm_mb = 0;
+  // phase u of a chunk: K-64 step u >> 1 (= its buffer), K-32 half u & 1
+  auto step = [&](auto uc, bool hold) {
     constexpr int u = decltype(uc)::value;
-    using SSlot = std::integral_constant<int, (u + 3) & 3>;
+    constexpr int buf = u >> 1, h = u & 1;
     // ---- LOAD ----
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) xf[p][kk] = *(const bf16x8*)(smem + aoff[u >> 1][p][kk] + (u & 1) * ST);
+      for (int p = 0; p < 4; ++p) xf[p][kk] = *(const bf16x8*)(smem + aoff[h][kk] + buf * OPB + p * (32 * ROWB));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wf[i][kk] = *(const bf16x8*)(smem + boff[u >> 1][i][kk] + (u & 1) * ST);
+      for (int i = 0; i < 2; ++i) wf[i][kk] = *(const bf16x8*)(smem + boff[h][kk] + buf * OPB + i * (32 * ROWB));
     }
-    if (u == 0) stage(SSlot{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + 3 * ROWB);   // step 3 of this chunk
-    else stage(SSlot{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + (u - 1) * ROWB);    // steps 0..2 of the next one
+    if (u == 0) stage(std::integral_constant<int, 1>{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + ROWB);   // step 1 of this chunk
+    if (u == 2) stage(std::integral_constant<int, 0>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff);          // step 0 of the next one
     __builtin_amdgcn_sched_barrier(0);
-    if (grp) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (h == 1 && grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long tq = 0;
+    if (kTiming) { tq = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     __builtin_amdgcn_s_barrier();
+    if (kTiming) { tm_lb += __builtin_amdgcn_s_memtime() - tq; }
     __builtin_amdgcn_sched_barrier(0);
     // ---- MFMA ----
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);                            // (with / without: 0.825 / 0.824 ms - kept for the hand-over at the barrier)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1554,14 +1563,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
         for (int p = 0; p < 4; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], xf[p][kk], acc[i][p], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!grp) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (h == 1 && !grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (u == 3 && hold) return;                               // waves 4-7, last phase of a tile: epilogue first, then this barrier
+    if (kTiming) { tq = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     __builtin_amdgcn_s_barrier();
+    if (kTiming) { tm_mb += __builtin_amdgcn_s_memtime() - tq; }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // epilogue-side lane role: 4 lanes x 8 columns cover the 32 columns (64 B) one accumulator block holds of an output row
   const int e_px = lane >> 2, e_ch = lane & 3;
+  unsigned long long tm_walk = 0, tm_epi = 0, tm_n = 0, tm0 = 0, tm1 = 0;
   for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
+    if (kTiming) tm0 = __builtin_amdgcn_s_memtime();
     const G4Tile c = g4_decode(kc, tile);
     const int col0 = c.n0 + wc * 64;
 #pragma unroll
@@ -1572,16 +1586,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
         for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
 
     for (int kq = 0; kq < nk4; ++kq) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
+      step(std::integral_constant<int, 0>{}, false);
+      step(std::integral_constant<int, 1>{}, false);
+      step(std::integral_constant<int, 2>{}, false);
+      // Tile end.  In lockstep the two groups' epilogues would run one after the other (waves 0-3 during the others' last MFMA segment and
+      // beyond, waves 4-7 during the first MFMA segment of the next tile: 2 E - 2 segments of idle matrix pipe per tile).  The waves 4-7
+      // therefore run their epilogue BEFORE the barrier that closes their last MFMA segment: both epilogues overlap, E + 1 segment.
+      step(std::integral_constant<int, 3>{}, grp && kq == nk4 - 1);
       __builtin_amdgcn_sched_barrier(0);
       g4_advance(st, a, kc);
       publish(st);
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (kTiming) tm1 = __builtin_amdgcn_s_memtime();
     // bias / gate rows of the lane's 16 channels: loaded HERE, not before the K walk - 48 registers the walk does not have (2 waves per SIMD);
     // they land under the first accumulator block's trip through LDS
     asm volatile("" ::: "memory");
@@ -1602,7 +1620,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     // ---- epilogue: the wave's 128 x 64 result, one 32-row x 32-column accumulator block at a time through its own 4 KB LDS slice
     // (fp32, XOR-swizzled 128-B rows), then 16-B stores with 4 lanes covering 64 contiguous bytes of a row ----
     {
-      char* const eslice = smem + gemm8p::EPI + wave * 4096;
+      char* const eslice = smem + EPI + wave * 4096;
       unsigned o_off[2], r_off[2];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -1684,6 +1702,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9)
     __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0), as a builtin: the compiler's own wait tracking sees the queue empty
     asm volatile("" ::: "memory");
+    if (kTiming) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); tm_walk += tm1 - tm0; tm_epi += tm2 - tm1; ++tm_n; }
+    if (grp) {                                                // the barrier held back above
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (kTiming && a.zero && blockIdx.x == 100 && lane == 0) {     // TIMING build: `zero` carries the host's debug buffer
+    unsigned long long* o = (unsigned long long*)a.zero + wave * 8;
+    o[0] = tm_walk; o[1] = tm_lb; o[2] = tm_mb; o[3] = tm_epi; o[4] = tm_n; o[5] = (unsigned long long)nk4 * 4;
   }
   if (!grp) {                                                 // balance the second group's extra first barrier
     __builtin_amdgcn_sched_barrier(0);
@@ -1711,13 +1739,13 @@ static const bf16_t* zero_page() {
 // environment switches.  Which shapes of the 33x720x1280 clip reach which kernel:
 //   conv3x3_halo4x  3x3(x3) stride-1 convs with Cin % 64 == 0, Cout % 128 == 0, H, W >= 16 (every VAE resnet conv) and the
 //                   upsample-fused 3x3 convs (Upsample3D)                                       268 + 12 launches, 55 % of the step
-//   gemm4x          plain GEMMs with M >= 4096, Cout % 256 == 0, Cin % 128 == 0, Cin >= 256 (DiT qkv / out / ff)    168 launches
+//   gemm8p          plain GEMMs with M >= 4096, Cout % 256 == 0, Cin % 128 == 0, Cin >= 256 (DiT qkv / out / ff)    168 launches
 //   smallk          pointwise convs with Cin_pad == 32: SpatialNorm conv_y||conv_b on the latent grid                    158 launches
 //   igemm_fast      everything else without upsampling: stride-2 downsample convs, the (3,1,1) forms of encoder.conv_in / decoder.conv_out,
 //                   decoder.conv_in (16 -> 512), the 1x1x1 shortcuts, encoder.conv_out, patch / text embedding, proj_out, the row
-//                   tails of the gemm4x GEMMs, 3x3 convs of small clips (H or W < 16)
+//                   tails of the gemm8p GEMMs, 3x3 convs of small clips (H or W < 16)
 //   igemm (v1)      upsample-fused convs too small for the halo tile (test-sized clips), frames above the 31-bit buffer range     0
-// (The 8-wave ping-pong generations conv3x3_halo8 / gemm8 are gone: every production shape they still carried - 8 + ~10 launches
+// (Round 1's 8-wave generations conv3x3_halo8 / gemm8 are gone: every production shape they still carried - 8 + ~10 launches
 // per clip - runs on igemm_fast within noise of its old time.)
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------------------------
@@ -1781,8 +1809,8 @@ __global__ __launch_bounds__(256) void smallk_kernel(const bf16_t* __restrict__ 
   }
 }
 
-enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM4X, K_SMALLK };
-static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm4x_kernel",
+enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM8P, K_SMALLK };
+static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8p_kernel",
                                            "smallk_kernel"};
 
 static ConvKernel select_kernel(const dove_conv_desc* d) {
@@ -1797,7 +1825,7 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
   if (plain_gemm) {
     if (d->cout_pad % 256 == 0 && d->cout_store % 256 == 0 && d->cin % 128 == 0 && d->cin >= 256 && (long long)256 * d->cin * 2 < (1ll << 31) &&
         d->ldo < (1 << 20) && d->ldr < (1 << 20) && (d->act == 0 || d->act == 1))
-      return K_GEMM4X;
+      return K_GEMM8P;
   }
   const bool conv3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad_h == 1 && d->pad_w == 1 && d->act == 0 && !d->gate &&
                      d->cout_pad % 128 == 0 && frame_fits;
@@ -1862,12 +1890,12 @@ extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
 
 static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern);
 
-// gemm4x tail: ntiles 256x256 tiles on G persistent workgroups take ceil(ntiles / G) rounds, and the last round of the DiT's
+// GEMM tail: ntiles 256x256 tiles on G persistent workgroups take ceil(ntiles / G) rounds, and the last round of the DiT's
 // N = 3072 GEMMs (864 tiles on 256 CUs) keeps 96 CUs busy for a whole tile time.  When the rows behind the last FULL round fit
 // one resident wave of igemm_fast's 128x128 tiles (2 workgroups per CU), those rows go to igemm_fast instead: they then cost
-// about 0.6 of a gemm4x round spread over every CU.  Rows are disjoint, both launches are ordered on the stream, the epilogue
+// about 0.6 of a gemm8p round spread over every CU.  Rows are disjoint, both launches are ordered on the stream, the epilogue
 // (bias / GELU / gated residual; gate_split shifted by the row offset) is the same code path as for any igemm_fast GEMM.
-static bool gemm4x_tail_split(const dove_conv_desc* d, long long* rows_main) {
+static bool gemm_tail_split(const dove_conv_desc* d, long long* rows_main) {
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
   if (d->t_out != 1 || d->h_out != 1) return false;                                  // token-major [1, 1, N] linears only
   const int cus = cu_count(), tiles_n = d->cout_pad / 256;
@@ -1903,7 +1931,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(!d->out_f32 || (kern0 == K_IGEMM_FAST && !d->resid && d->act == 0),
                  "conv_igemm: out_f32 is only implemented for plain convs that dispatch to igemm_fast_kernel");
   long long rows_main = 0;
-  if (kern0 == K_GEMM4X && !DOVE_DBG_BUF && gemm4x_tail_split(d, &rows_main)) {
+  if (kern0 == K_GEMM8P && !DOVE_DBG_BUF && gemm_tail_split(d, &rows_main)) {
     dove_conv_desc m = *d, t = *d;
     m.w_in = m.w_out = (int)rows_main;
     const long long tail = (long long)d->w_out - rows_main;
@@ -1912,7 +1940,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
     t.out = (char*)d->out + rows_main * d->ldo * 2;
     if (d->resid) t.resid = (const char*)d->resid + rows_main * d->ldr * 2;
     t.gate_split = d->gate_split > rows_main ? d->gate_split - rows_main : 0;
-    const int rc = conv_dispatch(&m, stream, K_GEMM4X);
+    const int rc = conv_dispatch(&m, stream, K_GEMM8P);
     return rc ? rc : conv_dispatch(&t, stream, K_IGEMM_FAST);
   }
   const int rc = conv_dispatch(d, stream, kern0);
@@ -1946,68 +1974,69 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   hipStream_t s = (hipStream_t)stream;
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
   switch (kern) {
-    case K_GEMM4X: {
-      static PerDeviceOnce attr4g;
-      if (attr4g.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-      }
+    case K_GEMM8P: {
       a.tiles_n = d->cout_pad / 256;
       const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
       DOVE_CHECK_ARG(nt > 0 && nt < (1ll << 31), "conv_igemm: grid too large");
+      DOVE_CHECK_ARG(!(d->gate && d->act), "conv_igemm: gate with activation is not a path of the reference");
       const int cus = cu_count();
       const unsigned grid4 = nt > cus ? (unsigned)cus : (unsigned)nt;
 #ifdef DOVE_TIMING_BUILD
-      if (DOVE_DBG_BUF && d->act == 0 && !d->gate) {   // tools/gemm4x_timing.py
-        static PerDeviceOnce attrt;
-        if (attrt.first()) {
-          (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-        }
-        a.zero = (const bf16_t*)DOVE_DBG_BUF;
-        hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-      } else
-#endif
-#ifdef DOVE_TIMING_BUILD
       {
-        static int sched = -1;                                   // DOVE_GEMM4X_SCHED=0: the round-2 DMA order (tools/gemm4x_sched.py A/B)
-        if (sched < 0) { const char* e = getenv("DOVE_GEMM4X_SCHED"); sched = e ? atoi(e) : 1; }
-        if (sched == 0 && !d->gate && d->act == 0) {
-          static PerDeviceOnce attrs;
-          if (attrs.first()) (void)hipFuncSetAttribute((const void*)(gemm4x_kernel<false, false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          hipLaunchKernelGGL((gemm4x_kernel<false, false, false, 0>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x sched 0)");
-          return DOVE_OK;
-        }
-      }
-#endif
-#ifdef DOVE_TIMING_BUILD
-      {
-        const char* e8 = getenv("DOVE_GEMM8P");                  // tools/gemm8p_ab.py toggles it between calls
-        if (e8 && atoi(e8)) {
-          static PerDeviceOnce attr8;
-          if (attr8.first()) {
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        // the predecessor kernel, for within-run A/Bs: DOVE_GEMM8P=0 (read per call: tools/gemm8p_ab.py toggles it), with DOVE_GEMM4X_SCHED=0
+        // its round-2 DMA order (tools/gemm4x_sched.py); a debug buffer selects the s_memtime instantiations (tools/gemm*_timing.py)
+        const char* e8 = getenv("DOVE_GEMM8P");
+        if (e8 && atoi(e8) == 0) {
+          static PerDeviceOnce attr4g;
+          if (attr4g.first()) {
+            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)(gemm4x_kernel<false, false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
           }
-          if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
-          else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
-          else hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
-          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p)");
+          const char* es = getenv("DOVE_GEMM4X_SCHED");
+          if (DOVE_DBG_BUF && d->act == 0 && !d->gate) {
+            a.zero = (const bf16_t*)DOVE_DBG_BUF;
+            hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          } else if (es && atoi(es) == 0 && !d->gate && d->act == 0) {
+            hipLaunchKernelGGL((gemm4x_kernel<false, false, false, 0>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          } else if (d->gate) {
+            hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          } else if (d->act == 1) {
+            hipLaunchKernelGGL((gemm4x_kernel<true, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          } else {
+            hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+          }
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
+          return DOVE_OK;
+        }
+        if (DOVE_DBG_BUF) {
+          static PerDeviceOnce attr8t;
+          if (attr8t.first()) {
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+          }
+          a.zero = (const bf16_t*)DOVE_DBG_BUF;
+          if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          else hipLaunchKernelGGL((gemm8p_kernel<false, false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p timing)");
           return DOVE_OK;
         }
       }
 #endif
-      if (d->gate) {
-        DOVE_CHECK_ARG(d->act == 0, "conv_igemm: gate with activation is not a path of the reference");
-        hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-      } else if (d->act == 1) {
-        hipLaunchKernelGGL((gemm4x_kernel<true, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-      } else {
-        hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
+      static PerDeviceOnce attr8;
+      if (attr8.first()) {
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
       }
-      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
+      if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      else hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p)");
       return DOVE_OK;
     }
     case K_SMALLK: {

@@ -72,7 +72,7 @@ typedef struct dove_conv_desc {
   int out_f32;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
-/* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm4x_kernel,
+/* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm8p_kernel,
  * smallk_kernel) - for reporting (bench.py's per-kernel roofline) and for tests that pin which production shape
  * runs where; the rule is a pure function of the descriptor (no environment switches) */
 const char* dove_conv_kernel_name(const dove_conv_desc* d);

@@ -104,7 +104,7 @@ def test_dispatch_rule_mirror(lib):
             assert rows == d.t_out * -(-d.h_out // 16) * -(-d.w_out // 32) * 4
     names = {  # production shape -> kernel (cin, cout, k, T, H, W, up, stride)
         (32, 1024, (1, 1, 1), 2, 90, 160, 0, 1): "smallk_kernel",           # SpatialNorm conv_y || conv_b on the latent grid
-        (3072, 9216, (1, 1, 1), 1, 1, 18226, 0, 1): "gemm4x_kernel",
+        (3072, 9216, (1, 1, 1), 1, 1, 18226, 0, 1): "gemm8p_kernel",
         (32, 128, (3, 3, 3), 9, 720, 1280, 0, 1): "igemm_fast_kernel",
         (128, 32, (3, 3, 3), 8, 720, 1280, 0, 1): "igemm_fast_kernel",
         (128, 128, (3, 3), 8, 720, 1280, 0, 2): "igemm_fast_kernel",
@@ -163,8 +163,8 @@ def test_kernel_dispatch_table():
         "decoder.conv_in 16->512": (name((3, 90, 160), 512, 16, (3, 3, 3)), "igemm_fast_kernel"),
         "decoder.conv_out 128->3": (name((9, 720, 1280), 3, 128, (3, 3, 3)), "igemm_fast_kernel"),
         "downsample conv stride 2": (name((9, 720, 1280), 128, 128, (3, 3), stride=2, pad=(0, 0)), "igemm_fast_kernel"),
-        "DiT qkv 3072->9216": (name((1, 1, 18226), 9216, 3072, ()), "gemm4x_kernel"),
-        "DiT ff2 12288->3072 gated": (name((1, 1, 18226), 3072, 12288, (), gated=True), "gemm4x_kernel"),
+        "DiT qkv 3072->9216": (name((1, 1, 18226), 9216, 3072, ()), "gemm8p_kernel"),
+        "DiT ff2 12288->3072 gated": (name((1, 1, 18226), 3072, 12288, (), gated=True), "gemm8p_kernel"),
         "SpatialNorm conv_y||conv_b 16->256": (name((3, 90, 160), 256, 16, (1, 1, 1)), "smallk_kernel"),
         "resnet shortcut 256->128 @ 720p": (name((9, 720, 1280), 128, 256, (1, 1, 1)), "igemm_fast_kernel"),
         "text embedding 4096->3072 (226 rows)": (name((1, 1, 226), 3072, 4096, ()), "igemm_fast_kernel"),
@@ -179,4 +179,4 @@ def test_kernel_dispatch_table():
     for cname, N, cin, cout, kw in T.LIN_CASES:
         covered.add(name((1, 1, N), cout, cin, (), act=kw.get("act", 0), gated=kw.get("gate", False), resid=kw.get("resid_only", False)))
     # the superseded 8-wave generations (conv3x3_halo8, gemm8) no longer exist: five kernels carry every shape
-    assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "gemm4x_kernel", "smallk_kernel"}, covered
+    assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "gemm8p_kernel", "smallk_kernel"}, covered

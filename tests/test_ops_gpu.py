@@ -54,7 +54,7 @@ CONV_CASES = [
     ("c3d_96_64", 96, 64, (3, 3, 3), 2, 8, 8, {}),
     ("c111_128_256", 128, 256, (1, 1, 1), 3, 9, 11, {}),
     ("c111_16_1024", 16, 1024, (1, 1, 1), 3, 4, 6, {}),
-    ("c111_M6144", 128, 256, (1, 1, 1), 2, 48, 64, {}),            # a plain GEMM that misses gemm4x's shape rules: igemm_fast
+    ("c111_M6144", 128, 256, (1, 1, 1), 2, 48, 64, {}),            # a plain GEMM that misses gemm8p's shape rules: igemm_fast
     # smallk_kernel: CogVideoXSpatialNorm3D's conv_y || conv_b on the 16-channel latent (Cin_pad 32), ragged last row block
     ("c111_smallk_spatialnorm", 16, 512, (1, 1, 1), 2, 45, 81, {}),
     ("c2d_down_even", 128, 128, (3, 3), 3, 16, 20, {"stride": 2, "pad": (0, 0)}),
@@ -117,7 +117,7 @@ LIN_CASES = [
     ("lin_12288_3072_gate_inplace", 270, 12288, 3072, {"gate": True, "inplace": True}),
     ("lin_M1", 1, 256, 256, {}),
     ("lin_M129", 129, 256, 64, {}),
-    # plain GEMMs with M >= 4096 that miss gemm4x's shape rules (were gemm8, now igemm_fast): ragged M tail, every K-loop tail length (nk = 1, 2, 3, 4, 96), epilogues
+    # plain GEMMs with M >= 4096 that miss gemm8p's shape rules (were gemm8, now igemm_fast): ragged M tail, every K-loop tail length (nk = 1, 2, 3, 4, 96), epilogues
     ("lin8_basic", 4700, 3072, 256, {}),
     ("lin8_gelu", 4096, 256, 1024, {"act": 1}),
     ("lin8_gate_inplace", 5000, 1024, 128, {"gate": True, "inplace": True}),
@@ -125,12 +125,12 @@ LIN_CASES = [
     ("lin8_k64", 4100, 64, 256, {}),
     ("lin8_k96", 4200, 96, 128, {}),
     ("lin8_k128", 4608, 128, 3072, {}),
-    # gemm4x persistent 256x256 kernel (M >= 4096, cout % 256 == 0, cin % 128 == 0): ragged M tail, one and many K chunks,
+    # gemm8p persistent 256x256 kernel (M >= 4096, cout % 256 == 0, cin % 128 == 0): ragged M tail, one and many K chunks,
     # more tiles than CUs (tile switch inside a workgroup), GELU / gated in-place residual epilogues
     ("lin4x_ragged", 4099, 256, 256, {}),
     ("lin4x_many_tiles", 20011, 256, 1024, {}),
     ("lin4x_many_tiles_gate", 20011, 384, 768, {"gate": True, "inplace": True}),
-    # gemm4x + igemm_fast tail split (rows behind the last full round of 256 tiles): 316 tiles -> 16384 rows + 3627 rows; the
+    # gemm8p + igemm_fast tail split (rows behind the last full round of 256 tiles): 316 tiles -> 16384 rows + 3627 rows; the
     # gate's row-class boundary before / inside the tail; GELU; the DiT's own N = 3072 shape (864 tiles -> 16384 + 1842 rows)
     ("lin4x_tail_gate", 20011, 256, 1024, {"gate": True, "inplace": True}),
     ("lin4x_tail_gate_late", 20011, 256, 1024, {"gate": True, "gate_split": 18000}),
@@ -718,9 +718,9 @@ def test_prodshape_upsample_conv_256_sampled(tmode, T_in, t_out):
 
 
 def test_prodshape_dit_linears_sampled():
-    """The DiT's two extreme linears at N = 18 226 rows: qkv (3072 -> 9216, + bias; 2592 tiles = 10 full rounds of gemm4x + a 50-row
+    """The DiT's two extreme linears at N = 18 226 rows: qkv (3072 -> 9216, + bias; 2592 tiles = 10 full rounds of gemm8p + a 50-row
     tail on igemm_fast) and ff2 (12 288 -> 3072 with the gated in-place residual, text / video gate rows split at 226; 864 tiles =
-    16 384 rows on gemm4x + 1842 on the tail kernel).  Sampled rows: first / last, the 256-row tile seams, both sides of the gate's
+    16 384 rows on gemm8p + 1842 on the tail kernel).  Sampled rows: first / last, the 256-row tile seams, both sides of the gate's
     row-class boundary and of each tail split."""
     N = 18226
     g = torch.Generator(device="cuda").manual_seed(121)

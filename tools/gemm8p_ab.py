@@ -14,7 +14,8 @@ M = 18226
 g = torch.Generator(device="cuda").manual_seed(1)
 rows = torch.tensor([0, 31, 127, 128, 255, 256, 4095, 9999, 16383, 16384, 18175, 18176, 18225], device="cuda")
 cases = (("qkv", 3072, 9216, {}), ("out", 3072, 3072, {"gated": True}), ("ff1", 3072, 12288, {"act": 1}), ("ff2", 12288, 3072, {"gated": True}),
-         ("plain+resid", 3072, 3072, {"resid": True}), ("ragged 4100 rows", 3072, 3072, {"rows": 4100}))
+         ("plain+resid", 3072, 3072, {"resid": True}), ("ragged 4100 rows", 3072, 3072, {"rows": 4100}),
+         ("ff1 shape, plain", 3072, 12288, {}), ("qkv shape, GELU", 3072, 9216, {"act": 1}), ("ff2 shape, plain", 12288, 3072, {}))
 ONLY = sys.argv[1] if len(sys.argv) > 1 else None          # e.g. "ff1": one case, few repeats (PMC passes)
 ROUNDS = 2 if ONLY else 5
 for name, K, N, opt in cases:
@@ -33,9 +34,10 @@ for name, K, N, opt in cases:
     if opt.get("gated"):
         kw["gate"] = torch.randn(2, N, device="cuda", generator=g)
         kw["gate_split"] = 226
-    ys, ts = {}, {0: [], 1: []}
+    VARS = (0, 1)                                              # DOVE_GEMM8P=0: gemm4x (the predecessor, TIMING build only), 1: gemm8p (the product kernel)
+    ys, ts = {}, {v: [] for v in VARS}
     for rnd in range(ROUNDS):
-        for v in (0, 1):
+        for v in VARS:
             os.environ["DOVE_GEMM8P"] = str(v)
             y = torch.empty(m, N, dtype=torch.bfloat16, device="cuda")
             ops.linear(x, pc, out=y, **kw)
