@@ -751,6 +751,39 @@ def test_prodshape_dit_linears_sampled():
     close("prod_linear_ff2_gated", out[rows.cuda()], ref)
 
 
+def test_prodshape_dit_linears_mx_sampled():
+    """The same two linears on the MXFP8 GEMM of BASELINE configs[4] at N = 18 226 rows (ragged last row tile, 10.1 / 3.4 rounds of 256
+    tiles), against dequantise-then-fp32-matmul of the SAME quantised operands at sampled rows (block scales run along K of a row, so
+    a row's reference needs that row only)."""
+    N = 18226
+    g = torch.Generator(device="cuda").manual_seed(123)
+    gw = torch.Generator().manual_seed(124)
+    rows = torch.tensor([0, 1, 225, 226, 227, 255, 256, 257, 4095, 4096, 9999, 16383, 16384, 16385, 18175, 18176, 18177, 18224, 18225])
+    # qkv
+    w = torch.randn(9216, 3072, generator=gw) * 3072 ** -0.5
+    b = torch.randn(9216, generator=gw) * 0.1
+    pw = ops.pack_linear_mx(w, b, "cuda")
+    x = (torch.randn(N, 3072, device="cuda", generator=g) * torch.exp(torch.randn(1, 3072, device="cuda", generator=g))).to(BF)
+    z = ops.linear_mx(ops.mx_quant(x), pw)
+    torch.cuda.synchronize()
+    ref = E.linear_mx_ref(x[rows.cuda()].cpu(), w, b)
+    close("prod_linear_mx_qkv", z[rows.cuda()], ref)
+    del z, pw, w
+    # ff2, gated residual
+    w = torch.randn(3072, 12288, generator=gw) * 12288 ** -0.5
+    b = torch.randn(3072, generator=gw) * 0.1
+    pw = ops.pack_linear_mx(w, b, "cuda")
+    x = torch.randn(N, 12288, device="cuda", generator=g).to(BF)
+    hs = torch.randn(N, 3072, device="cuda", generator=g).to(BF)
+    gate = torch.randn(2, 3072, generator=gw)
+    out = ops.linear_mx(ops.mx_quant(x), pw, resid=hs, gate=gate.cuda().contiguous(), gate_split=226)
+    torch.cuda.synchronize()
+    y = E.linear_mx_ref(x[rows.cuda()].cpu(), w, b).float()
+    ref = (hs[rows.cuda()].float().cpu() + gate[(rows >= 226).long()] * y)
+    # linear_mx_ref rounded y to bf16 before the gate; the kernel applies bias, gate and residual in fp32 and rounds once
+    close("prod_linear_mx_ff2_gated", out[rows.cuda()], ref.to(BF))
+
+
 def _sample_queries(N):
     return torch.tensor([0, 1, 31, 32, 127, 128, 129, 4095, 4096, 9000, 9001, 18175, 18176, 18207, 18208, 18224, 18225])
 
