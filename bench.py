@@ -136,6 +136,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a peer that left must not make the communicator's watchdog abort this process: rank 0 still has the line to print (see the
+        # guard around the single-clip mode below)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         if args.oversubscribe:
             local = 0
             torch.cuda.set_device(0)
@@ -214,9 +217,12 @@ def main():
     else:
         assert out.shape == (1, 3, args.frames, args.height, args.width) and bool(torch.isfinite(out).all())
 
-    # ---- N > 1: the same ranks now run ONE clip together (BASELINE configs[2]); same barrier / max-over-ranks timing ----
-    single = None
-    if use_dist and world > 1 and not strong:
+    def measure_single_clip():
+        fault = os.environ.get("DOVE_BENCH_STRONG_FAULT", "")      # debug only (tests of the guard below): "raise:<rank>" / "hang:<rank>"
+        if fault == f"raise:{rank}":
+            raise RuntimeError("injected fault (DOVE_BENCH_STRONG_FAULT)")
+        if fault == f"hang:{rank}":
+            time.sleep(1e6)
         import torch.distributed as dist
         clip0 = video if rank == 0 else prepare_clip(synth_lr_clip(args.frames, args.height // up, args.width // up, seed=42, device=dev), up)
         for _ in range(max(1, args.warmup)):            # the first sharded call records the halo plan (blocking receives)
@@ -237,7 +243,7 @@ def main():
         assert sum(int(x[1]) for x in infos) == args.frames, "the ranks' decoded frames do not add up to the clip"
         macs1 = flops.clip_macs(v, t, args.frames, args.height, args.width)
         n_tok = macs1["tokens"]
-        single = {
+        return {
             "what": "ONE clip sharded over all ranks (BASELINE configs[2]): halo-exact VAE (frame-batches / paired pieces per rank, "
                     "temporal-conv borders by send/recv rank -> rank+1) + sequence/head-parallel DiT (one all_to_all each way per layer); "
                     "bit-identical to the one-GPU result (tests/test_dist_gpu.py)",
@@ -319,8 +325,6 @@ def main():
                                          for k, a in top}},
             "model_build_s": t_build,
         }
-        if single is not None:
-            res["single_clip"] = single
         if args.oversubscribe:
             res["invalid"] = "debug run: all ranks share GPU 0 over gloo (--oversubscribe)"
         if strong:
@@ -374,6 +378,32 @@ def main():
                 "speedup_vs_headline_this_run": (vsteps * args.frames / tv) / value,
                 "psnr_vs_bf16_path_db_this_clip": float((10 * torch.log10(1.0 / (mse + 1e-8))).mean()),
                 "psnr_note": "full-size clip, random-init weights (saturated output); the un-saturated 42-layer gate is in tests/test_parity_gpu.py"}]
+    # ---- N > 1: the same ranks now run ONE clip together (BASELINE configs[2]); same barrier / max-over-ranks timing.  This mode
+    # has run on RCCL with one rank only (no multi-GPU box was available to the builder; tests: gloo, R = 2 / 4 / 8 processes on one GPU), so it
+    # must not be able to take the weak-scaling line - measured and assembled above - down with it: an exception on any rank, or a
+    # collective that never returns, ends in `single_clip: {"error": ...}` on the ONE line rank 0 prints, and every rank leaves with 0 ----
+    if use_dist and world > 1 and not strong:
+        import threading
+        limit = float(os.environ.get("DOVE_BENCH_STRONG_TIMEOUT", 180.0 + 6.0 * elapsed * (1.0 + args.warmup / max(args.steps, 1))))
+
+        def leave(err):
+            if rank == 0:
+                res["single_clip"] = {"error": err, "note": "the weak-scaling fields of this line were measured before this mode ran and are unaffected"}
+                print(json.dumps(res), flush=True)
+            sys.stdout.flush()
+            os._exit(0)                                        # not sys.exit: a communicator with a dead peer may hang in its destructor
+
+        dog = threading.Timer(limit, leave, args=(f"single-clip mode did not finish within {limit:.0f} s (a rank failed or a collective hung)",))
+        dog.daemon = True
+        dog.start()
+        try:
+            single = measure_single_clip()
+        except BaseException as e:                             # noqa: BLE001 - report, never crash the line
+            leave(f"{type(e).__name__}: {e}")
+        dog.cancel()
+        if rank == 0:
+            res["single_clip"] = single
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if use_dist:
         import torch.distributed as dist
