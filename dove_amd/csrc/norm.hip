@@ -414,39 +414,98 @@ extern "C" int dove_layernorm_modulate_bf16(const void* x, void* y, long long ro
 //   Q' [H][Npad][64] = RoPE(LN64(q)) * (softmax_scale * log2 e)      (rows >= text_len get RoPE)
 //   K' [H][Npad][64] = RoPE(LN64(k))
 //   V^T[H][64][Npad] = v transposed (so the PV MFMA reads its A operand like K)
-// One lane owns one (token, head) 64-vector: LayerNorm and the interleaved-pair rotation are lane-local.
+// Eight lanes own one (token, head) 64-vector, 16 bytes each: every load / store instruction of a wave covers whole 128-B lines of
+// 8 tokens (one lane per vector touched 64 different lines per instruction and ran at 2.6 TB/s: round 3).  LayerNorm statistics are
+// reduced over the 8 lanes by three xor-shuffles; the interleaved-pair rotation stays inside a lane's 8 values.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict__ qkv, long long N, long long Npad,
-                                                       int heads, int text_len, const float* __restrict__ gq,
-                                                       const float* __restrict__ bq, const float* __restrict__ gk,
-                                                       const float* __restrict__ bk, const float* __restrict__ cosT,
-                                                       const float* __restrict__ sinT, float qscale, float eps,
-                                                       bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh,
-                                                       bf16_t* __restrict__ Vt, int v_swap) {
-  __shared__ float vt[4][64][65];   // V transpose staging, one slice per wave (row stride 65: conflict-free both ways)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int h = blockIdx.y;
-  const int which = blockIdx.z;  // 0 q, 1 k, 2 v
-  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 64;
-  const long long n = n0 + lane;
-  if (n0 >= N) return;
+constexpr int QK_HB = 4;                                       // heads per thread: the token's cos / sin rows (fp32: 4x the bytes of the data they
+                                                               // rotate) are fetched once per QK_HB heads, not once per head
+__global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__ qkv, long long N, long long Npad, int heads, int text_len,
+                                                      const float* __restrict__ gq, const float* __restrict__ bq,
+                                                      const float* __restrict__ gk, const float* __restrict__ bk,
+                                                      const float* __restrict__ cosT, const float* __restrict__ sinT, float qscale, float eps,
+                                                      bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh) {
+  const int c = threadIdx.x & 7;                               // 8-value chunk of the 64-vector
+  const int h0 = blockIdx.y * QK_HB, which = blockIdx.z;       // 0 q, 1 k
+  const long long n = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
   const int D = heads * 64;
-  float f[64];
-  if (which == 2 && (Npad & 7) == 0) {
-    // the wave's 64 tokens x 64 dims go through LDS so that lane d owns row d of V^T: 128 contiguous bytes per lane instead of
-    // 64 two-byte stores Npad apart (2.5 -> 3.4 TB/s for the whole kernel)
-    if (n < N) {
-      const bf16_t* src = qkv + n * (3LL * D) + 2LL * D + h * 64;
+  const bool live = n < N;                                     // all 8 lanes of a token agree: the shuffles below stay inside live groups
+  const long long nn = live ? n : N - 1;                       // dead lanes compute on a valid row and store nothing
+  const float* gam = (which == 0 ? gq : gk) + c * 8;
+  const float* bet = (which == 0 ? bq : bk) + c * 8;
+  const f32x4 g0 = *(const f32x4*)gam, g1 = *(const f32x4*)(gam + 4), b0 = *(const f32x4*)bet, b1 = *(const f32x4*)(bet + 4);
+  const bool rope = nn >= text_len && cosT;
+  f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+  if (rope) {
+    const float* cr = cosT + (nn - text_len) * 64 + c * 8;
+    const float* sr = sinT + (nn - text_len) * 64 + c * 8;
+    c0 = *(const f32x4*)cr; c1 = *(const f32x4*)(cr + 4); s0 = *(const f32x4*)sr; s1 = *(const f32x4*)(sr + 4);
+  }
+  const float sc = which == 0 ? qscale : 1.0f;
+  const bf16_t* src = qkv + nn * (3LL * D) + (long long)which * D + c * 8;
+  bf16_t* dst = (which == 0 ? Qh : Kh) + nn * 64 + c * 8;
+  uint4 raw[QK_HB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) unpack8(*(const uint4*)(src + i * 8), f + i * 8);
-    } else {
+  for (int j = 0; j < QK_HB; ++j) raw[j] = h0 + j < heads ? *(const uint4*)(src + (h0 + j) * 64) : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int d = 0; d < 64; ++d) f[d] = 0.f;                          // keys past N inside the pad stay zero
+  for (int j = 0; j < QK_HB; ++j) {
+    float f[8];
+    unpack8(raw[j], f);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += f[e];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    const float mean = s * (1.0f / 64.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = f[e] - mean; v += t * t; }
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    const float rstd = rsqrtf(v * (1.0f / 64.0f) + eps);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+    if (rope) {
+      // diffusers rounds LN output to the model dtype before apply_rotary_emb's fp32 math; keep fp32 here
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = f[2 * i], b = f[2 * i + 1];
+        const float ca = i < 2 ? c0[2 * i] : c1[2 * i - 4], cb = i < 2 ? c0[2 * i + 1] : c1[2 * i - 3];
+        const float sa = i < 2 ? s0[2 * i] : s1[2 * i - 4], sb = i < 2 ? s0[2 * i + 1] : s1[2 * i - 3];
+        f[2 * i] = a * ca - b * sa;
+        f[2 * i + 1] = b * cb + a * sb;
+      }
     }
 #pragma unroll
-    for (int d = 0; d < 64; ++d) vt[wave][lane][d] = f[d];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int e = 0; e < 8; ++e) f[e] *= sc;
+    if (live && h0 + j < heads) *(uint4*)(dst + (long long)(h0 + j) * Npad * 64) = pack8(f);
+  }
+}
+
+// V^T: a wave's 64 tokens x 64 dims go through LDS so that lane d owns row d of V^T (128 contiguous bytes per lane instead of 64
+// two-byte stores Npad apart); the loads are the same 8-lanes-per-token full-line pattern as above.
+__global__ __launch_bounds__(256) void v_post_kernel(const bf16_t* __restrict__ qkv, long long N, long long Npad, int heads,
+                                                     bf16_t* __restrict__ Vt, int v_swap) {
+  __shared__ float vt[4][64][65];   // one slice per wave (row stride 65: conflict-free both ways)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = blockIdx.y;
+  const long long n0 = ((long long)blockIdx.x * 4 + wave) * 64;
+  if (n0 >= N) return;
+  const int D = heads * 64;
+  const int t8 = lane >> 3, c = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long n = n0 + i * 8 + t8;
+    float f[8];
+    if (n < N) unpack8(*(const uint4*)(qkv + n * (3LL * D) + 2LL * D + h * 64 + c * 8), f);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = 0.f;                           // keys past N inside the pad stay zero
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt[wave][i * 8 + t8][c * 8 + e] = f[e];
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((Npad & 7) == 0) {
     bf16_t* dst = Vt + ((long long)h * 64 + lane) * Npad + n0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -458,49 +517,9 @@ __global__ __launch_bounds__(256) void qkv_post_kernel(const bf16_t* __restrict_
       for (int e = 0; e < 8; ++e) o[e] = v_swap ? vt[wave][g16 + odd + (e & 3) + (e >> 2) * 8][lane] : vt[wave][j * 8 + e][lane];
       if (n0 + j * 8 + 8 <= Npad) *(uint4*)(dst + j * 8) = pack8(o);
     }
-    return;
-  }
-  if (n >= N) return;
-  const bf16_t* src = qkv + n * (3LL * D) + (long long)which * D + h * 64;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) unpack8(*(const uint4*)(src + i * 8), f + i * 8);
-  if (which == 2) {                                                     // row stride not 16-byte aligned (rank-local packing)
-    bf16_t* dst = Vt + ((long long)h * 64) * Npad + n;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) dst[(long long)d * Npad] = f2bf(f[d]);
-    return;
-  }
-  const float* gam = which == 0 ? gq : gk;
-  const float* bet = which == 0 ? bq : bk;
-  float s = 0.f;
-#pragma unroll
-  for (int d = 0; d < 64; ++d) s += f[d];
-  const float mean = s * (1.0f / 64.0f);
-  float v = 0.f;
-#pragma unroll
-  for (int d = 0; d < 64; ++d) { const float t = f[d] - mean; v += t * t; }
-  const float rstd = rsqrtf(v * (1.0f / 64.0f) + eps);
-#pragma unroll
-  for (int d = 0; d < 64; ++d) f[d] = (f[d] - mean) * rstd * gam[d] + bet[d];
-  if (n >= text_len && cosT) {
-    // diffusers rounds LN output to the model dtype before apply_rotary_emb's fp32 math; keep fp32 here
-    const float* cr = cosT + (n - text_len) * 64;
-    const float* sr = sinT + (n - text_len) * 64;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      const float a = f[2 * i], b = f[2 * i + 1];
-      f[2 * i] = a * cr[2 * i] - b * sr[2 * i];
-      f[2 * i + 1] = b * cr[2 * i + 1] + a * sr[2 * i + 1];
-    }
-  }
-  const float sc = which == 0 ? qscale : 1.0f;
-  bf16_t* dst = (which == 0 ? Qh : Kh) + ((long long)h * Npad + n) * 64;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f[i * 8 + e] * sc;
-    *(uint4*)(dst + i * 8) = pack8(o);
+  } else {                                                              // row stride not 16-byte aligned (rank-local packing): natural order,
+    bf16_t* dst = Vt + ((long long)h * 64 + lane) * Npad + n0;          // two-byte stores of the tokens that exist
+    for (int j = 0; j < 64 && n0 + j < N; ++j) dst[j] = f2bf(vt[wave][j][lane]);
   }
 }
 
@@ -515,9 +534,10 @@ extern "C" int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, 
   DOVE_CHECK_ARG(N > 0 && Npad >= N, "qkv_post: Npad must be >= N");
   DOVE_CHECK_ARG((cosT == nullptr) == (sinT == nullptr), "qkv_post: cos/sin must both be given or both be null");
   DOVE_CHECK_ARG(v_order == 0 || (v_order == 1 && Npad % 16 == 0), "qkv_post: v_order 1 (quad-swapped V^T) needs Npad %% 16 == 0");
-  dim3 grid((unsigned)((N + 255) / 256), heads, 3);
-  hipLaunchKernelGGL(qkv_post_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
-                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh, (bf16_t*)Vt, v_order);
+  hipLaunchKernelGGL(qk_post_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((heads + QK_HB - 1) / QK_HB), 2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
+                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh);
+  hipLaunchKernelGGL(v_post_kernel, dim3((unsigned)((N + 255) / 256), heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
+                     (bf16_t*)Vt, v_order);
   DOVE_CHECK_LAUNCH("dove_qkv_post_bf16");
   return DOVE_OK;
 }
