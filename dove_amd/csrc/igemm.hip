@@ -64,6 +64,7 @@ struct IgemmArgs {
   float* gn_partial;   // conv3x3_halo4x only: fused GroupNorm(32) partial sums of the stored output, [rows][32][2]
   int cpg_log;         // log2(channels per group) = log2(Cout / 32)
   int out_f32;         // igemm_fast only: `out` is float [..][ldo] (no bf16 rounding): the tap-split conv_out's partial sums
+  int nt_out;          // gemm8p only: nontemporal output stores (outputs larger than the Infinity Cache: see conv_dispatch)
 };
 
 template <int BN, int BK>
@@ -1688,7 +1689,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
                 }
               }
               const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
-              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 64, 0);
+              if (a.nt_out) __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 64, 2);   // aux 2 = nt
+              else __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 64, 0);
               __builtin_amdgcn_sched_barrier(0);                       // store-data hazard: see gemm4x
               asm volatile("s_nop 3" ::: "memory");
               __builtin_amdgcn_sched_barrier(0);
@@ -1963,12 +1965,12 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
   a.out_f32 = d->out_f32;
+  a.nt_out = 0;
   a.debug = 0;
 #ifdef DOVE_TIMING_BUILD
   {
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("DOVE_IGEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
-    a.debug = ablate;
+    const char* e = getenv("DOVE_IGEMM_ABLATE");          // read per call: the A/B tools toggle it
+    a.debug = e ? atoi(e) : 0;
   }
 #endif
   hipStream_t s = (hipStream_t)stream;
@@ -1976,6 +1978,15 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   switch (kern) {
     case K_GEMM8P: {
       a.tiles_n = d->cout_pad / 256;
+      // An output larger than the 256 MB Infinity Cache streams through it and evicts the operand panels the other workgroups are about to
+      // re-read: written nontemporally, ff1 (18 226 x 12 288: 448 MB) runs 10-12 % faster back to back, qkv (336 MB) 1.5-2.4 %, the 112 MB
+      // outputs of out / ff2 1.0-1.5 % slower.  Inside the operator the consumers then read from HBM what the cache might have kept: the
+      // whole clip gains 0.1-0.25 % (within-run, three A/Bs; profiles/r03_gemm8p_nt.log) - kept because it never loses, not because it matters
+      a.nt_out = (long long)M * d->ldo * 2 > (256ll << 20);
+#ifdef DOVE_TIMING_BUILD
+      if (a.debug & 8) a.nt_out = 1;                             // tools/gemm8p_nt.py: force on / off
+      if (a.debug & 16) a.nt_out = 0;
+#endif
       const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
       DOVE_CHECK_ARG(nt > 0 && nt < (1ll << 31), "conv_igemm: grid too large");
       DOVE_CHECK_ARG(!(d->gate && d->act), "conv_igemm: gate with activation is not a path of the reference");
