@@ -1,5 +1,7 @@
-"""Whole-operator A/B of a TIMING-build switch on the headline clip: process_video alternately with DOVE_IGEMM_ABLATE = A and = B
-(read per call by the timing library).  Usage: python tools/e2e_env_ab.py <A> <B> [rounds]   e.g. 16 0 = gemm8p nt stores forced off vs the product rule."""
+"""Whole-operator A/B of a TIMING-build switch on the headline clip: process_video alternately with <VAR> = A and = B (variables the
+timing library reads per call).  Usage: python tools/e2e_env_ab.py <VAR> <A> <B> [rounds]
+  DOVE_IGEMM_ABLATE 16 0   gemm8p nontemporal output stores forced off vs the product rule
+  DOVE_GEMM8P 0 1          gemm4x (round 2's GEMM) vs gemm8p"""
 import os
 import statistics
 import sys
@@ -18,8 +20,8 @@ from dove_amd.inference import process_video  # noqa: E402
 from dove_amd.pipeline import CogVideoXPipeline  # noqa: E402
 from safetensors.torch import load_file  # noqa: E402
 
-A, B = sys.argv[1], sys.argv[2]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+VAR, A, B = sys.argv[1], sys.argv[2], sys.argv[3]
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 dev = torch.device("cuda", 0)
 text = load_file(os.path.join(ROOT, "tests", "golden", "empty_prompt_embedding.safetensors"))["prompt_embedding"]
 v, t, s = config.default_configs()
@@ -29,7 +31,7 @@ noise = torch.randn(1, 16, 9, 90, 160, device=dev, generator=torch.Generator(dev
 ts, outs = {A: [], B: []}, {}
 for rnd in range(rounds + 1):
     for k in (A, B):
-        os.environ["DOVE_IGEMM_ABLATE"] = k
+        os.environ[VAR] = k
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
@@ -38,4 +40,4 @@ for rnd in range(rounds + 1):
             ts[k].append(time.perf_counter() - t0)
         outs[k] = out
 ma, mb = statistics.median(ts[A]), statistics.median(ts[B])
-print(f"DOVE_IGEMM_ABLATE={A}: {ma * 1e3:.1f} ms per clip | ={B}: {mb * 1e3:.1f} ms per clip ({(ma / mb - 1) * 100:+.2f} %)   outputs equal: {bool(torch.equal(outs[A], outs[B]))}", flush=True)
+print(f"{VAR}={A}: {ma * 1e3:.1f} ms per clip | ={B}: {mb * 1e3:.1f} ms per clip ({(ma / mb - 1) * 100:+.2f} %)   outputs equal: {bool(torch.equal(outs[A], outs[B]))}", flush=True)
