@@ -58,10 +58,11 @@ __device__ __forceinline__ f32x16 mfma_c_in(bf16x8 a, bf16x8 b, const f32x16& c)
 // The eight K / V^T LDS-DMA loads of a tile pair are issued as one burst behind the barrier.  Spreading them two at a time between the four
 // MFMA groups of the pair's first tile (fenced like gemm4x's groups, where that is worth +5-8 %) changes nothing here: 4.263 / 4.267 / 4.260 ms
 // (profiles/r03_attn_dma.log) - the second workgroup of the CU computes through the first one's burst.
-template <int NW, bool XCD = true>
+template <int NW, bool XCD = true, bool FIXED = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
-                                                          long long N, long long Npad, long long ldo, int qblocks) {
+                                                          long long N, long long Npad, long long ldo, int qblocks,
+                                                          const float* __restrict__ bound = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384, VOFF = 8192;
   constexpr float THR = 6.0f;                    // rescale when a score exceeds the running max by 2^6
@@ -92,6 +93,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   float m = 0.f, lsum = 0.f;                     // m becomes a real maximum on the first tile
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  // FIXED (compile time, experiment) / fixed (run time): the caller bounds every score of this head (|q . k| <= max |q| max |k|, squared
+  // norms from dove_qkv_post_bf16): a constant shift rides in the C operand and the loop needs no running maximum at all - the constant
+  // cancels in O / l.  Bounds above 60 (exp2 would leave the normal range for anti-aligned rows) fall back to the running maximum.
+  bool fixed = FIXED;
+  if (bound) {
+    const float b = FIXED ? bound[h] : 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);   // [head][q, k]: max squared row norms
+    fixed = FIXED || b <= 60.0f;
+    if (fixed) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -b;
+    }
+  }
+  fixed = __builtin_amdgcn_readfirstlane(fixed);
 
   const int ntiles = (int)((N + 63) / 64);
   const int srow = tid >> 3;
@@ -126,8 +140,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     for (int c = 0; c < 4; ++c) koff[b][c] = row * 128 + (((c * 2 + hi) ^ sw) << 4);
   }
 
-  auto compute = [&](auto bufc, int tile) {
+  auto compute = [&](auto bufc, int tile, auto fixc) {
     constexpr int BUF = decltype(bufc)::value;
+    constexpr bool kFixed = decltype(fixc)::value;   // no running maximum: the constant shift is already in negm
     // ---- (S - m)^T[kv][q] = K Q^T - m : the shift rides in the C operand of the first MFMA of each chain ----
     f32x16 st[2];
 #pragma unroll
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
         }
     }
     // ---- lazy online softmax (base 2; Q carries scale*log2e) ----
+    if (!kFixed) {
     float mt = st[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -169,6 +185,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
       for (int r = 0; r < 16; ++r) {
         o[0][r] *= alpha; o[1][r] *= alpha; st[0][r] -= delta; st[1][r] -= delta; negm[r] = -m;
       }
+    }
     }
     float ps = 0.f;
 #pragma unroll
@@ -214,21 +231,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   using B3 = std::integral_constant<int, 3>;
   stage(B0{}, 0);
   if (1 < ntiles) stage(B1{}, 1);
-  for (int it = 0; it < ntiles; it += 4) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 2 < ntiles) stage(B2{}, it + 2);
-    if (it + 3 < ntiles) stage(B3{}, it + 3);
-    compute(B0{}, it);
-    if (it + 1 < ntiles) compute(B1{}, it + 1);
-    if (it + 2 >= ntiles) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 4 < ntiles) stage(B0{}, it + 4);
-    if (it + 5 < ntiles) stage(B1{}, it + 5);
-    compute(B2{}, it + 2);
-    if (it + 3 < ntiles) compute(B3{}, it + 3);
+  // the tile loop exists twice - with and without the running maximum - so that neither copy carries the other's branch
+#define DOVE_ATTN_LOOP(FX)                                                  \
+  for (int it = 0; it < ntiles; it += 4) {                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                        \
+    if (it + 2 < ntiles) stage(B2{}, it + 2);                               \
+    if (it + 3 < ntiles) stage(B3{}, it + 3);                               \
+    compute(B0{}, it, FX{});                                                \
+    if (it + 1 < ntiles) compute(B1{}, it + 1, FX{});                       \
+    if (it + 2 >= ntiles) break;                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                        \
+    if (it + 4 < ntiles) stage(B0{}, it + 4);                               \
+    if (it + 5 < ntiles) stage(B1{}, it + 5);                               \
+    compute(B2{}, it + 2, FX{});                                            \
+    if (it + 3 < ntiles) compute(B3{}, it + 3, FX{});                       \
   }
+  if (fixed) { DOVE_ATTN_LOOP(std::true_type) } else { DOVE_ATTN_LOOP(std::false_type) }
+#undef DOVE_ATTN_LOOP
 
   const float l = lsum + __shfl_xor(lsum, 32);
   const float inv = 1.0f / l;
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 }
 
 extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N,
-                                        long long Npad, int heads, int head_dim, long long ldo, void* stream) {
+                                        long long Npad, int heads, int head_dim, long long ldo, const float* norm2, void* stream) {
   DOVE_CHECK_ARG(Qh && Kh && Vt && O, "attention_fwd: null pointer");
   DOVE_CHECK_ARG(head_dim == 64, "attention_fwd: head_dim must be 64 (got %d)", head_dim);
   DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128, "attention_fwd: Npad must be N rounded up to 128");
@@ -263,8 +284,11 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   }
   const int qblocks = (int)((Npad + NW * 32 - 1) / (NW * 32));
   DOVE_CHECK_ARG((long long)qblocks * heads < (1ll << 31), "attention_fwd: grid too large");
+#ifdef DOVE_TIMING_BUILD
+  { const char* e = getenv("DOVE_ATTN_BOUND"); if (e && atoi(e) == 0) norm2 = nullptr; }   // tools/e2e_env_ab.py: running maximum vs bound
+#endif
   hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), dim3((unsigned)(qblocks * heads)), dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
-                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks);
+                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
 }
@@ -281,8 +305,16 @@ extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const 
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
-  const int w = nw == 14 ? 4 : nw;
+  static float* fixed_bound = nullptr;           // experiment (nw = 44 / 54): a constant score bound for every head
+  if (!fixed_bound) {
+    float hb[256];
+    for (int i = 0; i < 256; ++i) hb[i] = 24.0f;   // 44: the bound itself; 54 (run-time path): sqrt(24 * 24) * 1.01
+    (void)hipMalloc((void**)&fixed_bound, sizeof(hb));
+    (void)hipMemcpy(fixed_bound, hb, sizeof(hb), hipMemcpyHostToDevice);
+  }
+  const int w = nw >= 14 ? 4 : nw;
   const int qblocks = (int)((Npad + w * 32 - 1) / (w * 32));
   dim3 grid((unsigned)qblocks, heads);
   hipStream_t s = (hipStream_t)stream;
@@ -291,6 +323,8 @@ extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const 
   else if (nw == 6) hipLaunchKernelGGL((attn_fwd_kernel<6, false>), grid, dim3(384), LDS, s, ATTN_ARGS);
   else if (nw == 8) hipLaunchKernelGGL((attn_fwd_kernel<8, false>), grid, dim3(512), LDS, s, ATTN_ARGS);
   else if (nw == 14) hipLaunchKernelGGL((attn_fwd_kernel<4, true>), dim3((unsigned)(qblocks * heads)), dim3(256), LDS, s, ATTN_ARGS);
+  else if (nw == 44) hipLaunchKernelGGL((attn_fwd_kernel<4, true, true>), dim3((unsigned)(qblocks * heads)), dim3(256), LDS, s, ATTN_ARGS, fixed_bound);
+  else if (nw == 54) hipLaunchKernelGGL((attn_fwd_kernel<4, true>), dim3((unsigned)(qblocks * heads)), dim3(256), LDS, s, ATTN_ARGS, fixed_bound);
   else return -1;
 #undef ATTN_ARGS
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16_nw");

@@ -1287,6 +1287,8 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
   o = ConvOpt(); o.out = hs + (size_t)L * D; CHK(linear(c, tok, nv, c->pe_proj, o, &dummy, stream));
   c->arena.release(tok);
   const float qscale = (1.0f / sqrtf((float)cf.dit_head_dim)) * 1.4426950408889634f;
+  float* norm2 = (float*)c->arena.alloc((size_t)Hh * 2 * sizeof(float));   // per-head score bound, dove_qkv_post_bf16 -> dove_attention_fwd_bf16
+  DOVE_CHECK_ARG(norm2, "workspace exhausted (attention score bounds)");
   if (c->opt_attn_mx && c->attn8_n != N) {                      // e4m3 operands of dove_attention_fwd_mxfp8 (every padded row is rewritten per call)
     if (c->Q8) { (void)hipFree(c->Q8); (void)hipFree(c->K8); (void)hipFree(c->V8); (void)hipFree(c->Vs8); }
     const size_t b8 = (size_t)Hh * npad * 64;
@@ -1319,9 +1321,9 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
       c->arena.release(qkv);
       CHK(dove_attention_fwd_mxfp8(c->Q8, c->K8, c->V8, c->Vs8, n1, N, npad, Hh, 64, D, stream));
     } else {
-      CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, /*v_order=*/1, stream));
+      CHK(dove_qkv_post_bf16(qkv, N, npad, Hh, 64, L, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cosp, sinp, qscale, 1e-6f, c->Qh, c->Kh, c->Vt, /*v_order=*/1, norm2, stream));
       c->arena.release(qkv);
-      CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, stream));      // attention output reuses n1
+      CHK(dove_attention_fwd_bf16(c->Qh, c->Kh, c->Vt, n1, N, npad, Hh, 64, D, norm2, stream));      // attention output reuses n1
     }
     o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g1; o.gate_split = L; o.out = hs;
     CHK(big(n1, b.out, b.out8, o, &dummy));
@@ -1341,7 +1343,7 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
   bf16_t* po;
   CHK(linear(c, n1, nv, c->proj_out, ConvOpt(), &po, stream));
   CHK(dove_unpatchify(po, c->proj_out.cout_store(), T, cf.dit_out_channels, h, w, pt, p, v_out, out_dtype, stream));
-  c->arena.release(po); c->arena.release(a1); c->arena.release(n1); c->arena.release(hs);
+  c->arena.release(po); c->arena.release(a1); c->arena.release(n1); c->arena.release(hs); c->arena.release(norm2);
   return DOVE_OK;
 }
 

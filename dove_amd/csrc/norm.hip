@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__
                                                       const float* __restrict__ gq, const float* __restrict__ bq,
                                                       const float* __restrict__ gk, const float* __restrict__ bk,
                                                       const float* __restrict__ cosT, const float* __restrict__ sinT, float qscale, float eps,
-                                                      bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh) {
+                                                      bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh, float* __restrict__ norm2) {
+  __shared__ float smax[4][QK_HB];
   const int c = threadIdx.x & 7;                               // 8-value chunk of the 64-vector
   const int h0 = blockIdx.y * QK_HB, which = blockIdx.z;       // 0 q, 1 k
   const long long n = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -476,7 +477,27 @@ __global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] *= sc;
-    if (live && h0 + j < heads) *(uint4*)(dst + (long long)(h0 + j) * Npad * 64) = pack8(f);
+    const uint4 packed = pack8(f);
+    if (live && h0 + j < heads) *(uint4*)(dst + (long long)(h0 + j) * Npad * 64) = packed;
+    if (norm2) {
+      // squared norm of the STORED (bf16-rounded, scaled, rotated) row: what bounds the attention scores of this head (dove_attention_fwd_bf16)
+      float r[8];
+      unpack8(packed, r);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q += r[e] * r[e];
+      q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);          // the row (8 lanes)
+      q = fmaxf(q, __shfl_xor(q, 8)); q = fmaxf(q, __shfl_xor(q, 16)); q = fmaxf(q, __shfl_xor(q, 32));   // the wave's 8 rows
+      if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6][j] = q;
+    }
+  }
+  if (norm2) {                                                 // one atomic per workgroup, head and operand (dead rows repeat row N - 1)
+    __syncthreads();
+    const int j = threadIdx.x;
+    if (j < QK_HB && h0 + j < heads) {
+      const float q = fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]));
+      atomicMax((unsigned*)(norm2 + (h0 + j) * 2 + which), __float_as_uint(q));     // non-negative floats order like their bit patterns
+    }
   }
 }
 
@@ -526,7 +547,7 @@ __global__ __launch_bounds__(256) void v_post_kernel(const bf16_t* __restrict__ 
 extern "C" int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
                                    const float* gq, const float* bq, const float* gk, const float* bk,
                                    const float* cosT, const float* sinT, float qscale, float eps, void* Qh, void* Kh,
-                                   void* Vt, int v_order, void* stream) {
+                                   void* Vt, int v_order, float* norm2, void* stream) {
   DOVE_CHECK_ARG(qkv && Qh && Kh && Vt && gq && bq && gk && bk, "qkv_post: null pointer");
   DOVE_CHECK_ARG(head_dim == 64, "qkv_post: head_dim must be 64 (got %d)", head_dim);
   // Npad is only the row stride of the head-major outputs here (the attention kernel is what wants a multiple of 128);
@@ -534,8 +555,12 @@ extern "C" int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, 
   DOVE_CHECK_ARG(N > 0 && Npad >= N, "qkv_post: Npad must be >= N");
   DOVE_CHECK_ARG((cosT == nullptr) == (sinT == nullptr), "qkv_post: cos/sin must both be given or both be null");
   DOVE_CHECK_ARG(v_order == 0 || (v_order == 1 && Npad % 16 == 0), "qkv_post: v_order 1 (quad-swapped V^T) needs Npad %% 16 == 0");
+  if (norm2) {
+    const hipError_t me = hipMemsetAsync(norm2, 0, sizeof(float) * 2 * heads, (hipStream_t)stream);
+    if (me != hipSuccess) { dove_set_error("qkv_post: clearing norm2 failed: %s", hipGetErrorString(me)); return DOVE_ELAUNCH; }
+  }
   hipLaunchKernelGGL(qk_post_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((heads + QK_HB - 1) / QK_HB), 2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
-                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh);
+                     text_len, gq, bq, gk, bk, cosT, sinT, qscale, eps, (bf16_t*)Qh, (bf16_t*)Kh, norm2);
   hipLaunchKernelGGL(v_post_kernel, dim3((unsigned)((N + 255) / 256), heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, N, Npad, heads,
                      (bf16_t*)Vt, v_order);
   DOVE_CHECK_LAUNCH("dove_qkv_post_bf16");

@@ -118,6 +118,16 @@ def _all_to_all(out, inp, out_splits, in_splits, group):
     out.copy_(h)
 
 
+def _all_reduce_max(t, group):
+    """In place element-wise maximum of a small fp32 tensor over the group (exact: every rank ends with the same bits)."""
+    if _direct(group) or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return
+    h = t.cpu()
+    dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
+    t.copy_(h)
+
+
 def _broadcast(t, src, group):
     """In place on ``t`` (contiguous)."""
     if _direct(group) or not t.is_cuda:
@@ -563,6 +573,10 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     att = e(N, hloc * 64)
     back = e(nloc * hloc * 64 * world)
     att_loc = e(nloc, D)
+    # per-head score bound of the attention kernel (max squared q / k row norms): every rank takes the maximum over ITS rows of all heads,
+    # the element-wise maximum over the ranks is what one GPU computes over all rows (bit for bit), and my heads' slice goes to the kernel
+    norm2 = torch.empty(heads, 2, dtype=torch.float32, device=dev)
+    h0 = dist.get_rank(group) * hloc
 
     def a2a(out, inp, out_splits, in_splits):
         _all_to_all(out, inp, out_splits, in_splits, group)
@@ -571,14 +585,15 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
         n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], tr.eps, md["m1"], lt_loc)
         qkv = ops.linear(n1, blk["qkv"])
         ops.qkv_post(qkv, nloc, nloc, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
-                     qscale, 1e-6, Ql, Kl, Vl, v_order=0)        # natural key order: the pieces are assembled below
+                     qscale, 1e-6, Ql, Kl, Vl, v_order=0, norm2=norm2)   # natural key order: the pieces are assembled below
+        _all_reduce_max(norm2, group)
         a2a(rq, Ql.view(-1), blk_in, blk_out)
         a2a(rk, Kl.view(-1), blk_in, blk_out)
         a2a(rv, Vl.view(-1), blk_in, blk_out)
         # [source rank][hloc][rows of that rank][64] (V^T: [hloc][64][rows]) -> the kernel's [hloc][all rows][64] / quad-swapped
         # [hloc][64][all rows] with zero pad columns: ONE launch (was 3 x world slice copies + a pad clear + an in-place swap)
         ops.ulysses_place(rq, rk, rv, counts, hloc, N, npad, Qh, Kh, Vt)
-        ops.attention(Qh, Kh, Vt, N, npad, hloc, att)
+        ops.attention(Qh, Kh, Vt, N, npad, hloc, att, norm2=norm2[h0:h0 + hloc])
         # heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
         a2a(back, att.view(-1), blk_out, blk_in)
         # [source rank = head group][my rows][hloc*64] -> [my rows][all heads]: one strided copy

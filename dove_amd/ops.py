@@ -276,12 +276,15 @@ def layernorm_modulate(x, gamma, beta, eps, mod=None, split=0, out=None):
     return out
 
 
-def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1):
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1, norm2=None):
     """``v_order=1``: V^T rows in the quad-swapped key order ``attention`` reads (include/dove_hip.h); 0 = natural (pieces that
-    are assembled later and converted with ``vt_quad_swap``)."""
-    L.require_cuda(qkv, gq, bq, gk, bk, cos, sin, Qh, Kh, Vt)
+    are assembled later and converted with ``vt_quad_swap``).  ``norm2`` (fp32 [heads, 2], optional): receives the max squared row
+    norms of the stored q / k rows per head - the score bound ``attention`` can use instead of a running maximum."""
+    L.require_cuda(qkv, gq, bq, gk, bk, cos, sin, Qh, Kh, Vt, norm2)
+    if norm2 is not None:
+        assert norm2.dtype == torch.float32 and norm2.shape == (heads, 2) and norm2.is_contiguous()
     L.check(L.load().dove_qkv_post_bf16(L.ptr(qkv), N, Npad, heads, 64, text_len, L.ptr(gq), L.ptr(bq), L.ptr(gk), L.ptr(bk),
-                                        L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), v_order,
+                                        L.ptr(cos), L.ptr(sin), qscale, eps, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), v_order, L.ptr(norm2),
                                         L.stream_ptr()), "dove_qkv_post_bf16")
 
 
@@ -302,9 +305,12 @@ def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
                                              L.stream_ptr()), "dove_ulysses_place_bf16")
 
 
-def attention(Qh, Kh, Vt, N, Npad, heads, out):
-    L.require_cuda(Qh, Kh, Vt, out)
-    L.check(L.load().dove_attention_fwd_bf16(L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), L.ptr(out), N, Npad, heads, 64, out.shape[1],
+def attention(Qh, Kh, Vt, N, Npad, heads, out, norm2=None):
+    """``norm2`` (fp32 [heads, 2] of THESE heads, from ``qkv_post``): constant-shift softmax instead of the running maximum."""
+    L.require_cuda(Qh, Kh, Vt, out, norm2)
+    if norm2 is not None:
+        assert norm2.dtype == torch.float32 and norm2.shape == (heads, 2) and norm2.is_contiguous()
+    L.check(L.load().dove_attention_fwd_bf16(L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), L.ptr(out), N, Npad, heads, 64, out.shape[1], L.ptr(norm2),
                                              L.stream_ptr()), "dove_attention_fwd_bf16")
     return out
 

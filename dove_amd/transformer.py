@@ -207,6 +207,7 @@ class CogVideoXTransformer3DModel:
         N = Lt + nv
         blocks_mod, final_mod = self._modulation(t)
         npad, Qh, Kh, Vt, Vs = self._buffers(N)
+        norm2 = torch.empty(Lh, 2, dtype=torch.float32, device=self.device)     # per-head score bound, qkv_post -> attention
 
         hs = torch.empty(N, D, dtype=torch.bfloat16, device=self.device)
         tok = ops.patchify(hidden, pt, p, self.pe_proj.cin_pad)
@@ -228,8 +229,8 @@ class CogVideoXTransformer3DModel:
                 att = ops.attention_mx(Qh, Kh, Vt, Vs, N, npad, Lh, n1)
             else:
                 ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
-                             1e-6, Qh, Kh, Vt)
-                att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1)      # reuse n1's storage for the attention output
+                             1e-6, Qh, Kh, Vt, norm2=norm2)
+                att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1, norm2=norm2)   # reuse n1's storage for the attention output
             big(att, blk["out"], resid=hs, gate=md["gate1"], gate_split=Lt, out=hs)
             n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
             f1 = big(n2, blk["ff1"], act=1)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 10
+#define DOVE_ABI_VERSION 11
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -119,9 +119,13 @@ int dove_layernorm_modulate_bf16(const void* x, void* y, long long rows, int D, 
  * 16 consecutive keys are stored [0-3, 8-11, 4-7, 12-15] - the order in which the QK^T MFMA leaves the probabilities in a lane,
  * so that P needs no cross-lane exchange before the PV MFMA.  dove_vt_quad_swap_bf16 converts rows [rows][Npad] between the two
  * orders in place (an involution; for hosts that assemble Vt from natural-order pieces, e.g. after an all-to-all). */
+/* norm2 (may be NULL): float [heads][2], receives max over the N rows of |q row|^2 and |k row|^2 of every head, taken from the STORED
+ * (bf16-rounded, rotated, scaled) values - what dove_attention_fwd_bf16 needs to bound its scores.  The array is cleared and filled
+ * on the stream; a host that shards the rows takes the element-wise maximum of the ranks' arrays (exact, so the sharded result
+ * stays bit-identical). */
 int dove_qkv_post_bf16(const void* qkv, long long N, long long Npad, int heads, int head_dim, int text_len,
                        const float* gq, const float* bq, const float* gk, const float* bk, const float* cosT,
-                       const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, int v_order, void* stream);
+                       const float* sinT, float qscale, float eps, void* Qh, void* Kh, void* Vt, int v_order, float* norm2, void* stream);
 int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, void* stream);
 /* Receive side of the Q' / K' / V^T all-to-all of the sequence/head-parallel DiT (dove_amd.dist; not in the reference: one clip over
  * several GPUs): rq, rk = per source rank i the block [hloc][counts[i]][64], rv = [hloc][64][counts[i]] (natural key order), blocks in
@@ -131,9 +135,13 @@ int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, cons
                             long long Npad, void* Qh, void* Kh, void* Vt, void* stream);
 
 /* F.scaled_dot_product_attention (no mask, non-causal) on the operands above, Vt in QUAD-SWAPPED key order; Qh carries
- * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64). */
+ * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64).
+ * norm2 (may be NULL): float [heads][2] = max squared row norms of this call's Qh / Kh heads (dove_qkv_post_bf16).  With it, every
+ * score of head h is bounded by b = 1.01 sqrt(norm2[h][0] norm2[h][1]) (Cauchy-Schwarz) and the softmax runs with that constant shift
+ * instead of a running maximum (the constant cancels in O / l): -7 % kernel time.  Heads with b > 60 - where exp2 could leave the
+ * normal fp32 range for anti-aligned rows - and calls with norm2 == NULL use the running maximum. */
 int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
-                            int heads, int head_dim, long long ldo, void* stream);
+                            int heads, int head_dim, long long ldo, const float* norm2, void* stream);
 
 /* layout glue at the [B,C,T,H,W] boundary (B = 1) */
 int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, float scale, float shift, void* y,

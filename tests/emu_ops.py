@@ -228,7 +228,7 @@ def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
     vt_quad_swap(Vt)
 
 
-def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1):
+def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Qh, Kh, Vt, v_order=1, norm2=None):
     D = heads * 64
     q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, heads, 64) for i in range(3))
     q = F.layer_norm(q, (64,), gq.float(), bq.float(), eps)
@@ -245,14 +245,18 @@ def qkv_post(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, ep
     Qh[:, :N] = (q * qscale).permute(1, 0, 2).to(BF)
     Kh[:, :N] = k.permute(1, 0, 2).to(BF)
     Vt[:, :, :N] = v.permute(1, 2, 0).to(BF)
+    if norm2 is not None:                                               # max squared norms of the STORED rows (include/dove_hip.h)
+        norm2[:, 0] = (Qh[:, :N].float() ** 2).sum(-1).amax(-1)
+        norm2[:, 1] = (Kh[:, :N].float() ** 2).sum(-1).amax(-1)
     if v_order == 1:
         assert Vt.shape[-1] % 16 == 0
         Vt[:, :, N:] = 0                                                # the swap moves tail keys into [N, Npad): keep the pad defined
         vt_quad_swap(Vt)
 
 
-def attention(Qh, Kh, Vt, N, Npad, heads, out):
-    """Vt in the quad-swapped key order (dove_attention_fwd_bf16's contract)."""
+def attention(Qh, Kh, Vt, N, Npad, heads, out, norm2=None):
+    """Vt in the quad-swapped key order (dove_attention_fwd_bf16's contract).  ``norm2`` only selects HOW the kernel shifts its softmax;
+    the exact softmax below is the reference for both ways."""
     q, k, v = Qh.float()[:, :N], Kh.float()[:, :N], Vt.float()[:, :, _quad_swap_index(Vt.shape[-1])][:, :, :N]
     s = torch.einsum("hqd,hkd->hqk", q, k) * math.log(2.0)       # Qh carries scale*log2(e)
     p = torch.softmax(s, dim=-1)

@@ -287,17 +287,27 @@ def test_qkv_post_and_attention(N, heads, text_len):
     Qr, Kr, Vr = z(heads, npad, 64), z(heads, npad, 64), z(heads, 64, npad)
     E.qkv_post(qkv, N, npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, 1e-6, Qr, Kr, Vr)
     Qg, Kg, Vg = z(heads, npad, 64).cuda(), z(heads, npad, 64).cuda(), z(heads, 64, npad).cuda()
+    n2 = torch.full((heads, 2), -1.0, device="cuda")             # stale contents: the call clears the array itself
     ops.qkv_post(qkv.cuda(), N, npad, heads, text_len, gq.cuda(), bq.cuda(), gk.cuda(), bk.cuda(), cos.cuda(), sin.cuda(),
-                 qscale, 1e-6, Qg, Kg, Vg)
+                 qscale, 1e-6, Qg, Kg, Vg, norm2=n2)
     torch.cuda.synchronize()
     close("qkv_post.Q", Qg, Qr)
     close("qkv_post.K", Kg, Kr)
     close("qkv_post.Vt", Vg, Vr)
+    # the score bound: max squared norms of the rows the kernel STORED (fp32 sums of bf16 squares; only the summation order differs)
+    want = torch.stack([(Qg[:, :N].float() ** 2).sum(-1).amax(-1), (Kg[:, :N].float() ** 2).sum(-1).amax(-1)], dim=1)
+    assert torch.allclose(n2, want, rtol=1e-5, atol=0), (n2, want)
     ref = E.attention(Qr, Kr, Vr, N, npad, heads, torch.zeros(N, D, dtype=BF))
     got = ops.attention(Qr.cuda(), Kr.cuda(), Vr.cuda(), N, npad, heads, torch.zeros(N, D, dtype=BF, device="cuda"))
     torch.cuda.synchronize()
     # P is rounded to bf16 before PV in the kernel (flash attention): allow 2 ulp
     close(f"attention_{N}_{heads}", got, ref, rtol=3e-2, afrac=8e-3)
+    # the same product with the constant shift from the bound instead of the running maximum (what the DiT runs)
+    nr = torch.stack([(Qr[:, :N].float() ** 2).sum(-1).amax(-1), (Kr[:, :N].float() ** 2).sum(-1).amax(-1)], dim=1).cuda().contiguous()
+    assert float(1.01 * (nr[:, 0] * nr[:, 1]).sqrt().max()) < 60.0
+    got2 = ops.attention(Qr.cuda(), Kr.cuda(), Vr.cuda(), N, npad, heads, torch.zeros(N, D, dtype=BF, device="cuda"), norm2=nr)
+    torch.cuda.synchronize()
+    close(f"attention_bound_{N}_{heads}", got2, ref, rtol=3e-2, afrac=8e-3)
 
 
 @pytest.mark.parametrize("counts,hloc", [([37, 36, 40], 2), ([300], 3), ([1, 0, 130, 61], 1), ([2279, 2278, 2278, 2278, 2278, 2278, 2279, 2278], 6)])
@@ -436,6 +446,46 @@ def test_attention_spiked_rows():
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
     torch.cuda.synchronize()
     close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
+    # with the score bound: the spikes push it far above 60, so these heads must take the running-maximum path by themselves
+    n2 = _norm2(Q, K, N).cuda()
+    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().min()) > 60.0
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    torch.cuda.synchronize()
+    close("attention_spike_bound_fallback", got, ref, rtol=3e-2, afrac=8e-3)
+
+
+def _norm2(Q, K, N):
+    return torch.stack([(Q[:, :N].float() ** 2).sum(-1).amax(-1), (K[:, :N].float() ** 2).sum(-1).amax(-1)], dim=1).contiguous()
+
+
+def test_attention_loose_bound():
+    """Constant-shift softmax with a bound far above every real score: one long query row and one long key row that are orthogonal put
+    the Cauchy-Schwarz bound at ~50 (in base-2 exponent units) while the scores stay within +-3 - every probability is then ~2^-47
+    before the normalisation, which must not cost precision (fp32 range, bf16 keeps its 8 relative bits)."""
+    N, heads = 700, 2
+    npad = 768
+    g = torch.Generator().manual_seed(23)
+    Q = torch.zeros(heads, npad, 64, dtype=BF)
+    K = torch.zeros(heads, npad, 64, dtype=BF)
+    V = torch.zeros(heads, 64, npad, dtype=BF)
+    q = torch.randn(heads, N, 64, generator=g) * 0.3
+    k = torch.randn(heads, N, 64, generator=g) * 0.3
+    q[:, 11] = 0
+    q[:, 11, 0] = 7.0
+    k[:, :, 0] = 0                                  # nothing answers the long query
+    k[:, 500] = 0
+    k[:, 500, 1] = 7.0
+    q[:, :, 1] = 0                                  # and nothing asks for the long key
+    Q[:, :N], K[:, :N] = q.to(BF), k.to(BF)
+    V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
+    E.vt_quad_swap(V)
+    n2 = _norm2(Q, K, N).cuda()
+    b = 1.01 * (n2[:, 0] * n2[:, 1]).sqrt()
+    assert 45.0 < float(b.min()) and float(b.max()) < 60.0, b
+    ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    torch.cuda.synchronize()
+    close("attention_loose_bound", got, ref, rtol=3e-2, afrac=8e-3)
 
 
 @pytest.mark.parametrize("cin,cout,k,T,H,W,up,resid", [
@@ -795,7 +845,7 @@ def test_prodshape_attention_18226_sampled():
     npad = (N + 127) // 128 * 128
     g = torch.Generator().manual_seed(131)
     q = (torch.randn(heads, N, 64, generator=g) * 0.5).to(BF)          # Qh carries scale * log2(e): scores ~ N(0, 4) in base 2
-    k = torch.randn(heads, N, 64, generator=g).to(BF)
+    k = (torch.randn(heads, N, 64, generator=g) * 0.7).to(BF)          # |q| |k| stays below the 60 above which the bound is not used
     v = torch.randn(heads, 64, N, generator=g).to(BF)
     Q = torch.zeros(heads, npad, 64, dtype=BF)
     K = torch.zeros(heads, npad, 64, dtype=BF)
@@ -808,6 +858,11 @@ def test_prodshape_attention_18226_sampled():
     p = torch.softmax(torch.einsum("hqd,hkd->hqk", q.float()[:, rows], k.float()) * math.log(2.0), dim=-1)
     ref = torch.einsum("hqk,hdk->hqd", p, v.float()).permute(1, 0, 2).reshape(len(rows), heads * 64).to(BF)
     close("prod_attention_18226", got[rows.cuda()], ref, rtol=3e-2, afrac=8e-3)
+    n2 = _norm2(Q, K, N).cuda()
+    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().max()) < 60.0
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    torch.cuda.synchronize()
+    close("prod_attention_18226_bound", got[rows.cuda()], ref, rtol=3e-2, afrac=8e-3)
 
 
 def test_prodshape_attention_mx_18226_sampled():

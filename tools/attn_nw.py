@@ -21,7 +21,9 @@ V = torch.zeros(H, 64, npad, dtype=torch.bfloat16, device="cuda")
 Q[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 0.18 * 1.6).to(torch.bfloat16)
 K[:, :N] = (torch.randn(H, N, 64, device="cuda", generator=g) * 1.6).to(torch.bfloat16)
 V[:, :, :N] = torch.randn(H, 64, N, device="cuda", generator=g).to(torch.bfloat16)
-outs = {nw: torch.zeros(N, H * 64, dtype=torch.bfloat16, device="cuda") for nw in (4, 14, 8)}     # 14 = 4 waves, XCD-contiguous 1-D grid
+# 14 = 4 waves, XCD-contiguous 1-D grid (the product); 44 = 14 with a constant per-head score bound instead of the running maximum
+CODES = tuple(int(a) for a in sys.argv[1:]) or (4, 14, 8)
+outs = {nw: torch.zeros(N, H * 64, dtype=torch.bfloat16, device="cuda") for nw in CODES}
 t = {nw: [] for nw in outs}
 for rnd in range(5):
     for nw, o in outs.items():
@@ -37,7 +39,10 @@ for rnd in range(5):
 fl = 4.0 * N * N * 64 * H
 for nw in outs:
     ms = statistics.median(t[nw])
-    print(f"NW={nw}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s   equal to NW=4: {bool(torch.equal(outs[nw], outs[4]))}", flush=True)
+    d = (outs[nw].float() - outs[CODES[0]].float()).abs().max().item()
+    print(f"NW={nw}: {ms:.3f} ms  {fl / ms / 1e9:7.1f} TFLOP/s   equal to NW={CODES[0]}: {bool(torch.equal(outs[nw], outs[CODES[0]]))} (max abs diff {d:.3g}, max |out| {outs[nw].float().abs().max().item():.3g})", flush=True)
+if len(sys.argv) > 1:
+    sys.exit(0)
 
 # ---- MXFP8 attention, same question ----
 from dove_amd import ops  # noqa: E402
