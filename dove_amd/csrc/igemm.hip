@@ -659,7 +659,7 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // (Round 3 tried two other placements of a step's 2-4 LDS-DMA instructions - spread by sched_group_barrier: -4 %, the compiler also
 // re-clusters the fragment reads; four sched_barrier-fenced quarters of {<= 1 DMA, 4 reads, 8 MFMAs}: +-0.3 % - profiles/r03_halo4x_dma.log.
 // Unlike gemm4x's eight DMAs per step, two to four do not back up the CU's address path; the pinned order below stays.)
-template <bool kUp, bool kTiming>
+template <bool kUp, bool kTiming, bool kPipe = true>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = Halo4xCfg;
@@ -920,6 +920,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int q2 = 0; q2 < 2; ++q2) { gs[h][q2] = f32x2{0.f, 0.f}; gq[h][q2] = f32x2{0.f, 0.f}; }
+        auto wr = [&](int p, int h) {                          // accumulators of tile row p, channel half h -> the wave's slice (fp32)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+              f32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = acc[h * 2 + i2][p][gq * 4 + e];
+              *(f32x4*)(eslice + l31 * EROW + (i2 * 32 + 8 * gq + 4 * hi) * 4) = o;
+            }
+        };
+        if (kPipe) wr(0, 0);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int oh = c.oh0 + 4 * wave + p;
@@ -936,15 +948,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
               for (int it = 0; it < 4; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 128, 0);
             }
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-              for (int gq = 0; gq < 4; ++gq) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[h * 2 + i2][p][gq * 4 + e];
-                *(f32x4*)(eslice + l31 * EROW + (i2 * 32 + 8 * gq + 4 * hi) * 4) = o;
-              }
+            if (!kPipe) wr(p, h);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
             f32x4 lo[4], hi4[4];
 #pragma unroll
@@ -953,6 +957,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
               hi4[it] = *(const f32x4*)(eslice + (it * 8 + e_px) * EROW + e_ch * 32 + 16);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the next block's accumulators go into the slice NOW: its reads above are complete, and the write latency then runs under
+            // this block's bias / residual / statistics arithmetic and stores instead of in front of the next block's reads
+            if (kPipe && (p < 3 || h < 1)) wr(h ? p + 1 : p, h ^ 1);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
@@ -2079,6 +2086,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/halo4x_timing.py
         a.gate = (const float*)DOVE_DBG_BUF;
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      } else
+#endif
+#ifdef DOVE_TIMING_BUILD
+      if ((a.debug & 64) && kern == K_HALO4X) {                  // tools/e2e_env_ab.py DOVE_IGEMM_ABLATE 64 0: epilogue without the early slice write
+        static PerDeviceOnce attrp;
+        if (attrp.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
