@@ -69,3 +69,48 @@ def test_asm_mfma_feeds_only_the_chained_mfma(src, tmp_path):
         else:
             raise AssertionError(f"asm MFMA at line {i}: no consumer found")
     assert n_asm >= 4, f"expected the asm MFMAs of the S chains, found {n_asm}"
+
+
+def _kernel_body(lines, mangled_prefix):
+    """Lines of the first kernel whose label starts with `mangled_prefix`, up to its s_endpgm."""
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled_prefix + ":"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start:end + 1]
+
+
+def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(tmp_path):
+    """gemm8p stages its operands one K-64 step ahead by LDS-DMA and waits for them with hand-placed `s_waitcnt vmcnt(0)` at the two
+    places the ring argument needs (igemm.hip: end of LOAD / MFMA of the odd phases).  hipcc's own wait insertion knows nothing about
+    those asm waits: when the epilogue's VGPR loads looked pending to it at the K loop's header, it put `s_waitcnt vmcnt(1)` /
+    `vmcnt(0)` in front of the first fragment reads of every 128-deep chunk and drained the stream there (round 3; fixed by ending the
+    epilogue with the `s_waitcnt` BUILTIN, which its tracking sees).  Pinned here: inside the K walk every vmcnt wait sits in an asm
+    block, each phase has its 12 fragment reads and 16 MFMAs, and the kernel uses no scratch."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "g.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-result",
+                           os.path.join(ROOT, "dove_amd", "csrc", "igemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    lines = text.split("\n")
+    for variant in ("ILb0ELb0ELb0E", "ILb1ELb0ELb0E", "ILb0ELb1ELb0E"):          # plain, GELU, gated
+        name = f"_Z13gemm8p_kernel{variant}Ev9IgemmArgsx"
+        m = re.search(rf"\.set {name}\.private_seg_size, (\d+)", text)
+        assert m and int(m.group(1)) == 0, f"{name}: scratch in use"
+        body = _kernel_body(lines, name)
+        # the K walk = the stretch between the first and the last MFMA of the kernel (the epilogue has none)
+        mf = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mf) == 64, f"{name}: expected 4 phases x 16 MFMAs in the unrolled chunk, found {len(mf)}"
+        first_read = next(i for i, l in enumerate(body) if "ds_read_b128" in l)      # the prologue only stages; the epilogue's reads follow the last MFMA
+        walk = body[first_read - 2:mf[-1] + 12]
+        in_asm, bare = False, []
+        for l in walk:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif "s_waitcnt" in l and "vmcnt" in l and not in_asm:
+                bare.append(l.strip())
+        assert not bare, f"{name}: compiler-inserted vmcnt waits inside the K walk would drain the operand stream: {bare}"
+        assert sum("ds_read_b128" in l for l in walk) == 48, f"{name}: 12 fragment reads per phase expected"
+        assert sum("lds" in l and "buffer_load_dwordx4" in l for l in walk) == 16, f"{name}: 8 LDS-DMAs in each of the two even phases expected"
