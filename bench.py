@@ -298,7 +298,7 @@ def main():
         fp8_parts = (["qkv/out/ff linears"] if args.dit_linear == "mxfp8" else []) + (["attention"] if args.dit_attention == "mxfp8" else [])
         headline = not fp8_parts
         res = {
-            "metric": "SR frames/s (33x720x1280 4x one-step, whole job)", "value": value, "unit": "frames/s",
+            "metric": f"SR frames/s ({args.frames}x{args.height}x{args.width} 4x one-step, whole job)", "value": value, "unit": "frames/s",
             "n_gpus": observed_world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if headline else "mxfp8 (DiT " + " + ".join(fp8_parts) + ": e4m3 + E8M0 block scales) + bf16 (everything else)",
@@ -325,6 +325,8 @@ def main():
                                          for k, a in top}},
             "model_build_s": t_build,
         }
+        if (args.frames, args.height, args.width) != (33, 720, 1280):
+            res["note"] = "not BASELINE.json's headline clip size (33x720x1280): a side measurement"
         if args.oversubscribe:
             res["invalid"] = "debug run: all ranks share GPU 0 over gloo (--oversubscribe)"
         if strong:
