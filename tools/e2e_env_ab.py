@@ -1,7 +1,9 @@
 """Whole-operator A/B of a TIMING-build switch on the headline clip: process_video alternately with <VAR> = A and = B (variables the
 timing library reads per call).  Usage: python tools/e2e_env_ab.py <VAR> <A> <B> [rounds]
   DOVE_IGEMM_ABLATE 16 0   gemm8p nontemporal output stores forced off vs the product rule
-  DOVE_GEMM8P 0 1          gemm4x (round 2's GEMM) vs gemm8p"""
+  DOVE_GEMM8P 0 1          gemm4x (round 2's GEMM) vs gemm8p
+  DOVE_ATTN_BOUND 0 1      attention with the running maximum vs the per-head score bound
+  DOVE_IGEMM_ABLATE 64 0   conv3x3_halo4x epilogue without / with the early slice write"""
 import os
 import statistics
 import sys
