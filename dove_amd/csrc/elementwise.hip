@@ -163,13 +163,15 @@ extern "C" int dove_conv_out_gather(const float* p, long long ldp, int T, int H,
 }
 
 // ---- Downsample3D temporal pool: odd T keeps frame 0 and averages pairs (1,2),(3,4)..; even T pairs (0,1).. ----
+__host__ __device__ inline int odd_to(int T) { return (T & 1) ? 1 + (T - 1) / 2 : T / 2; }
 __global__ void avgpool_time_kernel(const bf16_t* __restrict__ x, int T, long long frame8, bf16_t* __restrict__ y) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-element chunk within a frame
   if (i >= frame8) return;
-  const int to = blockIdx.y;
+  const int To = odd_to(T);
+  const int inst = blockIdx.y / To, to = blockIdx.y - inst * To;   // instance of nb (each [T][frame] -> [To][frame], back to back)
   const int odd = T & 1;
-  const uint4* xs = (const uint4*)x;
-  uint4* ys = (uint4*)y;
+  const uint4* xs = (const uint4*)x + (long long)inst * T * frame8;
+  uint4* ys = (uint4*)y + (long long)inst * To * frame8;
   if (odd && to == 0) {
     ys[i] = xs[i];
     return;
@@ -183,15 +185,19 @@ __global__ void avgpool_time_kernel(const bf16_t* __restrict__ x, int T, long lo
   ys[(long long)to * frame8 + i] = pack8(a);
 }
 
-extern "C" int dove_avgpool_time_bf16(const void* x, int T, long long frame_elems, void* y, void* stream) {
+extern "C" int dove_avgpool_time_nb_bf16(const void* x, int nb, int T, long long frame_elems, void* y, void* stream) {
   DOVE_CHECK_ARG(x && y, "avgpool_time: null pointer");
   DOVE_CHECK_ARG(T >= 2 && frame_elems % 8 == 0 && frame_elems > 0, "avgpool_time: need T >= 2 and frame_elems %% 8 == 0");
-  const int To = (T & 1) ? 1 + (T - 1) / 2 : T / 2;
+  const int To = odd_to(T);
+  DOVE_CHECK_ARG(nb >= 1 && (long long)nb * To <= 65535, "avgpool_time: bad instance count %d", nb);
   const long long f8 = frame_elems / 8;
-  hipLaunchKernelGGL(avgpool_time_kernel, dim3((unsigned)((f8 + 255) / 256), To), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(avgpool_time_kernel, dim3((unsigned)((f8 + 255) / 256), nb * To), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, T, f8, (bf16_t*)y);
   DOVE_CHECK_LAUNCH("dove_avgpool_time_bf16");
   return DOVE_OK;
+}
+extern "C" int dove_avgpool_time_bf16(const void* x, int T, long long frame_elems, void* y, void* stream) {
+  return dove_avgpool_time_nb_bf16(x, 1, T, frame_elems, y, stream);
 }
 
 // ---- DiagonalGaussianDistribution: split channels-last moments into [2L,T,h,w] params, and sample ----

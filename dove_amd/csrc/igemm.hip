@@ -65,7 +65,27 @@ struct IgemmArgs {
   int cpg_log;         // log2(channels per group) = log2(Cout / 32)
   int out_f32;         // igemm_fast only: `out` is float [..][ldo] (no bf16 rounding): the tap-split conv_out's partial sums
   int nt_out;          // gemm8p only: nontemporal output stores (outputs larger than the Infinity Cache: see conv_dispatch)
+  // dove_conv_desc.nb independent instances back to back along the frame axis (the tile-batched VAE): T_out / T_in above are the TOTALS
+  // (nb x per-instance), seg_out / seg_in the per-instance frame counts; temporal taps, the conv cache and tmode are per instance
+  int seg_out, seg_in;
+  long long cache_bs;  // elements between two instances' cache frames
 };
+
+// frame of the INPUT a temporal tap reads: output frame t (global index over all instances), tap dt of kt (causal: taps before an
+// instance's first frame come from its conv cache, or replicate its frame 0), or the tmode map of the upsample convs (kt == 1)
+__device__ __forceinline__ const bf16_t* igemm_src_frame(const IgemmArgs& a, int t, int dt, long long frame_elems) {
+  const int b = a.seg_out == a.T_out ? 0 : t / a.seg_out;
+  const int tl = t - b * a.seg_out;
+  const long long f0 = (long long)b * a.seg_in;
+  if (a.kt > 1) {
+    const int fv = tl + dt - (a.kt - 1);
+    if (fv >= 0) return a.x + (f0 + fv) * frame_elems;
+    if (a.cache) return a.cache + (long long)b * a.cache_bs + (long long)(a.kt - 1 + fv) * frame_elems;
+    return a.x + f0 * frame_elems;
+  }
+  const int tin = a.tmode == 0 ? tl : (a.tmode == 1 ? (tl >> 1) : (tl == 0 ? 0 : 1 + ((tl - 1) >> 1)));
+  return a.x + (f0 + tin) * frame_elems;
+}
 
 template <int BN, int BK>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
@@ -117,16 +137,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int dw = tap % a.kw;
     const int dh = (tap / a.kw) % a.kh;
     const int dt = tap / (a.kw * a.kh);
-    const bf16_t* fp;
-    if (a.kt > 1) {
-      const int fv = t + dt - (a.kt - 1);
-      if (fv >= 0) fp = a.x + fv * frame_elems;
-      else if (a.cache) fp = a.cache + (a.kt - 1 + fv) * frame_elems;
-      else fp = a.x;
-    } else {
-      const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-      fp = a.x + tin * frame_elems;
-    }
+    const bf16_t* fp = igemm_src_frame(a, t, dt, frame_elems);
     const int k0 = kc * BK + c * 8;
     char* As = smem + buf * STAGE;
 #pragma unroll
@@ -324,16 +335,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
   const int nk = a.kt * a.kh * a.kw * kc_per_tap;
 
   // ---- scalar K-walk state (the NEXT K-step to stage); everything below lives in SGPRs ----
-  auto frame_ptr = [&](int dt) -> const bf16_t* {
-    if (a.kt > 1) {
-      const int fv = t + dt - (a.kt - 1);
-      if (fv >= 0) return a.x + fv * frame_elems;
-      if (a.cache) return a.cache + (a.kt - 1 + fv) * frame_elems;
-      return a.x;
-    }
-    const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-    return a.x + tin * frame_elems;
-  };
+  auto frame_ptr = [&](int dt) -> const bf16_t* { return igemm_src_frame(a, t, dt, frame_elems); };
   int s_kc = 0, s_dw = 0, s_dh = 0, s_dt = 0;
   const bf16_t* s_fp = frame_ptr(0);
   const bf16_t* s_wp = a.w + (long long)n0 * a.Cin;
@@ -577,7 +579,9 @@ struct H4State {
   unsigned voffA[12];                                         // lane offsets of the 12 halo rounds (spatial tile of nxt)
   int n_tile, n_dt, n_kc, n_oh0, n_ow0;                       // group `nxt`: tile, frame tap, channel chunk
   bool n_on;                                                  // nxt's tile exists (else: zero-length descriptors)
-  int t;                                                      // output frame of nxt's tile
+  int t;                                                      // output frame of nxt's tile WITHIN its instance (dove_conv_desc.nb)
+  long long f0;                                               // first input frame of that instance
+  const bf16_t* cache_b;                                      // that instance's conv cache (nullptr: none)
   const bf16_t* wt_base;                                      // weights of nxt's cout tile
   const bf16_t* h_base;                                       // nxt's halo source: frame + channel chunk
   const bf16_t* wg_nxt;                                       // nxt's weights: tap 0 of (frame tap, chunk)
@@ -626,7 +630,10 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
       s.voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
     }
   }
-  s.t = q.t;
+  const int b = a.seg_out == a.T_out ? 0 : __builtin_amdgcn_readfirstlane(q.t / a.seg_out);
+  s.t = q.t - b * a.seg_out;
+  s.f0 = (long long)b * a.seg_in;
+  s.cache_b = a.cache ? h4_pin64(a.cache + (long long)b * a.cache_bs) : nullptr;
   s.wt_base = a.w + (long long)q.n0 * a.Cin;
   s.n_dt = 0; s.n_kc = 0;
 }
@@ -638,9 +645,9 @@ __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const
   const int t = s.t;
   const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
   const int fv = t + s.n_dt - (a.kt - 1);
-  const bool from_cache = a.kt > 1 && fv < 0 && a.cache != nullptr;
+  const bool from_cache = a.kt > 1 && fv < 0 && s.cache_b != nullptr;
   const int fidx = a.kt > 1 ? (fv >= 0 ? fv : (from_cache ? a.kt - 1 + fv : 0)) : tin;
-  const bf16_t* f = h4_pin64((from_cache ? a.cache : a.x) + (long long)fidx * k.frame_elems);
+  const bf16_t* f = h4_pin64(from_cache ? s.cache_b + (long long)fidx * k.frame_elems : a.x + (s.f0 + fidx) * k.frame_elems);
   s.h_base = f + s.n_kc * BK;
   s.h_nrec = s.n_on ? k.frame_bytes - s.n_kc * ROWB : 0;      // off stream: zero-length descriptor -> harmless zero fill
   s.wg_nxt = s.wt_base + (long long)(s.n_dt * 9) * k.wtap_stride + s.n_kc * BK;
@@ -1822,8 +1829,10 @@ enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM8P, K_
 static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8p_kernel",
                                            "smallk_kernel"};
 
+static inline int desc_nb(const dove_conv_desc* d) { return d->nb > 1 ? d->nb : 1; }
+
 static ConvKernel select_kernel(const dove_conv_desc* d) {
-  const long long M = (long long)d->t_out * d->h_out * d->w_out;
+  const long long M = (long long)desc_nb(d) * d->t_out * d->h_out * d->w_out;
   const bool frame_fits = (long long)d->h_in * d->w_in * d->cin * 2 < (1ll << 31);
   const bool plain_gemm = d->kt == 1 && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->up == 0 && d->tmode == 0 &&
                           d->t_in == d->t_out && d->h_in == d->h_out && d->w_in == d->w_out && d->cout_pad % 128 == 0 && M >= 4096 &&
@@ -1894,7 +1903,7 @@ extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
   if (d->cout_store != 128 && d->cout_store != 256 && d->cout_store != 512) return 0;   // 4 / 8 / 16 channels per group
   if (d->cout_store != d->cout_pad) return 0;
   const long long th = (d->h_out + halo8::TH - 1) / halo8::TH, tw = (d->w_out + halo8::TW - 1) / halo8::TW;
-  return (long long)d->t_out * th * tw * 4;
+  return (long long)desc_nb(d) * d->t_out * th * tw * 4;      // instance-major: instance b owns rows [b * rows / nb, (b + 1) * rows / nb)
 }
 
 static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern);
@@ -1934,6 +1943,10 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d->up == 0 || d->up == 1, "conv_igemm: up must be 0/1");
   DOVE_CHECK_ARG(d->kt == 1 || (d->tmode == 0 && d->t_in == d->t_out), "conv_igemm: causal temporal taps need t_in == t_out and tmode 0");
   DOVE_CHECK_ARG(d->t_out > 0 && d->h_out > 0 && d->w_out > 0 && d->t_in > 0 && d->h_in > 0 && d->w_in > 0, "conv_igemm: empty tensor");
+  DOVE_CHECK_ARG(d->nb >= 0 && d->nb <= 4096 && (long long)desc_nb(d) * d->t_out < (1 << 20), "conv_igemm: bad instance count nb = %d", d->nb);
+  DOVE_CHECK_ARG(d->cache_stride == 0 || (d->cache && d->cache_stride >= (long long)(d->kt - 1) * d->h_in * d->w_in * d->cin),
+                 "conv_igemm: cache_stride (%lld) is smaller than one instance's cache", d->cache_stride);
+  DOVE_CHECK_ARG(desc_nb(d) == 1 || (!d->gate && !d->out_f32), "conv_igemm: nb > 1 is not combined with gate / out_f32");
   DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
                  "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
   const ConvKernel kern0 = select_kernel(d);
@@ -1965,8 +1978,11 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   IgemmArgs a;
   a.x = (const bf16_t*)d->x; a.cache = (const bf16_t*)d->cache; a.w = (const bf16_t*)d->w;
   a.bias = d->bias; a.resid = (const bf16_t*)d->resid; a.gate = d->gate; a.out = (bf16_t*)d->out; a.zero = zp;
-  a.T_out = d->t_out; a.H_out = d->h_out; a.W_out = d->w_out;
-  a.T_in = d->t_in; a.H_in = d->h_in; a.W_in = d->w_in;
+  const int nb = desc_nb(d);
+  a.T_out = nb * d->t_out; a.H_out = d->h_out; a.W_out = d->w_out;
+  a.T_in = nb * d->t_in; a.H_in = d->h_in; a.W_in = d->w_in;
+  a.seg_out = d->t_out; a.seg_in = d->t_in;
+  a.cache_bs = d->cache_stride ? d->cache_stride : (long long)(d->kt - 1) * d->h_in * d->w_in * d->cin;
   a.Cin = d->cin; a.Cout_pad = d->cout_pad; a.Cout_st = d->cout_store;
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
@@ -1981,7 +1997,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   }
 #endif
   hipStream_t s = (hipStream_t)stream;
-  const long long M = (long long)d->t_out * d->h_out * d->w_out;
+  const long long M = (long long)nb * d->t_out * d->h_out * d->w_out;
   switch (kern) {
     case K_GEMM8P: {
       a.tiles_n = d->cout_pad / 256;

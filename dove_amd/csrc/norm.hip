@@ -60,8 +60,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 }
 
 template <typename PT>   // float: per-block partials; double: the first-level sums of gn_reduce_rows_kernel
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const PT* __restrict__ partial, int nblocks, double count,
-                                                          float eps, float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const PT* __restrict__ partial_all, int nblocks, double count,
+                                                          float eps, float* __restrict__ stats_all) {
+  // blockIdx.x = instance (the batched forms: nb independent tensors, each with its own rows and its own statistics)
+  const PT* __restrict__ partial = partial_all + (long long)blockIdx.x * nblocks * 64;
+  float* __restrict__ stats = stats_all + blockIdx.x * 64;
   const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;  // 4 strided partial sums per (group, which)
   double acc = 0.0;
 #pragma unroll 8
@@ -107,8 +110,10 @@ __global__ void gn_finalize_sums_kernel(const double* __restrict__ sums, double 
 // partial rows written by a conv epilogue (one per tile x wave) -> 256 rows for gn_finalize_kernel; fixed order.  The first-level
 // sums stay fp64 (they used to be rounded to fp32 here): sums of fp32 tile partials are then exact in practice at every level, so
 // a frame-batch split over a rank pair (dove_amd.dist, whose pieces have other row counts) finalises to the same (mean, rstd)
-__global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ partial, long long rows,
-                                                             double* __restrict__ out) {
+__global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __restrict__ partial_all, long long rows,
+                                                             double* __restrict__ out_all) {
+  const float* __restrict__ partial = partial_all + (long long)blockIdx.y * rows * 64;     // blockIdx.y = instance
+  double* __restrict__ out = out_all + (long long)blockIdx.y * gridDim.x * 64;
   const int tid = threadIdx.x, j = tid & 63, part = tid >> 6;
   double acc = 0.0;
   for (long long r = (long long)blockIdx.x * 4 + part; r < rows; r += (long long)gridDim.x * 4) acc += (double)partial[r * 64 + j];
@@ -118,20 +123,26 @@ __global__ __launch_bounds__(256) void gn_reduce_rows_kernel(const float* __rest
   if (tid < 64) out[blockIdx.x * 64 + tid] = (sh[tid] + sh[tid + 64]) + (sh[tid + 128] + sh[tid + 192]);
 }
 
-extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws,
-                                                float* stats, void* stream) {
+extern "C" int dove_groupnorm_finalize_partials_nb(const float* partial, long long rows, int nb, double count, float eps, void* ws,
+                                                   size_t ws_bytes, float* stats, void* stream) {
   DOVE_CHECK_ARG(partial && ws && stats, "groupnorm_finalize_partials: null pointer");
-  DOVE_CHECK_ARG(rows > 0 && count > 0, "groupnorm_finalize_partials: empty input");
+  DOVE_CHECK_ARG(rows > 0 && count > 0 && nb >= 1 && nb <= 65535, "groupnorm_finalize_partials: empty input");
   hipStream_t s = (hipStream_t)stream;
   if (rows <= 1024) {
-    hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(1), dim3(256), 0, s, partial, (int)rows, count, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(nb), dim3(256), 0, s, partial, (int)rows, count, eps, stats);
   } else {
-    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256), dim3(256), 0, s, partial, rows, (double*)ws);
+    DOVE_CHECK_ARG(ws_bytes >= (size_t)nb * 256 * 64 * sizeof(double), "groupnorm_finalize_partials: scratch of %zu bytes, %d instances need %zu",
+                   ws_bytes, nb, (size_t)nb * 256 * 64 * sizeof(double));
+    hipLaunchKernelGGL(gn_reduce_rows_kernel, dim3(256, nb), dim3(256), 0, s, partial, rows, (double*)ws);
     DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials(reduce)");
-    hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(1), dim3(256), 0, s, (const double*)ws, 256, count, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel<double>, dim3(nb), dim3(256), 0, s, (const double*)ws, 256, count, eps, stats);
   }
   DOVE_CHECK_LAUNCH("dove_groupnorm_finalize_partials");
   return DOVE_OK;
+}
+extern "C" int dove_groupnorm_finalize_partials(const float* partial, long long rows, double count, float eps, void* ws,
+                                                float* stats, void* stream) {
+  return dove_groupnorm_finalize_partials_nb(partial, rows, 1, count, eps, ws, (size_t)256 * 64 * sizeof(double), stats, stream);
 }
 
 extern "C" int dove_groupnorm_sums_from_partials(const float* partial, long long rows, void* ws, double* sums, void* stream) {
@@ -171,8 +182,12 @@ static int gn_partial_launch(const void* x, long long npix, long long frame_pix,
   // only a scratch buffer too small for frames x bpf rows lowers it (the result stays deterministic, but no longer split-invariant)
   long long bpf = (frame_pix + (long long)nsub * 32 - 1) / ((long long)nsub * 32);
   if (bpf > 256) bpf = 256;
-  if (bpf * frames > ws_blocks) bpf = ws_blocks / frames;
-  if (bpf < 1) bpf = 1;
+  if (bpf * frames > ws_blocks) {
+    // a lowered block count would change the summation order with the number of frames in the call: a frame-batch split over a rank
+    // pair (dove_amd.dist) or a batch of tiles would silently stop reducing to the statistics of the single call - refuse instead
+    dove_set_error("%s: %lld frames x %lld blocks per frame exceed the %d scratch rows", who, frames, bpf, ws_blocks);
+    return 0;
+  }
   hipLaunchKernelGGL(gn_partial_kernel, dim3((unsigned)bpf, (unsigned)frames), dim3(256), 0, s, (const bf16_t*)x, frame_pix, C, cpp_log,
                      (float*)partial_ws);
   return (int)(bpf * frames);
@@ -186,6 +201,22 @@ extern "C" int dove_groupnorm_stats_bf16(const void* x, long long npix, long lon
   if (!rows) return DOVE_EINVAL;
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(partial)");
   hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(1), dim3(256), 0, s, (const float*)partial_ws, rows,
+                     (double)npix * (double)(C / 32), eps, stats);
+  DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
+  return DOVE_OK;
+}
+
+/* nb instances [nb][npix][C] back to back (npix = pixels of ONE instance): stats [nb][32][2].  The partial rows are per (frame, fixed share
+ * of the frame), i.e. exactly the rows nb separate calls would write, as long as the scratch holds nb * frames * blocks-per-frame rows. */
+extern "C" int dove_groupnorm_stats_nb_bf16(const void* x, int nb, long long npix, long long frame_pix, int C, float eps, void* partial_ws,
+                                             int ws_blocks, float* stats, void* stream) {
+  DOVE_CHECK_ARG(x && partial_ws && stats && nb >= 1, "groupnorm_stats: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int rows = gn_partial_launch(x, npix * nb, frame_pix > 0 ? frame_pix : npix, C, partial_ws, ws_blocks, s, "groupnorm_stats");
+  if (!rows) return DOVE_EINVAL;
+  DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(partial)");
+  DOVE_CHECK_ARG(rows % nb == 0, "groupnorm_stats: %d partial rows do not split over %d instances", rows, nb);
+  hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)partial_ws, rows / nb,
                      (double)npix * (double)(C / 32), eps, stats);
   DOVE_CHECK_LAUNCH("dove_groupnorm_stats_bf16(finalize)");
   return DOVE_OK;
@@ -212,10 +243,11 @@ extern "C" int dove_groupnorm_sums_bf16(const void* x, long long npix, long long
 struct GnApplyArgs {
   const bf16_t* x; bf16_t* y; const float* stats; const float* gamma; const float* beta;
   const bf16_t* yb;
-  int T, H, W, C, cpp_log;
+  int T, H, W, C, cpp_log;       // T = frames of ONE instance; the grid covers nb * T frames
   int hz, wz, sshift;
-  int tmap[32];
+  int tmap[32];                  // per-instance frame map into that instance's Tz latent frames
   int act;
+  int Tz;                        // latent frames per instance (yb is [nb * Tz, hz, wz, 2C])
 };
 
 // grid = (rows of H, T): each block walks image rows, threads = (C/8 channel chunks) x (256/(C/8)) pixels
@@ -225,16 +257,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyArgs a) {
   const int q = tid & (cpp - 1), sub = tid >> a.cpp_log;
   const int nsub = 256 >> a.cpp_log;
   const int cpg = a.C / 32;
+  const int t = blockIdx.y;                                   // global frame: instance b = t / T, frame t - b T of it
+  const int b = t / a.T;
+  const float* __restrict__ stats = a.stats + b * 64;         // every instance has its own GroupNorm scope
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = q * 8 + e, g = ch / cpg;
-    const float mean = a.stats[g * 2], rstd = a.stats[g * 2 + 1];
+    const float mean = stats[g * 2], rstd = stats[g * 2 + 1];
     sc[e] = rstd * a.gamma[ch];
     sh[e] = a.beta[ch] - mean * sc[e];
   }
-  const int t = blockIdx.y;
-  const int tz = a.tmap[t];
+  const int tz = b * a.Tz + a.tmap[t - b * a.T];
   for (int h = blockIdx.x; h < a.H; h += gridDim.x) {
     const long long rowbase = ((long long)t * a.H + h) * a.W;
     const long long zrow = ((long long)tz * a.hz + (h >> a.sshift)) * a.wz;
@@ -280,10 +314,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyArgs a) {
   }
 }
 
-extern "C" int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, int W, int C, const float* stats,
-                                          const float* gamma, const float* beta, int silu, const void* yb, int hz,
-                                          int wz, int sshift, const int* tmap, void* stream) {
+extern "C" int dove_groupnorm_apply_nb_bf16(const void* x, void* y, int nb, int T, int H, int W, int C, const float* stats,
+                                             const float* gamma, const float* beta, int silu, const void* yb, int Tz, int hz,
+                                             int wz, int sshift, const int* tmap, void* stream) {
   DOVE_CHECK_ARG(x && y && stats && gamma && beta, "groupnorm_apply: null pointer");
+  DOVE_CHECK_ARG(nb >= 1 && (long long)nb * T <= 65535, "groupnorm_apply: bad instance count %d", nb);
   DOVE_CHECK_ARG(C >= 32 && C <= 2048 && (C & (C - 1)) == 0, "groupnorm_apply: C (%d) must be a power of two in [32,2048]", C);
   DOVE_CHECK_ARG(T > 0 && T <= 32 && H > 0 && W > 0, "groupnorm_apply: need 0 < T <= 32 frames per batch (got %d), H, W > 0", T);
   GnApplyArgs a;
@@ -292,16 +327,21 @@ extern "C" int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, i
   int cpp_log = 0;
   while ((1 << cpp_log) < C / 8) ++cpp_log;
   a.cpp_log = cpp_log;
-  a.hz = hz; a.wz = wz; a.sshift = sshift;
+  a.hz = hz; a.wz = wz; a.sshift = sshift; a.Tz = Tz;
   for (int i = 0; i < 32; ++i) a.tmap[i] = 0;
   if (yb) {
     DOVE_CHECK_ARG(tmap, "groupnorm_apply: spatial norm needs a frame map");
     DOVE_CHECK_ARG(sshift >= 0 && sshift <= 8 && (hz << sshift) >= H && (wz << sshift) >= W, "groupnorm_apply: latent grid too small");
     for (int i = 0; i < T; ++i) a.tmap[i] = tmap[i];
   }
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(H < 4096 ? H : 4096, T), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(H < 4096 ? H : 4096, nb * T), dim3(256), 0, (hipStream_t)stream, a);
   DOVE_CHECK_LAUNCH("dove_groupnorm_apply_bf16");
   return DOVE_OK;
+}
+extern "C" int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, int W, int C, const float* stats,
+                                          const float* gamma, const float* beta, int silu, const void* yb, int hz,
+                                          int wz, int sshift, const int* tmap, void* stream) {
+  return dove_groupnorm_apply_nb_bf16(x, y, 1, T, H, W, C, stats, gamma, beta, silu, yb, 0, hz, wz, sshift, tmap, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

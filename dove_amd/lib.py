@@ -27,6 +27,7 @@ class ConvDesc(C.Structure):
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
         ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
         ("gn_partial", C.c_void_p), ("out_f32", C.c_int),
+        ("nb", C.c_int), ("cache_stride", C.c_longlong),
     ]
 
     def __init__(self, *a, **k):
@@ -66,6 +67,10 @@ SIGNATURES = {
     "dove_conv_igemm_bf16": [C.POINTER(ConvDesc), _VP],
     "dove_groupnorm_stats_bf16": [_VP, _LL, _LL, _I, _F, _VP, _I, _VP, _VP],
     "dove_groupnorm_finalize_partials": [_VP, _LL, C.c_double, _F, _VP, _VP, _VP],
+    "dove_groupnorm_stats_nb_bf16": [_VP, _I, _LL, _LL, _I, _F, _VP, _I, _VP, _VP],
+    "dove_groupnorm_finalize_partials_nb": [_VP, _LL, _I, C.c_double, _F, _VP, C.c_size_t, _VP, _VP],
+    "dove_groupnorm_apply_nb_bf16": [_VP, _VP, _I, _I, _I, _I, _I, _VP, _VP, _VP, _I, _VP, _I, _I, _I, _I, C.POINTER(C.c_int), _VP],
+    "dove_avgpool_time_nb_bf16": [_VP, _I, _I, _LL, _VP, _VP],
     "dove_groupnorm_sums_bf16": [_VP, _LL, _LL, _I, _VP, _I, _VP, _VP],
     "dove_groupnorm_finalize_sums": [_VP, C.c_double, _F, _VP, _VP],
     "dove_groupnorm_sums_from_partials": [_VP, _LL, _VP, _VP, _VP],

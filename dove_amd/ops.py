@@ -88,16 +88,22 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
          out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None,
-         gn_eps: float | None = None, out_f32: bool = False) -> torch.Tensor:
+         gn_eps: float | None = None, out_f32: bool = False, nb: int = 1) -> torch.Tensor:
     """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo].
 
     ``gn_eps``: the output feeds an nn.GroupNorm(32, C, eps) (resnet norm1/norm2, SpatialNorm's norm_layer).  When the
     dispatched kernel can fuse the statistics into its epilogue (``dove_conv_gn_partial_rows`` > 0), they are computed
     there and attached to the returned tensor as ``out.gn_stats`` ([32,2] mean / rstd, fp32) - `groupnorm_stats_of`
-    then skips the separate pass over the tensor; otherwise nothing is attached and the caller's path is unchanged."""
-    L.require_cuda(x, cache, resid, gate, out)
+    then skips the separate pass over the tensor; otherwise nothing is attached and the caller's path is unchanged.
+
+    ``nb`` > 1: x holds nb independent instances back to back along the frame axis ([nb*T, H, W, C]; ``t_out`` stays the per-instance
+    count) - the same-shaped tiles of the tiled VAE in one launch (include/dove_hip.h dove_conv_desc.nb).  ``cache`` is then
+    [nb, kt-1, H, W, C], possibly a strided view (dim 0) of the previous frame-batch's input; statistics come back as [nb, 32, 2]."""
+    L.require_cuda(x, resid, gate, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 4, (x.dtype, x.shape)
     T, H, W, Cx = x.shape
+    assert T % nb == 0, (T, nb)
+    T //= nb
     if Cx != pc.cin_pad:
         raise RuntimeError(f"conv: input has {Cx} channels, packed weight expects {pc.cin_pad}")
     ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
@@ -110,12 +116,20 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         ldo = pc.cout_store
     odt = torch.float32 if out_f32 else torch.bfloat16        # out_f32: un-rounded accumulators (tap-split conv_out, conv_out_gather)
     if out is None:
-        out = torch.empty(t_out, hw_out[0], hw_out[1], ldo, dtype=odt, device=x.device)
+        out = torch.empty(nb * t_out, hw_out[0], hw_out[1], ldo, dtype=odt, device=x.device)
     else:
-        assert out.shape == (t_out, hw_out[0], hw_out[1], ldo) and out.dtype == odt
+        assert out.shape == (nb * t_out, hw_out[0], hw_out[1], ldo) and out.dtype == odt
+    cache_stride = 0
     if cache is not None:
-        assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
+        if nb > 1:
+            assert cache.shape == (nb, pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16 and cache.is_cuda, (cache.shape, x.shape)
+            assert cache[0].is_contiguous() and cache.device == x.device
+            cache_stride = cache.stride(0)
+        else:
+            L.require_cuda(cache)
+            assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
     d = L.ConvDesc()
+    d.nb, d.cache_stride = nb, cache_stride
     d.x, d.cache, d.w = x.data_ptr(), (cache.data_ptr() if cache is not None else None), pc.w.data_ptr()
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None
@@ -133,7 +147,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         L.load().dove_timing_set_debug_buf(C.c_void_p(debug_buf.data_ptr()))
     d.out_f32 = int(out_f32)
     if resid is not None:
-        assert resid.dtype == torch.bfloat16 and resid.numel() == t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
+        assert resid.dtype == torch.bfloat16 and resid.numel() == nb * t_out * hw_out[0] * hw_out[1] * resid.shape[-1]
     if gate is not None:
         assert gate.dtype == torch.float32 and gate.shape == (2, pc.cout_pad)
     partial = None
@@ -148,29 +162,35 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     L.check(L.load().dove_conv_igemm_bf16(C.byref(d), L.stream_ptr()), "dove_conv_igemm_bf16")
     if _profiler is not None:
         e1.record()
-        flops = 2.0 * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
+        flops = 2.0 * nb * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
         _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1, L.load().dove_conv_kernel_name(C.byref(d)).decode()))
     if partial is None:
         if getattr(out, "gn_stats", None) is not None:      # a re-used `out` tensor must not keep statistics of old contents
             out.gn_stats = None
             out.gn_rows = None
     else:
-        stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
         count = float(t_out * hw_out[0] * hw_out[1]) * (pc.cout_store // 32)
-        L.check(L.load().dove_groupnorm_finalize_partials(partial.data_ptr(), partial.shape[0], count, gn_eps, L.ptr(_ws(x.device)),
-                                                          L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials")
+        if nb > 1:
+            stats = torch.empty(nb, 32, 2, dtype=torch.float32, device=x.device)
+            ws = _ws(x.device, nb * 512)                       # nb x 256 rows of 64 doubles
+            L.check(L.load().dove_groupnorm_finalize_partials_nb(partial.data_ptr(), partial.shape[0] // nb, nb, count, gn_eps, L.ptr(ws),
+                                                                 ws.numel() * 4, L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials_nb")
+        else:
+            stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
+            L.check(L.load().dove_groupnorm_finalize_partials(partial.data_ptr(), partial.shape[0], count, gn_eps, L.ptr(_ws(x.device)),
+                                                              L.ptr(stats), L.stream_ptr()), "dove_groupnorm_finalize_partials")
         out.gn_stats = (stats, gn_eps, out._version)           # torch's in-place counter: a later torch write voids them
         out.gn_rows = partial                                  # raw per-tile sums: dove_amd.dist combines them across a rank pair
     return out
 
 
-def groupnorm_stats_of(x: torch.Tensor, eps: float) -> torch.Tensor:
+def groupnorm_stats_of(x: torch.Tensor, eps: float, nb: int = 1) -> torch.Tensor:
     """GroupNorm(32) statistics of x: the ones its producing conv already computed (``conv(..., gn_eps=eps)``), else a
-    pass over x."""
+    pass over x.  ``nb`` > 1: x is nb instances back to back, one statistics scope each ([nb, 32, 2])."""
     have = getattr(x, "gn_stats", None)
-    if have is not None and have[1] == eps and have[2] == x._version:
+    if have is not None and have[1] == eps and have[2] == x._version and have[0].numel() == nb * 64:
         return have[0]
-    return groupnorm_stats(x, eps)
+    return groupnorm_stats(x, eps, nb)
 
 
 def linear(x: torch.Tensor, pc: PackedConv, **kw) -> torch.Tensor:
@@ -187,12 +207,21 @@ _gn_ws: dict = {}
 GN_WS_ROWS = 4096        # partial rows of scratch: 9 frames x 256 blocks per frame at most (csrc/norm.hip gn_partial_launch)
 
 
-def _ws(device):
-    # one scratch buffer per (device, stream): the two-stream VAE mode runs GroupNorm statistics concurrently
+def _ws(device, rows: int = GN_WS_ROWS):
+    # one scratch buffer per (device, stream): the two-stream VAE mode runs GroupNorm statistics concurrently.  It only ever grows
+    # (launches that used the old buffer are ordered before anything that re-uses its memory on the same stream)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
-    if key not in _gn_ws:
-        _gn_ws[key] = torch.empty(GN_WS_ROWS * 64, dtype=torch.float32, device=device)
+    rows = max(rows, GN_WS_ROWS)
+    if key not in _gn_ws or _gn_ws[key].numel() < rows * 64:
+        _gn_ws[key] = torch.empty(rows * 64, dtype=torch.float32, device=device)
     return _gn_ws[key]
+
+
+def _gn_rows_needed(x, frames: int) -> int:
+    """Partial rows csrc/norm.hip gn_partial_launch writes for `frames` frames of x's frame size (at most 256 blocks per frame)."""
+    fp = _frame_pix(x) or x.numel() // x.shape[-1]
+    nsub = 256 // max(x.shape[-1] // 8, 1)
+    return frames * min(256, -(-fp // (max(nsub, 1) * 32)))
 
 
 def _frame_pix(x):
@@ -200,14 +229,21 @@ def _frame_pix(x):
     return x.shape[1] * x.shape[2] if x.dim() == 4 else 0
 
 
-def groupnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
-    """x [T,H,W,C] (one frame-batch) -> stats [32,2] (mean, rstd) fp32."""
+def groupnorm_stats(x: torch.Tensor, eps: float, nb: int = 1) -> torch.Tensor:
+    """x [T,H,W,C] (one frame-batch) -> stats [32,2] (mean, rstd) fp32; ``nb`` > 1: [nb*T,H,W,C] -> [nb,32,2], one scope per instance."""
     L.require_cuda(x)
     assert x.dtype == torch.bfloat16
     Cc = x.shape[-1]
+    frames = x.shape[0] if x.dim() == 4 else 1
+    ws = _ws(x.device, _gn_rows_needed(x, frames))
+    if nb > 1:
+        assert x.dim() == 4 and x.shape[0] % nb == 0
+        stats = torch.empty(nb, 32, 2, dtype=torch.float32, device=x.device)
+        L.check(L.load().dove_groupnorm_stats_nb_bf16(L.ptr(x), nb, x.numel() // Cc // nb, _frame_pix(x), Cc, eps, L.ptr(ws), ws.numel() // 64,
+                                                      L.ptr(stats), L.stream_ptr()), "dove_groupnorm_stats_nb_bf16")
+        return stats
     stats = torch.empty(32, 2, dtype=torch.float32, device=x.device)
-    ws = _ws(x.device)
-    L.check(L.load().dove_groupnorm_stats_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, eps, L.ptr(ws), GN_WS_ROWS, L.ptr(stats),
+    L.check(L.load().dove_groupnorm_stats_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, eps, L.ptr(ws), ws.numel() // 64, L.ptr(stats),
                                                L.stream_ptr()), "dove_groupnorm_stats_bf16")
     return stats
 
@@ -218,7 +254,8 @@ def groupnorm_sums(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == torch.bfloat16
     Cc = x.shape[-1]
     sums = torch.empty(32, 2, dtype=torch.float64, device=x.device)
-    L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, L.ptr(_ws(x.device)), GN_WS_ROWS, L.ptr(sums),
+    ws = _ws(x.device, _gn_rows_needed(x, x.shape[0] if x.dim() == 4 else 1))
+    L.check(L.load().dove_groupnorm_sums_bf16(L.ptr(x), x.numel() // Cc, _frame_pix(x), Cc, L.ptr(ws), ws.numel() // 64, L.ptr(sums),
                                               L.stream_ptr()), "dove_groupnorm_sums_bf16")
     return sums
 
@@ -245,21 +282,24 @@ def groupnorm_from_sums(sums: torch.Tensor, count: float, eps: float) -> torch.T
     return stats
 
 
-def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
-    """y = silu?(GN(x) [* Y + B]) with the SpatialNorm3D table yb [Tz,hz,wz,2C] gathered by nearest resize."""
+def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None, nb=1):
+    """y = silu?(GN(x) [* Y + B]) with the SpatialNorm3D table yb [Tz,hz,wz,2C] gathered by nearest resize.  ``nb`` > 1: x [nb*T,..],
+    stats [nb,32,2], yb [nb*Tz,..], ``tmap`` the frame map of ONE instance."""
     L.require_cuda(x, stats, gamma, beta, yb, out)
     T, H, W, Cc = x.shape
+    assert T % nb == 0 and stats.numel() == nb * 64
+    T //= nb
     if out is None:
         out = torch.empty_like(x)
-    hz = wz = 0
+    Tz = hz = wz = 0
     tm = None
     if yb is not None:
-        assert yb.dtype == torch.bfloat16 and yb.shape[-1] == 2 * Cc and tmap is not None and len(tmap) == T
-        hz, wz = yb.shape[1], yb.shape[2]
+        assert yb.dtype == torch.bfloat16 and yb.shape[-1] == 2 * Cc and tmap is not None and len(tmap) == T and yb.shape[0] % nb == 0
+        Tz, hz, wz = yb.shape[0] // nb, yb.shape[1], yb.shape[2]
         tm = (C.c_int * T)(*tmap)
-    L.check(L.load().dove_groupnorm_apply_bf16(L.ptr(x), L.ptr(out), T, H, W, Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
-                                               int(silu), L.ptr(yb), hz, wz, sshift, tm, L.stream_ptr()),
-            "dove_groupnorm_apply_bf16")
+    L.check(L.load().dove_groupnorm_apply_nb_bf16(L.ptr(x), L.ptr(out), nb, T, H, W, Cc, L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                                  int(silu), L.ptr(yb), Tz, hz, wz, sshift, tm, L.stream_ptr()),
+            "dove_groupnorm_apply_nb_bf16")
     return out
 
 
@@ -372,14 +412,17 @@ def ncthw_from_cl(x: torch.Tensor, Cc: int, dtype, scale=1.0, shift=0.0, lo=-mat
     return y
 
 
-def avgpool_time(x: torch.Tensor) -> torch.Tensor:
+def avgpool_time(x: torch.Tensor, nb: int = 1) -> torch.Tensor:
+    """Downsample3D's temporal pool; ``nb`` > 1: x is nb instances [nb*T, H, W, C], pooled per instance."""
     L.require_cuda(x)
     T, H, W, Cc = x.shape
+    assert T % nb == 0
+    T //= nb
     if T == 1:
         return x
     To = 1 + (T - 1) // 2 if T % 2 else T // 2
-    y = torch.empty(To, H, W, Cc, dtype=torch.bfloat16, device=x.device)
-    L.check(L.load().dove_avgpool_time_bf16(L.ptr(x), T, H * W * Cc, L.ptr(y), L.stream_ptr()), "dove_avgpool_time_bf16")
+    y = torch.empty(nb * To, H, W, Cc, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_avgpool_time_nb_bf16(L.ptr(x), nb, T, H * W * Cc, L.ptr(y), L.stream_ptr()), "dove_avgpool_time_nb_bf16")
     return y
 
 

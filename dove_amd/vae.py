@@ -103,6 +103,8 @@ class AutoencoderKLCogVideoX:
         # per-kernel durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
         self.n_streams = 1
         self._streams = None
+        # enable_tiling(): run all tiles of one shape as one batch (False: one tile at a time, the round-3 loop - kept for the A/B)
+        self.tile_batching = True
         self._pack(state_dict)
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -165,8 +167,21 @@ class AutoencoderKLCogVideoX:
         """CogVideoXCausalConv3d with conv_cache: the front halo is the last kt-1 input frames of the previous batch."""
         pc = self.pc[name]
         if pc.kt == 1:
-            return ops.conv(x, pc, **kw)
+            return ops.conv(x, pc, nb=self._nb, **kw)
         k = pc.kt - 1
+        if self._nb > 1:
+            # nb same-shaped tiles in one launch (_tiled): x [nb*T, H, W, C], the cache a [nb, k, H, W, C] view of the previous
+            # frame-batch's input - instance b's first frames read cache[b]
+            nb = self._nb
+            x5 = x.view(nb, x.shape[0] // nb, *x.shape[1:])
+            prev = cache.get(name)
+            if x5.shape[1] >= k:
+                new = x5[:, -k:]
+            else:
+                pad = prev if prev is not None else x5[:, :1].expand(-1, k, -1, -1, -1)
+                new = torch.cat([pad, x5], dim=1)[:, -k:].contiguous()
+            cache[name] = new
+            return ops.conv(x, pc, cache=prev, nb=nb, **kw)
         fetch = getattr(cache, "fetch", None)      # dove_amd.dist.HaloCache: halo arrives from rank-1 over xGMI
         prev = fetch(name, (k,) + tuple(x.shape[1:]), x.device) if fetch else cache.get(name)
         events = getattr(cache, "events", None)    # StreamCache: frame-batches alternate between two HIP streams
@@ -194,36 +209,40 @@ class AutoencoderKLCogVideoX:
     #   first-frame rule, which diffusers derives from the batch's frame-count parity
     _gn_hook = None
     _piece_role = None
+    # > 1 while _tiled runs nb same-shaped tiles as ONE batch: every activation is [nb*T, H, W, C] (tile-major), every operator
+    # call carries nb, GroupNorm statistics and conv caches stay per tile
+    _nb = 1
 
     def _norm_silu(self, x, name, zq=None):
+        nb = self._nb
         if self._gn_hook is not None:
             stats = self._gn_hook(x)
         else:
-            stats = ops.groupnorm_stats_of(x, self.eps)   # fused into the producing conv's epilogue when it could be
+            stats = ops.groupnorm_stats_of(x, self.eps, nb)   # fused into the producing conv's epilogue when it could be
         g, b = self.aff[name]
         if zq is None:
-            return ops.groupnorm_apply(x, stats, g, b, silu=True)
-        yb = ops.conv(zq, self.pc[name + ".yb"])            # [Tz,hz,wz,2C] on the latent grid
+            return ops.groupnorm_apply(x, stats, g, b, silu=True, nb=nb)
+        yb = ops.conv(zq, self.pc[name + ".yb"])            # [Tz,hz,wz,2C] on the latent grid (pointwise: instances need no care)
         ratio = x.shape[1] // zq.shape[1]
         assert x.shape[1] == zq.shape[1] * ratio and x.shape[2] == zq.shape[2] * ratio and ratio & (ratio - 1) == 0
         return ops.groupnorm_apply(x, stats, g, b, silu=True, yb=yb, sshift=ratio.bit_length() - 1,
-                                   tmap=spatial_norm_tmap(x.shape[0], zq.shape[0]))
+                                   tmap=spatial_norm_tmap(x.shape[0] // nb, zq.shape[0] // nb), nb=nb)
 
     def _resnet(self, x, name, cache, zq=None):
         h = self._norm_silu(x, name + ".norm1", zq)
         h = self._cconv(h, name + ".conv1", cache, gn_eps=self.eps)         # feeds norm2
         h = self._norm_silu(h, name + ".norm2", zq)
         if name + ".conv_shortcut" in self.pc:
-            x = ops.conv(x, self.pc[name + ".conv_shortcut"])
+            x = ops.conv(x, self.pc[name + ".conv_shortcut"])   # pointwise: the same call for one tile or a batch of tiles
         return self._cconv(h, name + ".conv2", cache, resid=x, gn_eps=self.eps)   # feeds the next block's norm1 / norm_out
 
     def _downsample(self, x, name, compress_time):
         if compress_time:
-            x = ops.avgpool_time(x)
-        return ops.conv(x, self.pc[name], stride=2, pad=(0, 0))
+            x = ops.avgpool_time(x, self._nb)
+        return ops.conv(x, self.pc[name], stride=2, pad=(0, 0), nb=self._nb)
 
     def _upsample(self, x, name, compress_time):
-        T = x.shape[0]
+        T = x.shape[0] // self._nb
         if compress_time and self._piece_role is not None:
             # a piece of a split frame-batch: the piece that starts an odd-length batch keeps its first frame single,
             # every other piece doubles all of its frames (also a single-frame piece, which is not a 1-frame batch)
@@ -232,7 +251,7 @@ class AutoencoderKLCogVideoX:
             tmode, t_out = (2, 2 * T - 1) if T % 2 == 1 else (1, 2 * T)
         else:
             tmode, t_out = 0, T
-        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps)
+        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps, nb=self._nb)
 
     def _encoder(self, x, cache, split_in=False):
         """``split_in``: x is the im2col'ed input of ``ops.cl_im2col3x3_from_ncthw`` (untiled encode: a spatial tile must see zero
@@ -278,15 +297,38 @@ class AutoencoderKLCogVideoX:
         frame-batched network with its own conv caches (GroupNorm statistics become per tile); tiles are cross-faded
         IN PLACE with their already blended upper / left neighbours, cropped and concatenated."""
         T, H, W, _ = x_cl.shape
-        rows = []
-        for i in range(0, H, stride_h):
-            row = []
-            for j in range(0, W, stride_w):
+        ii, jj = list(range(0, H, stride_h)), list(range(0, W, stride_w))
+        rows = [[None] * len(jj) for _ in ii]
+        if self.tile_batching:
+            # the tiles are independent until the blend: all tiles of one shape (interior / bottom edge / right edge / corner) run as
+            # ONE batch - a launch per operator and shape class instead of one per tile (20 tiles -> 4 classes at 720x1280), the
+            # largest class first so that the host queues the small classes' launches while the GPU works on the big one.
+            # Per tile the arithmetic is that of the loop below, bit for bit (tests/test_e2e_gpu.py).
+            classes = {}
+            for a, i in enumerate(ii):
+                for b, j in enumerate(jj):
+                    classes.setdefault((min(tile_h, H - i), min(tile_w, W - j)), []).append((a, b))
+            for (th, tw), members in sorted(classes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1])):
+                nb = len(members)
                 cache, parts = {}, []
-                for s, e in frame_batches(T, batch):
-                    parts.append(fn(x_cl[s:e, i:i + tile_h, j:j + tile_w].contiguous(), cache))
-                row.append(torch.cat(parts, dim=0) if len(parts) > 1 else parts[0])
-            rows.append(row)
+                self._nb = nb
+                try:
+                    for s, e in frame_batches(T, batch):
+                        xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
+                        o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
+                        parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
+                finally:
+                    self._nb = 1
+                out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
+                for n, (a, b) in enumerate(members):
+                    rows[a][b] = out[n]
+        else:
+            for a, i in enumerate(ii):
+                for b, j in enumerate(jj):
+                    cache, parts = {}, []
+                    for s, e in frame_batches(T, batch):
+                        parts.append(fn(x_cl[s:e, i:i + tile_h, j:j + tile_w].contiguous(), cache))
+                    rows[a][b] = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
         out_rows = []
         for i, row in enumerate(rows):
             out_row = []

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 11
+#define DOVE_ABI_VERSION 12
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -70,6 +70,17 @@ typedef struct dove_conv_desc {
   /* != 0: `out` is float [..][ldo] and receives the un-rounded fp32 accumulators (+ bias): partial sums another kernel finishes
    * (dove_conv_out_gather).  Only for plain convs (no act / resid) that dispatch to igemm_fast_kernel; an error otherwise. */
   int out_f32;
+  /* nb > 1 (ABI 12): `nb` INDEPENDENT instances of this conv in one launch, laid out back to back along the frame axis -
+   * x [nb * t_in, h_in, w_in, cin], out / resid [nb * t_out, ...], gn_partial instance-major (dove_conv_gn_partial_rows(d) / nb rows
+   * each).  t_in / t_out stay PER-INSTANCE counts: causal temporal taps, the conv cache and tmode are evaluated inside an instance
+   * (instance b's first frames read ITS cache frames, cache + b * cache_stride).  The spatial tiles of diffusers' tiled_encode /
+   * tiled_decode (`--is_vae_st`, /root/reference/inference_script.py:642-645) are such instances: each tile sees zero padding at its
+   * own border and keeps its own conv cache and GroupNorm scope, so same-shaped tiles run as ONE launch instead of one per tile.
+   * Results are those of nb separate calls.  0 / 1 = one instance.  Not combined with gate / out_f32. */
+  int nb;
+  /* elements between two instances' cache frames; 0 = (kt-1) * h_in * w_in * cin (a dense [nb][kt-1][h][w][cin] array).  A cache that is
+   * a view of the previous frame-batch's input [nb][t_prev][h][w][cin] passes t_prev * h_in * w_in * cin. */
+  long long cache_stride;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 /* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm8p_kernel,
@@ -88,7 +99,9 @@ int dove_groupnorm_finalize_partials(const float* partial, long long rows, doubl
  * encoder.norm_out, and the norm_layer inside CogVideoXSpatialNorm3D).  stats = [32][2] (mean, rstd) fp32.
  * frame_pix = H*W of one frame (npix = frames * frame_pix; 0: treat the tensor as one frame): partial sums are formed per
  * (frame, fixed share of the frame), so a batch split into pieces of whole frames reduces to the same statistics.
- * partial_ws: >= ws_blocks*64 floats of scratch; ws_blocks >= frames (4096 rows never constrain a 9-frame batch). */
+ * partial_ws: >= ws_blocks*64 floats of scratch; ws_blocks >= frames * min(256, blocks a frame needs) - 4096 rows never constrain a
+ * 9-frame batch; a scratch too small for the call is an ERROR (a lowered block count would make the sums depend on how many frames
+ * share the call, which the split-invariance above forbids). */
 int dove_groupnorm_stats_bf16(const void* x, long long npix, long long frame_pix, int C, float eps, void* partial_ws, int ws_blocks,
                               float* stats, void* stream);
 /* Distributed form (dove_amd.dist, frame-batch split over a rank pair): raw per-group (sum, sum of squares) of one piece
@@ -106,6 +119,25 @@ int dove_groupnorm_sums_from_partials(const float* partial, long long rows, void
 int dove_groupnorm_apply_bf16(const void* x, void* y, int T, int H, int W, int C, const float* stats,
                               const float* gamma, const float* beta, int silu, const void* yb, int hz, int wz,
                               int sshift, const int* tmap, void* stream);
+
+/* ---- batched forms (ABI 12): `nb` independent instances back to back along the frame axis, each with its own GroupNorm scope - the
+ * same-shaped spatial tiles of AutoencoderKLCogVideoX.tiled_encode / tiled_decode (`--is_vae_st`, /root/reference/inference_script.py:
+ * 642-645) in ONE launch per operator instead of one per tile (dove_conv_desc.nb is the conv's form).  Each returns what nb separate
+ * calls of the un-suffixed function would: the partial sums are keyed by (instance, frame, share of the frame) as before.
+ *   stats_nb:             x [nb][npix][C] (npix = pixels of ONE instance, frame_pix of one frame) -> stats [nb][32][2];
+ *                         partial_ws >= nb * frames * min(256, ceil(frame_pix / (8192 / (C/8)))) rows of 64 floats (an error otherwise)
+ *   finalize_partials_nb: partial [nb][rows][32][2] (dove_conv_desc.gn_partial of a conv with nb instances; rows = rows of ONE
+ *                         instance) -> stats [nb][32][2]; ws >= nb * 128 KiB when rows > 1024
+ *   apply_nb:             x, y [nb * T, H, W, C], stats [nb][32][2], yb [nb * Tz, hz, wz, 2C], tmap [T] = frame map of ONE instance
+ *   avgpool_time_nb:      x [nb][T][frame] -> y [nb][To][frame] */
+int dove_groupnorm_stats_nb_bf16(const void* x, int nb, long long npix, long long frame_pix, int C, float eps, void* partial_ws,
+                                 int ws_blocks, float* stats, void* stream);
+int dove_groupnorm_finalize_partials_nb(const float* partial, long long rows, int nb, double count, float eps, void* ws, size_t ws_bytes,
+                                        float* stats, void* stream);
+int dove_groupnorm_apply_nb_bf16(const void* x, void* y, int nb, int T, int H, int W, int C, const float* stats, const float* gamma,
+                                 const float* beta, int silu, const void* yb, int Tz, int hz, int wz, int sshift, const int* tmap,
+                                 void* stream);
+int dove_avgpool_time_nb_bf16(const void* x, int nb, int T, long long frame_elems, void* y, void* stream);
 
 /* CogVideoXLayerNormZero / norm_final / AdaLayerNorm: y = LN(x)*gamma+beta, then *(1+scale)+shift with
  * mod = [2 row classes][shift|scale][D] fp32 (rows < split: class 0 = text); mod NULL -> plain LayerNorm. */

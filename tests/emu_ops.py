@@ -64,7 +64,15 @@ def _frame_index(t, tmode):
 
 
 def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, resid=None,
-         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None, out_f32=False):
+         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None, out_f32=False, nb=1):
+    if nb > 1:
+        # dove_conv_desc.nb: nb independent instances back to back along the frame axis = nb separate calls (that IS the contract)
+        assert out is None and gate is None and x.shape[0] % nb == 0
+        xs = x.view(nb, x.shape[0] // nb, *x.shape[1:])
+        rs = None if resid is None else resid.reshape(nb, -1, *resid.shape[1:])
+        return torch.cat([conv(xs[b], pc, cache=None if cache is None else cache[b], stride=stride, pad=pad, up=up, tmode=tmode, t_out=t_out,
+                               hw_out=hw_out, resid=None if rs is None else rs[b], act=act, ldo=ldo, gn_eps=gn_eps, out_f32=out_f32)
+                          for b in range(nb)], dim=0)
     T, H, W, Cx = x.shape
     assert Cx == pc.cin_pad
     ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
@@ -136,7 +144,9 @@ def linear(x, pc, **kw):
     return y.view(N, y.shape[-1])
 
 
-def groupnorm_stats(x, eps):
+def groupnorm_stats(x, eps, nb=1):
+    if nb > 1:
+        return torch.stack([groupnorm_stats(xb, eps) for xb in x.view(nb, x.shape[0] // nb, *x.shape[1:])])
     Cc = x.shape[-1]
     xf = x.double().reshape(-1, 32, Cc // 32)
     mean = xf.mean(dim=(0, 2))
@@ -162,11 +172,17 @@ def groupnorm_from_sums(sums, count, eps):
     return torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=1).float()
 
 
-def groupnorm_stats_of(x, eps):
-    return groupnorm_stats(x, eps)
+def groupnorm_stats_of(x, eps, nb=1):
+    return groupnorm_stats(x, eps, nb)
 
 
-def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None):
+def groupnorm_apply(x, stats, gamma, beta, *, silu=True, yb=None, sshift=0, tmap=None, out=None, nb=1):
+    if nb > 1:
+        assert out is None
+        xs = x.view(nb, x.shape[0] // nb, *x.shape[1:])
+        ys = None if yb is None else yb.view(nb, yb.shape[0] // nb, *yb.shape[1:])
+        return torch.cat([groupnorm_apply(xs[b], stats[b], gamma, beta, silu=silu, yb=None if ys is None else ys[b], sshift=sshift, tmap=tmap)
+                          for b in range(nb)], dim=0)
     T, H, W, Cc = x.shape
     cpg = Cc // 32
     mean = stats[:, 0].repeat_interleave(cpg)
@@ -365,7 +381,9 @@ def ncthw_from_cl(x, Cc, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=math.inf)
     return (x.float()[..., :Cc] * scale + shift).clamp(lo, hi).permute(3, 0, 1, 2).contiguous().to(dtype)
 
 
-def avgpool_time(x):
+def avgpool_time(x, nb=1):
+    if nb > 1:
+        return torch.cat([avgpool_time(xb) for xb in x.view(nb, x.shape[0] // nb, *x.shape[1:])], dim=0)
     T = x.shape[0]
     if T == 1:
         return x

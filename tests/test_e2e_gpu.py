@@ -211,6 +211,32 @@ def test_vae_tiling_real_tile_geometry_gpu():
     assert rel < 0.05 and rms_rel(d, d_ref) < 1.5e-2
 
 
+def test_vae_tile_batching_bit_identical_gpu():
+    """enable_tiling() runs all tiles of one shape as ONE batch (dove_conv_desc.nb and the *_nb GroupNorm / pool operators: per-tile conv
+    caches, zero padding and GroupNorm scope inside one launch).  Per tile that is the arithmetic of the one-tile-at-a-time loop, so the
+    two must agree bit for bit - on the production kernels: 128x128-px tiles (every level >= 16 rows: conv3x3_halo4x with fused
+    statistics, the upsample variant, igemm_fast's strided / (3,1,1) convs, smallk), 17 frames = two frame-batches (caches in use),
+    a 17x312x304 clip = 3x3 tiles in 4 shape classes (4, 2, 2, 1 tiles)."""
+    v, t, s = config.small_configs(num_layers=1)
+    v["sample_height"], v["sample_width"] = 256, 256
+    pipe = CogVideoXPipeline.from_config(v, t, s, seed=31, device="cuda")
+    vae = pipe.vae
+    vae.enable_tiling()
+    xb = synth_clip(17, 312, 304, seed=8).cuda().to(torch.bfloat16)
+    z = torch.randn(1, 16, 5, 39, 38, generator=torch.Generator().manual_seed(3)).cuda().to(torch.bfloat16)
+    assert vae.tile_batching
+    p1 = vae.encode(xb).latent_dist.parameters
+    d1 = vae.decode(z).sample
+    vae.tile_batching = False
+    p0 = vae.encode(xb).latent_dist.parameters
+    d0 = vae.decode(z).sample
+    vae.tile_batching = True
+    assert p1.shape[:3] == (1, 32, 5) and d1.shape[:3] == (1, 3, 17)     # (diffusers' row / column limits do not divide this size evenly)
+    assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(d1).all())
+    assert torch.equal(p1, p0), f"batched tiled encode differs from the tile loop: max {float((p1.float() - p0.float()).abs().max())}"
+    assert torch.equal(d1, d0), f"batched tiled decode differs from the tile loop: max {float((d1.float() - d0.float()).abs().max())}"
+
+
 def test_two_stream_vae_is_bit_identical(setup):
     """Alternate frame-batches on two HIP streams (per-conv events) must not change a single bit."""
     pipe, (v, t, s), wv, wt, text = setup

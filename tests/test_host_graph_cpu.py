@@ -140,19 +140,25 @@ def test_vae_tiling_vs_oracle(monkeypatch):
     pipe = CogVideoXPipeline.from_config(v, t, s, seed=9, device="cpu")
     ov = OracleVAE(v, weights.random_state_dict(weights.vae_param_shapes(v), 9))
     torch.manual_seed(4)
-    x = torch.randn(1, 3, 9, 120, 192).clamp(-1, 1)
+    x = torch.randn(1, 3, 17, 120, 192).clamp(-1, 1)        # 17 frames = two frame-batches: the per-tile conv caches are used
     pipe.vae.enable_tiling()
     pipe.vae.enable_slicing()
+    assert pipe.vae.tile_batching                            # 3 x 3 tiles in 4 shape classes (4, 2, 2, 1 tiles) = 4 batched passes
     p = pipe.vae.encode(x.to(torch.bfloat16)).latent_dist.parameters
     p_ref = ov.encode(x, tiling=True)
-    assert p.shape == p_ref.shape == (1, 32, 3, 15, 24)
+    assert p.shape == p_ref.shape == (1, 32, 5, 15, 24)
     assert rel(p, p_ref) < 0.06
     assert rel(p_ref, ov.encode(x)) > 0.2                    # tiling really changes the numbers (GroupNorm scope)
-    z = torch.randn(1, 16, 3, 15, 24)
+    z = torch.randn(1, 16, 5, 15, 24)
     d = pipe.vae.decode(z.to(torch.bfloat16)).sample
     d_ref = ov.decode(z, tiling=True)
-    assert d.shape == d_ref.shape == (1, 3, 9, 120, 192)
+    assert d.shape == d_ref.shape == (1, 3, 17, 120, 192)
     assert rel(d, d_ref) < 0.06
+    # one tile at a time (the round-3 loop) gives the same bits: batching only changes how many tiles share a launch
+    pipe.vae.tile_batching = False
+    assert torch.equal(p, pipe.vae.encode(x.to(torch.bfloat16)).latent_dist.parameters)
+    assert torch.equal(d, pipe.vae.decode(z.to(torch.bfloat16)).sample)
+    pipe.vae.tile_batching = True
     # below the tile threshold the tiled flag is a no-op, like diffusers
     small = torch.randn(1, 3, 5, 48, 80).clamp(-1, 1)
     assert rel(pipe.vae.encode(small.to(torch.bfloat16)).latent_dist.parameters, ov.encode(small)) < 0.06
