@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -94,6 +95,21 @@ __global__ void copy2d_kernel(char* dst, long long dpitch, const char* src, long
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / w2, c = i - r * w2;
     ((uint16_t*)(dst + r * dpitch))[c] = ((const uint16_t*)(src + r * spitch))[c];
+  }
+}
+// spatial tiles of one shape -> one batch: out [nb][nt][th][tw][C] <- x [T][H][W][C] frames [t0, t0 + nt), tile n at (oy[n], ox[n]); 16-byte chunks
+struct TileOrigins { int n; short oy[64], ox[64]; };
+__global__ void tile_gather_kernel(const bf16_t* __restrict__ x, int H, int W, int C8, int t0, int nt, int th, int tw, TileOrigins org,
+                                   bf16_t* __restrict__ out) {
+  const long long per = (long long)nt * th * tw * C8, total = per * org.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per);
+    long long r = i - (long long)n * per;
+    const int c = (int)(r % C8); r /= C8;
+    const int xx = (int)(r % tw); r /= tw;
+    const int yy = (int)(r % th);
+    const int t = (int)(r / th);
+    ((uint4*)out)[i] = ((const uint4*)x)[(((long long)(t0 + t) * H + org.oy[n] + yy) * W + org.ox[n] + xx) * C8 + c];
   }
 }
 inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int height, hipStream_t s) {
@@ -196,7 +212,9 @@ struct dove_ctx {
   // VAE
   std::unordered_map<std::string, Tensor> cache;        // conv_cache of the running clip (views or copies)
   std::unordered_map<std::string, void*> cache_owner;   // arena block a cache entry keeps alive (a retained conv input) or the copy itself
-  float* gn_ws = nullptr;
+  std::unordered_map<std::string, long long> cache_stride;   // nb > 1: elements between two instances' cache frames (dove_conv_desc.cache_stride)
+  int nb = 1;                                           // > 1 while tiled() runs nb same-shaped tiles as one batch (Tensor.T = nb x frames)
+  float* gn_ws = nullptr; int gn_ws_rows = 0;
   float* conv_out_bias = nullptr;                       // != NULL: decoder.conv_out runs tap-split ("decoder.conv_out.taps" + gather)
   Arena arena;
   std::string err;
@@ -317,25 +335,29 @@ void free_t(dove_ctx* c, Tensor& t) { c->arena.release(t.p); t.p = nullptr; }
 struct ConvOpt { const Tensor* cache = nullptr; int stride = 1, pad_h = -1, pad_w = -1, up = 0, tmode = 0, t_out = -1, act = 0;
                  const bf16_t* resid = nullptr; int ldr = 0; const float* gate = nullptr; long long gate_split = 0; bf16_t* out = nullptr; int ldo = -1;
                  float gn_eps = -1.f; float** gn_stats = nullptr;
-                 bool out_f32 = false; };   // out_f32: the returned Tensor holds float [..][ldo] (its C counts bf16 units = 2 * ldo)
+                 bool out_f32 = false;
+                 int nb = 1; long long cache_stride = 0; };   // nb > 1: dove_conv_desc.nb (x.T = nb x frames, t_out per instance)   // out_f32: the returned Tensor holds float [..][ldo] (its C counts bf16 units = 2 * ldo)
 // x [T,H,W,cin_pad] -> out (allocated unless opt.out).  When opt.gn_eps >= 0 and the kernel fuses GroupNorm statistics, *opt.gn_stats
 // receives [32][2] (mean, rstd) from the arena (caller releases); otherwise it is left NULL.
 int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tensor* out, void* stream) {
   if (x.C != pc.cin_pad) { dove_set_error("conv: input has %d channels, packed weight expects %d", x.C, pc.cin_pad); return DOVE_EINVAL; }
   const int ph = o.pad_h < 0 ? (pc.kh - 1) / 2 : o.pad_h, pw = o.pad_w < 0 ? (pc.kw - 1) / 2 : o.pad_w;
-  const int t_out = o.t_out < 0 ? x.T : o.t_out;
+  const int nb = o.nb > 1 ? o.nb : 1;
+  const int t_in = x.T / nb;
+  const int t_out = o.t_out < 0 ? t_in : o.t_out;             // per instance
   int ho, wo;
   if (o.stride == 1) { ho = x.H << o.up; wo = x.W << o.up; }
   else { ho = (x.H + 1 - pc.kh) / o.stride + 1; wo = (x.W + 1 - pc.kw) / o.stride + 1; }
   const int ldo = o.ldo < 0 ? pc.cout_store() : o.ldo;
   Tensor y;
-  if (o.out) { y.p = o.out; y.T = t_out; y.H = ho; y.W = wo; y.C = ldo; }
-  else CHK(alloc_t(c, t_out, ho, wo, o.out_f32 ? 2 * ldo : ldo, &y));
+  if (o.out) { y.p = o.out; y.T = nb * t_out; y.H = ho; y.W = wo; y.C = ldo; }
+  else CHK(alloc_t(c, nb * t_out, ho, wo, o.out_f32 ? 2 * ldo : ldo, &y));
   dove_conv_desc d;
   memset(&d, 0, sizeof(d));
   d.struct_size = (unsigned)sizeof(d);
   d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
-  d.t_in = x.T; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
+  d.t_in = t_in; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
+  d.nb = nb; d.cache_stride = o.cache ? o.cache_stride : 0;
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
   d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
   d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;
@@ -353,9 +375,9 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   CHK(dove_conv_igemm_bf16(&d, stream));
   if (o.gn_stats) *o.gn_stats = nullptr;
   if (partial) {
-    float* st = (float*)c->arena.alloc(64 * 4);
+    float* st = (float*)c->arena.alloc((size_t)nb * 64 * 4);
     const double count = (double)t_out * ho * wo * (pc.cout_store() / 32);
-    CHK(dove_groupnorm_finalize_partials(partial, rows, count, o.gn_eps, c->gn_ws, st, stream));
+    CHK(dove_groupnorm_finalize_partials_nb(partial, rows / nb, nb, count, o.gn_eps, c->gn_ws, (size_t)c->gn_ws_rows * 64 * 4, st, stream));
     c->arena.release(partial);
     *o.gn_stats = st;
   }
@@ -393,12 +415,54 @@ void spatial_norm_tmap(int tf, int tz, std::vector<int>* m) {
 // a small block at the back of the arena and x is released here.  Either way x must not be touched by the caller afterwards.
 int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt o, Tensor* out, void* stream) {
   const Packed& pc = c->pc.at(name);
+  o.nb = c->nb;
   if (pc.kt == 1) {
     CHK(conv(c, x, pc, o, out, stream));
     if (x_owned) free_t(c, x);
     return 0;
   }
   const int k = pc.kt - 1;
+  if (c->nb > 1) {
+    // nb same-shaped tiles in one launch (tiled()): x [nb][Ti][H][W][C]; the cache entry is nb x k frames, instance b's at p + b * stride
+    // - a view of the retained previous input when x is an arena block with >= k frames per instance, else a dense copy
+    const int nb = c->nb, Ti = x.T / nb;
+    const long long frame = (long long)x.H * x.W * x.C;
+    hipStream_t s = (hipStream_t)stream;
+    auto it = c->cache.find(name);
+    Tensor prev;
+    const bool have = it != c->cache.end();
+    if (have) { prev = it->second; o.cache = &prev; o.cache_stride = c->cache_stride[name]; }
+    CHK(conv(c, x, pc, o, out, stream));
+    void* old_owner = have ? c->cache_owner[name] : nullptr;
+    Tensor nc; nc.T = nb * k; nc.H = x.H; nc.W = x.W; nc.C = x.C;
+    if (x_owned && Ti >= k && c->arena.cap - c->arena.used > 8 * x.bytes()) {
+      nc.p = x.p + (long long)(Ti - k) * frame;
+      c->cache[name] = nc; c->cache_owner[name] = x.p; c->cache_stride[name] = (long long)Ti * frame;
+      c->arena.release(old_owner);
+      x.p = nullptr;
+      return 0;
+    }
+    nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
+    if (!nc.p) { dove_set_error("workspace exhausted (conv cache of %s: %zu bytes)", name.c_str(), nc.bytes()); return DOVE_EINVAL; }
+    if (Ti >= k) {
+      CHK(copy2d(nc.p, (size_t)k * frame * 2, x.p + (long long)(Ti - k) * frame, (size_t)Ti * frame * 2, (size_t)k * frame * 2, nb, s));
+    } else {                                                    // fewer frames than the halo: slide each instance's padded window
+      const long long pstride = have ? c->cache_stride[name] : 0;
+      for (int b = 0; b < nb; ++b) {
+        bf16_t* dst = nc.p + (long long)b * k * frame;
+        const bf16_t* xb = x.p + (long long)b * Ti * frame;
+        for (int j = 0; j < k - Ti; ++j) {
+          const bf16_t* src = have ? prev.p + (long long)b * pstride + (long long)(j + Ti) * frame : xb;
+          HIPCHK(hipMemcpyAsync(dst + (long long)j * frame, src, (size_t)frame * 2, hipMemcpyDeviceToDevice, s));
+        }
+        HIPCHK(hipMemcpyAsync(dst + (long long)(k - Ti) * frame, xb, (size_t)Ti * frame * 2, hipMemcpyDeviceToDevice, s));
+      }
+    }
+    c->cache[name] = nc; c->cache_owner[name] = nc.p; c->cache_stride[name] = (long long)k * frame;
+    c->arena.release(old_owner);
+    if (x_owned) free_t(c, x);
+    return 0;
+  }
   auto it = c->cache.find(name);
   if (c->halo_recv && it == c->cache.end()) {
     // first batch of a rank > 0: the conv_cache the previous batch would have left arrives from rank - 1 (same layer order there)
@@ -467,14 +531,15 @@ void rank_batches(const dove_ctx* c, int nb, int* b0, int* b1) {
 int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::string& name, const Tensor* zq, Tensor* out, void* stream) {
   const float eps = c->cfg.vae_norm_eps;
   float* stats = fused_stats;
+  const int nb = c->nb, Ti = x.T / nb;
   if (!stats) {
-    stats = (float*)c->arena.alloc(64 * 4);
-    CHK(dove_groupnorm_stats_bf16(x.p, x.elems() / x.C, (long long)x.H * x.W, x.C, eps, c->gn_ws, 4096, stats, stream));
+    stats = (float*)c->arena.alloc((size_t)nb * 64 * 4);
+    CHK(dove_groupnorm_stats_nb_bf16(x.p, nb, x.elems() / x.C / nb, (long long)x.H * x.W, x.C, eps, c->gn_ws, c->gn_ws_rows, stats, stream));
   }
   const auto& gb = c->aff.at(name);
   CHK(alloc_t(c, x.T, x.H, x.W, x.C, out));
   if (!zq) {
-    CHK(dove_groupnorm_apply_bf16(x.p, out->p, x.T, x.H, x.W, x.C, stats, gb.first, gb.second, 1, nullptr, 0, 0, 0, nullptr, stream));
+    CHK(dove_groupnorm_apply_nb_bf16(x.p, out->p, nb, Ti, x.H, x.W, x.C, stats, gb.first, gb.second, 1, nullptr, 0, 0, 0, 0, nullptr, stream));
   } else {
     Tensor yb;
     CHK(conv(c, *zq, c->pc.at(name + ".yb"), ConvOpt(), &yb, stream));
@@ -482,8 +547,9 @@ int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::strin
     int sshift = 0;
     while ((1 << sshift) < ratio) ++sshift;
     std::vector<int> tmap;
-    spatial_norm_tmap(x.T, zq->T, &tmap);
-    CHK(dove_groupnorm_apply_bf16(x.p, out->p, x.T, x.H, x.W, x.C, stats, gb.first, gb.second, 1, yb.p, yb.H, yb.W, sshift, tmap.data(), stream));
+    spatial_norm_tmap(Ti, zq->T / nb, &tmap);
+    CHK(dove_groupnorm_apply_nb_bf16(x.p, out->p, nb, Ti, x.H, x.W, x.C, stats, gb.first, gb.second, 1, yb.p, zq->T / nb, yb.H, yb.W, sshift,
+                                     tmap.data(), stream));
     free_t(c, yb);
   }
   c->arena.release(stats);
@@ -517,7 +583,7 @@ void clear_caches(dove_ctx* c);
 struct StageGuard {
   dove_ctx* c;
   explicit StageGuard(dove_ctx* ctx) : c(ctx) {
-    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; }
+    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; }
   }
   ~StageGuard() { if (c) --c->depth; }
 };
@@ -536,13 +602,14 @@ int encoder(dove_ctx* c, const Tensor& x, Tensor* out, void* stream) {
       snprintf(nm, sizeof nm, "encoder.down_blocks.%d.downsamplers.0", i);
       if (hs) { c->arena.release(hs); hs = nullptr; }
       Tensor p = h;
-      if (i < n_tdown && h.T > 1) {
-        const int To = h.T % 2 ? 1 + (h.T - 1) / 2 : h.T / 2;
-        CHK(alloc_t(c, To, h.H, h.W, h.C, &p));
-        CHK(dove_avgpool_time_bf16(h.p, h.T, (long long)h.H * h.W * h.C, p.p, stream));
+      const int Ti = h.T / c->nb;
+      if (i < n_tdown && Ti > 1) {
+        const int To = Ti % 2 ? 1 + (Ti - 1) / 2 : Ti / 2;
+        CHK(alloc_t(c, c->nb * To, h.H, h.W, h.C, &p));
+        CHK(dove_avgpool_time_nb_bf16(h.p, c->nb, Ti, (long long)h.H * h.W * h.C, p.p, stream));
         free_t(c, h);
       }
-      ConvOpt od; od.stride = 2; od.pad_h = 0; od.pad_w = 0;
+      ConvOpt od; od.stride = 2; od.pad_h = 0; od.pad_w = 0; od.nb = c->nb;
       Tensor d;
       CHK(conv(c, p, c->pc.at(nm), od, &d, stream));
       free_t(c, p);
@@ -570,8 +637,9 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
     if (i < cf.vae_num_blocks - 1) {
       snprintf(nm, sizeof nm, "decoder.up_blocks.%d.upsamplers.0", i);
       if (hs) { c->arena.release(hs); hs = nullptr; }
-      ConvOpt ou; ou.up = 1; ou.pad_h = 1; ou.pad_w = 1; ou.gn_eps = cf.vae_norm_eps; ou.gn_stats = &hs;
-      if (i < n_tdown && h.T > 1) { ou.tmode = h.T % 2 ? 2 : 1; ou.t_out = h.T % 2 ? 2 * h.T - 1 : 2 * h.T; }
+      ConvOpt ou; ou.up = 1; ou.pad_h = 1; ou.pad_w = 1; ou.gn_eps = cf.vae_norm_eps; ou.gn_stats = &hs; ou.nb = c->nb;
+      const int Ti = h.T / c->nb;
+      if (i < n_tdown && Ti > 1) { ou.tmode = Ti % 2 ? 2 : 1; ou.t_out = Ti % 2 ? 2 * Ti - 1 : 2 * Ti; }
       Tensor u;
       CHK(conv(c, h, c->pc.at(nm), ou, &u, stream));
       free_t(c, h);
@@ -593,6 +661,7 @@ void clear_caches(dove_ctx* c) {
   for (auto& kv : c->cache_owner) c->arena.release(kv.second);
   c->cache.clear();
   c->cache_owner.clear();
+  c->cache_stride.clear();
 }
 
 // ---- DiT (dove_amd/transformer.py) ------------------------------------------------------------------------------------------------
@@ -932,7 +1001,8 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
   CHK(dev_alloc(c, (size_t)cf.dit_time_embed_dim * 4, &m)); c->e1 = (float*)m;
   CHK(dev_alloc(c, (size_t)D * 4, &m)); c->temb = (float*)m;
   CHK(dev_alloc(c, (size_t)6 * D * 4, &m)); c->vtmp = (float*)m;
-  CHK(dev_alloc(c, (size_t)4096 * 64 * 4, &m)); c->gn_ws = (float*)m;
+  c->gn_ws_rows = 65536;                                 // 16 MiB: nb x frames x 256 rows of a tile batch's statistics pass
+  CHK(dev_alloc(c, (size_t)c->gn_ws_rows * 64 * 4, &m)); c->gn_ws = (float*)m;
   HIPCHK(hipDeviceSynchronize());                             // the borrowed source tensors may be released by the caller now
   c->raw.clear();
   c->finalized = true;
@@ -952,6 +1022,8 @@ extern "C" size_t dove_workspace_bytes(dove_ctx* c, int F, int H, int W) {
   // cache ~ 3 x top over the decoder, staging of one decoded frame-batch; x 1.5 for first-fit fragmentation
   // plus, memory permitting, every causal conv's input of the previous frame-batch retained instead of copied (~ 20 x top)
   long long vae = 22 * top;                                                       // measured high water at 33x720x1280: 17.4 x top
+  // enable_tiling(): the tiles of one shape run as one batch; overlapping tiles cover up to 6/5 x 5/4 = 1.5 x the frame
+  if (c->opt_tiling) vae = vae * 3 / 2;
   const int D = cf.dit_heads * cf.dit_head_dim;
   const long long Td = T + (T % cf.dit_patch_t);
   const long long N = cf.dit_max_text + (Td / cf.dit_patch_t) * (H / 8 / cf.dit_patch) * (W / 8 / cf.dit_patch);
@@ -997,50 +1069,89 @@ static bool wants_tiling(const dove_ctx* c, bool enc, int H, int W) {
   TileGeom g; tiling_geometry(c, enc, &g);
   return W > g.tile_w || H > g.tile_h;
 }
-// x [T][H][W][C] channels-last -> *out [T'][H'][W'][ld] (arena block of the caller's)
+// x [T][H][W][C] channels-last -> *out [T'][H'][W'][ld] (arena block of the caller's).  The tiles are independent until the blend, so all
+// tiles of one shape (interior / bottom edge / right edge / corner: 12 + 4 + 3 + 1 at 720x1280) run as ONE batch - dove_conv_desc.nb and the
+// *_nb operators, one launch per operator and shape class instead of one per tile, the largest class first (dove_amd/vae.py _tiled; per tile
+// the arithmetic is that of a tile-by-tile loop, bit for bit).
 static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stream) {
   TileGeom g; tiling_geometry(c, enc, &g);
   DOVE_CHECK_ARG(g.stride_h > 0 && g.stride_w > 0 && g.lim_h > 0 && g.lim_w > 0, "vae tiling: degenerate tile geometry (sample size %d x %d)", c->sample_h, c->sample_w);
+  DOVE_CHECK_ARG(x.C % 8 == 0 && x.H < 32768 && x.W < 32768, "vae tiling: unsupported input layout");
   hipStream_t s = (hipStream_t)stream;
   const int batch = enc ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch;
   std::vector<std::pair<int, int>> fb;
   frame_batches(x.T, batch, &fb);
-  std::vector<std::vector<Tensor>> rows;
+  std::vector<int> ii, jj;
+  for (int i = 0; i < x.H; i += g.stride_h) ii.push_back(i);
+  for (int j = 0; j < x.W; j += g.stride_w) jj.push_back(j);
+  std::vector<std::vector<Tensor>> rows(ii.size(), std::vector<Tensor>(jj.size()));
+  struct Cls { int th, tw; std::vector<std::pair<int, int>> members; };
+  std::vector<Cls> classes;
+  for (size_t a = 0; a < ii.size(); ++a)
+    for (size_t b = 0; b < jj.size(); ++b) {
+      const int th = std::min(g.tile_h, x.H - ii[a]), tw = std::min(g.tile_w, x.W - jj[b]);
+      size_t k = 0;
+      while (k < classes.size() && !(classes[k].th == th && classes[k].tw == tw)) ++k;
+      if (k == classes.size()) classes.push_back({th, tw, {}});
+      classes[k].members.push_back({(int)a, (int)b});
+    }
+  std::stable_sort(classes.begin(), classes.end(), [](const Cls& p, const Cls& q) {
+    return (long long)p.th * p.tw * (long long)p.members.size() > (long long)q.th * q.tw * (long long)q.members.size(); });
+  std::vector<void*> class_blocks;
+  int t_total = 0;
+  for (auto& se : fb) t_total += enc ? enc_batch_frames(c, se.second - se.first) : dec_batch_frames(c, se.second - se.first);
   c->direct_io_convs = true;
   int rc = 0;
-  for (int i = 0; i < x.H && !rc; i += g.stride_h) {
-    rows.emplace_back();
-    for (int j = 0; j < x.W && !rc; j += g.stride_w) {
-      const int th = std::min(g.tile_h, x.H - i), tw = std::min(g.tile_w, x.W - j);
-      Tensor xt;
-      if ((rc = alloc_t(c, x.T, th, tw, x.C, &xt))) break;
-      for (int t = 0; t < x.T && !rc; ++t)
-        rc = copy2d(xt.p + (long long)t * th * tw * x.C, (size_t)tw * x.C * 2, x.p + (((long long)t * x.H + i) * x.W + j) * x.C, (size_t)x.W * x.C * 2,
-                    (size_t)tw * x.C * 2, th, s);
+  for (size_t k = 0; k < classes.size() && !rc; ++k) {
+    const Cls& cl = classes[k];
+    for (size_t m0 = 0; m0 < cl.members.size() && !rc; m0 += 64) {             // (TileOrigins holds 64 tiles; 20 at 720x1280)
+      const int nb = (int)std::min<size_t>(64, cl.members.size() - m0);
+      TileOrigins org; org.n = nb;
+      for (int n = 0; n < nb; ++n) { org.oy[n] = (short)ii[cl.members[m0 + n].first]; org.ox[n] = (short)jj[cl.members[m0 + n].second]; }
       clear_caches(c);
-      Tensor tile;                                              // [sum of the batches' frames][oh][ow][ld], allocated once the first batch says oh, ow, ld
-      int t_done = 0, t_total = 0;
-      for (auto& se : fb) t_total += enc ? enc_batch_frames(c, se.second - se.first) : dec_batch_frames(c, se.second - se.first);
+      c->nb = nb;
+      Tensor cls_out;                                           // [nb][t_total][oh][ow][ld], allocated once the first batch says oh, ow, ld
+      int t_done = 0;
       for (auto& se : fb) {
-        if (rc) break;
-        Tensor xb = xt; xb.p = xt.p + (long long)se.first * th * tw * x.C; xb.T = se.second - se.first;
-        Tensor o;
-        if ((rc = enc ? encoder(c, xb, &o, stream) : decoder(c, xb, &o, stream))) break;
-        if (!tile.p) {
-          tile.T = t_total; tile.H = o.H; tile.W = o.W; tile.C = o.C;
-          tile.p = (bf16_t*)c->arena.alloc(tile.bytes(), true);
-          if (!tile.p) { dove_set_error("workspace exhausted (vae tile output: %zu bytes)", tile.bytes()); rc = DOVE_EINVAL; free_t(c, o); break; }
+        const int nt = se.second - se.first;
+        Tensor xb;
+        if ((rc = alloc_t(c, nb * nt, cl.th, cl.tw, x.C, &xb))) break;
+        {
+          const long long n16 = xb.elems() / 8;
+          const unsigned grid = (unsigned)std::min<long long>((n16 + 255) / 256, 8192);
+          hipLaunchKernelGGL(tile_gather_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, x.p, x.H, x.W, x.C / 8, se.first, nt, cl.th, cl.tw, org, xb.p);
+          if (hipGetLastError() != hipSuccess) { rc = DOVE_ELAUNCH; free_t(c, xb); break; }
         }
-        if (hipMemcpyAsync(tile.p + (long long)t_done * o.H * o.W * o.C, o.p, o.bytes(), hipMemcpyDeviceToDevice, s) != hipSuccess) rc = DOVE_ELAUNCH;
-        t_done += o.T;
+        Tensor o;
+        rc = enc ? encoder(c, xb, &o, stream) : decoder(c, xb, &o, stream);
+        // the first conv does not own its input (a view in the un-tiled paths): release the batch tensor here.  Its conv cache was copied.
+        free_t(c, xb);
+        if (rc) break;
+        const int To = o.T / nb;
+        if (!cls_out.p) {
+          cls_out.T = nb * t_total; cls_out.H = o.H; cls_out.W = o.W; cls_out.C = o.C;
+          cls_out.p = (bf16_t*)c->arena.alloc(cls_out.bytes(), true);
+          if (!cls_out.p) { dove_set_error("workspace exhausted (vae tile outputs: %zu bytes)", cls_out.bytes()); rc = DOVE_EINVAL; free_t(c, o); break; }
+          class_blocks.push_back(cls_out.p);
+        }
+        const long long oframe = (long long)o.H * o.W * o.C;
+        rc = copy2d(cls_out.p + (long long)t_done * oframe, (size_t)t_total * oframe * 2, o.p, (size_t)To * oframe * 2, (size_t)To * oframe * 2, nb, s);
+        t_done += To;
         free_t(c, o);
+        if (rc) break;
       }
       clear_caches(c);
-      free_t(c, xt);
+      c->nb = 1;
       if (!rc && t_done != t_total) { dove_set_error("vae tiling: a tile produced %d frames, expected %d", t_done, t_total); rc = DOVE_EINVAL; }
-      rows.back().push_back(tile);
+      if (rc) break;
+      for (int n = 0; n < nb; ++n) {
+        Tensor t; t.T = t_total; t.H = cls_out.H; t.W = cls_out.W; t.C = cls_out.C;
+        t.p = cls_out.p + (long long)n * t_total * cls_out.H * cls_out.W * cls_out.C;
+        rows[cl.members[m0 + n].first][cl.members[m0 + n].second] = t;
+      }
     }
   }
+  c->nb = 1;
   c->direct_io_convs = false;
   int Ho = 0, Wo = 0;
   if (!rc) {
@@ -1071,7 +1182,7 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
       y0 += ch;
     }
   }
-  for (auto& r : rows) for (auto& t : r) c->arena.release(t.p);
+  for (void* b : class_blocks) c->arena.release(b);
   return rc;
 }
 

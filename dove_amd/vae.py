@@ -105,6 +105,8 @@ class AutoencoderKLCogVideoX:
         self._streams = None
         # enable_tiling(): run all tiles of one shape as one batch (False: one tile at a time, the round-3 loop - kept for the A/B)
         self.tile_batching = True
+        self.tile_streams = 2
+        self._tile_stream = None
         self._pack(state_dict)
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -308,20 +310,35 @@ class AutoencoderKLCogVideoX:
             for a, i in enumerate(ii):
                 for b, j in enumerate(jj):
                     classes.setdefault((min(tile_h, H - i), min(tile_w, W - j)), []).append((a, b))
-            for (th, tw), members in sorted(classes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1])):
+            order = sorted(classes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
+            # tile_streams = 2: the largest class stays on the caller's stream, the edge classes (a fifth of the work at 720x1280) run
+            # on a second HIP stream - their launches fill the CUs the big class leaves idle in its partly filled last rounds and at
+            # the deep levels (a 30x45 latent tile is 2 x 2 conv tiles), and vice versa
+            side = None
+            if self.tile_streams > 1 and len(order) > 1 and x_cl.is_cuda:
+                if self._tile_stream is None:
+                    self._tile_stream = torch.cuda.Stream(device=self.device)
+                side, main = self._tile_stream, torch.cuda.current_stream()
+                side.wait_stream(main)                          # x_cl was produced on the caller's stream
+            for k, ((th, tw), members) in enumerate(order):
                 nb = len(members)
                 cache, parts = {}, []
                 self._nb = nb
-                try:
-                    for s, e in frame_batches(T, batch):
-                        xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
-                        o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
-                        parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
-                finally:
-                    self._nb = 1
-                out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
+                with torch.cuda.stream(side if (side is not None and k > 0) else None):
+                    try:
+                        for s, e in frame_batches(T, batch):
+                            xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
+                            o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
+                            parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
+                    finally:
+                        self._nb = 1
+                    out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
+                if side is not None and k > 0:
+                    out.record_stream(main)                     # blended / cropped on the caller's stream below
                 for n, (a, b) in enumerate(members):
                     rows[a][b] = out[n]
+            if side is not None:
+                main.wait_stream(side)
         else:
             for a, i in enumerate(ii):
                 for b, j in enumerate(jj):

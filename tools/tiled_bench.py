@@ -16,6 +16,7 @@ ap.add_argument("--mode", default="both")
 ap.add_argument("--frames", type=int, default=33)
 ap.add_argument("--height", type=int, default=720)
 ap.add_argument("--width", type=int, default=1280)
+ap.add_argument("--c-level", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 v, t, s = config.default_configs()
@@ -43,22 +44,37 @@ def tile_flop_ratio(H, W, th, tw, sh, sw):
 
 res = {}
 outs = {}
-for mode in (["untiled", "tiled_loop", "tiled"] if args.mode == "both" else [args.mode]):
+for mode in (["untiled", "tiled_loop", "tiled_1stream", "tiled"] if args.mode == "both" else [args.mode]):
     if mode.startswith("tiled"):
         vae.enable_slicing(); vae.enable_tiling()
-        vae.tile_batching = mode == "tiled"            # tiled_loop: one tile at a time (the round-3 path)
+        vae.tile_batching = mode != "tiled_loop"       # tiled_loop: one tile at a time (the round-3 path)
+        vae.tile_streams = 1 if mode == "tiled_1stream" else 2
     else:
         vae.disable_tiling()
     enc_ms, m = timed(lambda: vae.encode(video).latent_dist.parameters)
     dec_ms, d = timed(lambda: vae.decode(z, _range01=True).sample)
     res[mode] = {"encode_ms": enc_ms, "decode_ms": dec_ms, "vae_ms": enc_ms + dec_ms}
     outs[mode] = (m, d)
+if args.c_level:
+    # the same two modes through the graph-level C entry points (dove_vae_encode / dove_vae_decode with DOVE_OPT_VAE_TILING; one stream)
+    import copy
+    from dove_amd.graph import GraphContext
+    t1 = copy.deepcopy(t); t1["num_layers"] = 1
+    ctx = GraphContext(v, t1, weights.LazyStateDict(weights.vae_param_shapes(v), 1234, dev), weights.LazyStateDict(weights.dit_param_shapes(t1), 1234, dev), dev)
+    for mode in ("untiled", "tiled"):
+        ctx.enable_tiling(mode == "tiled")
+        enc_ms, m = timed(lambda: ctx.vae_encode(video[0]))
+        dec_ms, d = timed(lambda: ctx.vae_decode(z[0], range01=True))
+        res["c_level_" + mode] = {"encode_ms": enc_ms, "decode_ms": dec_ms, "vae_ms": enc_ms + dec_ms,
+                                  "bit_identical_to_python": bool(mode in outs and torch.equal(m, outs[mode][0][0]) and torch.equal(d, outs[mode][1][0])),
+                                  "workspace_high_water_gb": ctx.workspace_high_water() / 1e9}
 p = vae._tiling_params()
 re_, ne = tile_flop_ratio(args.height, args.width, p["smin_h"], p["smin_w"], int(p["smin_h"] * (1 - p["of_h"])), int(p["smin_w"] * (1 - p["of_w"])))
 rd_, nd = tile_flop_ratio(args.height // 8, args.width // 8, p["lmin_h"], p["lmin_w"], int(p["lmin_h"] * (1 - p["of_h"])), int(p["lmin_w"] * (1 - p["of_w"])))
 res["tiles"] = {"encode": ne, "decode": nd, "flop_ratio_encode": re_, "flop_ratio_decode": rd_}
 if "tiled_loop" in res and "tiled" in res:
-    res["loop_vs_batched_bit_identical"] = bool(torch.equal(outs["tiled"][0], outs["tiled_loop"][0]) and torch.equal(outs["tiled"][1], outs["tiled_loop"][1]))
+    res["loop_vs_batched_bit_identical"] = all(bool(torch.equal(outs[m][0], outs["tiled_loop"][0]) and torch.equal(outs[m][1], outs["tiled_loop"][1]))
+                                               for m in outs if m.startswith("tiled"))
 if "untiled" in res and "tiled" in res:
     res["tiled_vs_ideal"] = {"encode": res["untiled"]["encode_ms"] * re_ / res["tiled"]["encode_ms"],
                              "decode": res["untiled"]["decode_ms"] * rd_ / res["tiled"]["decode_ms"],
