@@ -224,6 +224,9 @@ class HaloCache(dict):
         self._posted = {}                               # name -> (buffer, work)
         self._sends = []
         self._dev = None
+        self.recv_blocking = 0                          # halos this stage fetched with a blocking receive (the recording pass)
+        self.recv_preposted = 0                         # ... and from a receive posted before the stage's first kernel
+        self.msg_bytes = []                             # size of every halo message sent, in conv order
 
     def _peer(self, r):
         return dist.get_global_rank(self.group, r) if self.group else r
@@ -245,10 +248,12 @@ class HaloCache(dict):
                 buf, work = self._posted.pop(name)
                 assert tuple(buf.shape) == tuple(like_shape), (name, buf.shape, like_shape)
                 work.wait()
+                self.recv_preposted += 1
                 return buf
             buf = torch.empty(like_shape, dtype=torch.bfloat16, device=device)
             _recv(buf, self._peer(self.rank - 1), self.group)
             self._record.append((name, tuple(like_shape)))
+            self.recv_blocking += 1
             return buf
         return self.get(name)
 
@@ -257,6 +262,10 @@ class HaloCache(dict):
         if self.phase in ("last", "both") and self.rank < self.world - 1:
             self._sends.append(_isend(new.contiguous(), self._peer(self.rank + 1), self.group))
             self.bytes_sent += new.numel() * 2
+            self.msg_bytes.append(new.numel() * 2)
+
+    def stats(self):
+        return dict(bytes_sent=self.bytes_sent, messages=list(self.msg_bytes), recv_blocking=self.recv_blocking, recv_preposted=self.recv_preposted)
 
     def finish(self):
         """End of the stage: every send has left, every posted receive was consumed, the plan is remembered."""
@@ -477,6 +486,7 @@ def encode_sharded(vae, x, group=None):
     outs, cache = _run_sharded(vae, x_cl, frame_batches(x_cl.shape[0], vae.enc_batch), world, rank, group, enc)
     moments = _gather_time(outs, group, world, vae.device)
     vae.last_halo_bytes = vae.last_halo_bytes_encode = cache.bytes_sent
+    vae.last_halo_stats_encode = cache.stats()
     return _SharedPosterior([moments], vae.lat, vae.dtype, group)
 
 
@@ -499,6 +509,7 @@ def decode_sharded(vae, z, group=None, _range01=False, _prescale=1.0, gather="al
                 for o in outs]
     post = dict(scale=0.5, shift=0.5, lo=0.0, hi=1.0) if _range01 else {}
     vae.last_halo_bytes = vae.last_halo_bytes_decode = cache.bytes_sent
+    vae.last_halo_stats_decode = cache.stats()
     if gather == "none":
         if not outs:
             return None

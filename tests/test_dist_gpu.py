@@ -115,3 +115,136 @@ def test_process_video_sharded_on_hip_bit_identical(world):
     assert res[0]["halo_bytes"] > 0
     bad = [r for r in res if not (r["equal"] and r["again"] and r["own"])]
     assert not bad, f"sharded result differs from the single-process one on ranks {[r['rank'] for r in bad]}: {bad[0]}"
+
+
+# ---- BASELINE configs[2] at its REAL size: 33x720x1280, 8 ranks (as 8 processes on the one GPU), full-width VAE, 2-layer DiT -------------
+RF, RH, RW = 33, 720, 1280
+HALO_L0_128 = 2 * 128 * RH * RW * 2          # 471 859 200 B: the 2-frame halo of a 128-channel conv at full resolution ("472 MB")
+HALO_L0_256 = 2 * 256 * RH * RW * 2          # 943 718 400 B: up_blocks.3's first conv reads the 256-channel upsampled tensor ("944 MB")
+
+
+def _real_inputs(t):
+    g = torch.Generator().manual_seed(5)
+    video = (torch.rand(1, 3, RF, RH, RW, generator=g) * 2 - 1).to(torch.bfloat16)
+    noise = torch.randn(1, 16, 1 + (RF - 1) // 4, RH // 8, RW // 8, generator=g)
+    text = torch.randn(226, t["text_embed_dim"], generator=g).to(torch.bfloat16)
+    return video, noise, text
+
+
+def _real_pipe(dev):
+    from dove_amd import config
+    from dove_amd.pipeline import CogVideoXPipeline
+    v, t, s = config.default_configs()                  # the CogVideoX1.5-5B VAE and DiT width; two DiT layers keep 8 processes light
+    t["num_layers"] = 2
+    return CogVideoXPipeline.from_config(v, t, s, seed=21, device=dev, init_device=dev), t
+
+
+def _real_worker(rank, world, port, q, ref_path):
+    import faulthandler
+    faulthandler.dump_traceback_later(560, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dove_amd import dist as ddist
+        pipe, t = _real_pipe(dev)
+        video, noise, text = (x.to(dev) for x in _real_inputs(t))
+        passes = []
+        import time
+        for _ in range(2):      # pass 1 records the halo plan (blocking receives), pass 2 runs on pre-posted receives only
+            torch.cuda.synchronize()
+            t0 = time.time()
+            mine = ddist.process_video_sharded(pipe, video, empty_prompt_embedding=text, posterior_noise=noise, gather="none")
+            torch.cuda.synchronize()
+            passes.append(dict(out=mine, s=time.time() - t0, enc=dict(pipe.vae.last_halo_stats_encode), dec=dict(pipe.vae.last_halo_stats_decode)))
+        nf = torch.tensor([0 if mine is None else mine.shape[2]])
+        counts = [torch.zeros(1, dtype=torch.long) for _ in range(world)]
+        dist.all_gather(counts, nf)
+        s0 = int(sum(int(x) for x in counts[:rank]))
+        ref = torch.load(ref_path)[:, :, s0:s0 + int(nf)].to(dev)
+        eq = [bool(p["out"] is not None and torch.equal(p["out"], ref)) for p in passes]
+        d = (passes[1]["out"].float() - ref.float()).abs()
+        q.put(dict(rank=rank, frames=int(nf), first=s0, equal=eq, max_diff=float(d.max()), n_diff=int((d > 0).sum()),
+                   seconds=[p["s"] for p in passes], enc=[p["enc"] for p in passes], dec=[p["dec"] for p in passes],
+                   peak_gb=torch.cuda.max_memory_allocated() / 1e9))
+    except BaseException:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_process_video_sharded_real_size_8_ranks(tmp_path):
+    """configs[2] - 33x720x1280, frame-chunk = 4, 8 ranks - at production size on the HIP kernels (8 processes on this box's one GPU,
+    gloo with host-staged wires): every rank's decoded frames (5,4,4,4,4,4,4,4) are BIT-IDENTICAL to the single-process result, on the
+    recording pass and on the pre-posted pass; the halo messages are the ones SURVEY.md 8(e) counts (six 472 MB halos in the encoder's
+    full-resolution block, eight of 472 MB + one of 944 MB in the decoder's); the second pass fetches EVERY halo from a receive posted
+    before the stage started (no blocking receive left).  Shard axis: /root/reference/inference_script.py:249-279, 690-703."""
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+    from dove_amd.inference import process_video
+    dev = torch.device("cuda", 0)
+    pipe, t = _real_pipe(dev)
+    video, noise, text = (x.to(dev) for x in _real_inputs(t))
+    ref = process_video(pipe, video, empty_prompt_embedding=text, posterior_noise=noise)
+    assert ref.shape == (1, 3, RF, RH, RW) and bool(torch.isfinite(ref).all())
+    ref_path = str(tmp_path / "ref.pt")
+    torch.save(ref.cpu(), ref_path)
+    del pipe, ref, video, noise, text
+    torch.cuda.empty_cache()
+    world = 8
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_real_worker, args=(r, world, port, q, ref_path), daemon=True) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res, t_end = [], time.time() + 580
+    try:
+        while time.time() < t_end and any(p.is_alive() for p in procs):
+            while not q.empty():
+                res.append(q.get())
+            if any("error" in r for r in res):
+                break
+            time.sleep(0.2)
+        while not q.empty():
+            res.append(q.get())
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            p.join(5)
+    errs = [r for r in res if "error" in r]
+    assert not errs, f"rank {errs[0]['rank']} failed:\n{errs[0]['error']}"
+    assert len(res) == world and all(p.exitcode == 0 for p in procs), f"rank exit codes {[p.exitcode for p in procs]}"
+    res.sort(key=lambda r: r["rank"])
+    print(f"[configs2 real size x8] {time.time() - t0:.0f} s; per rank: " + " | ".join(
+        f"r{r['rank']}: frames {r['frames']} eq {r['equal']} pass s {r['seconds'][0]:.1f}/{r['seconds'][1]:.1f} peak {r['peak_gb']:.1f} GB "
+        f"enc MB {r['enc'][1]['bytes_sent'] / 1e6:.0f} dec MB {r['dec'][1]['bytes_sent'] / 1e6:.0f}" for r in res))
+    assert [r["frames"] for r in res] == [5, 4, 4, 4, 4, 4, 4, 4]
+    bad = [r for r in res if not all(r["equal"])]
+    assert not bad, f"ranks {[r['rank'] for r in bad]} differ from the single-process result: {bad[0]['max_diff']} ({bad[0]['n_diff']} px)"
+    for r in res:
+        for stage, n128, n256 in (("enc", 6, 0), ("dec", 8, 1)):
+            for k in (0, 1):
+                st = r[stage][k]
+                if r["rank"] < world - 1:       # every rank but the last hands the halo of each causal conv to its successor
+                    assert st["messages"].count(HALO_L0_128) == n128 and st["messages"].count(HALO_L0_256) == n256, (r["rank"], stage, st["messages"])
+                    assert st["bytes_sent"] == sum(st["messages"]) == res[0][stage][k]["bytes_sent"]
+                else:
+                    assert st["bytes_sent"] == 0
+            n_halos = len(res[0][stage][0]["messages"])                # one per causal conv of the stage
+            if r["rank"] > 0:
+                assert r[stage][0]["recv_blocking"] == n_halos and r[stage][0]["recv_preposted"] == 0, (r["rank"], stage, r[stage][0])
+                assert r[stage][1]["recv_blocking"] == 0 and r[stage][1]["recv_preposted"] == n_halos, (r["rank"], stage, r[stage][1])
+            else:
+                assert r[stage][0]["recv_blocking"] == r[stage][1]["recv_preposted"] == 0
