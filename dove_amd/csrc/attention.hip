@@ -95,11 +95,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
   // FIXED (compile time, experiment) / fixed (run time): the caller bounds every score of this head (|q . k| <= max |q| max |k|, squared
   // norms from dove_qkv_post_bf16): a constant shift rides in the C operand and the loop needs no running maximum at all - the constant
-  // cancels in O / l.  Bounds above 60 (exp2 would leave the normal range for anti-aligned rows) fall back to the running maximum.
+  // cancels in O / l.  Bounds above 40 fall back to the running maximum: a row whose every key is anti-aligned has all its probabilities near
+  // 2^-2b, and 2^-80 keeps P, l and the P V products far inside the NORMAL fp32 / bf16 range (60, the first cutoff, left 2^-120 - six binades
+  // above the denormals, less than |v| can take away; LayerNorm'd q / k give b ~ 12).
   bool fixed = FIXED;
   if (bound) {
     const float b = FIXED ? bound[h] : 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);   // [head][q, k]: max squared row norms
-    fixed = FIXED || b <= 60.0f;
+    fixed = FIXED || b <= 40.0f;      // NaN compares false: the running maximum
     if (fixed) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) negm[r] = -b;

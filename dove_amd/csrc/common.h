@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the DOVE hot path.
 // wave = 64 lanes everywhere; bf16 is carried as raw uint16_t bit patterns.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,15 +36,17 @@ extern "C" void dove_set_error(const char* fmt, ...);
 
 // hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device: one flag per call site AND device, so a process that
 // drives several GPUs (dove_create(device) invites it) raises the limit on each of them
+// One limit for every per-device table of the library (this flag, igemm.hip's zero page and CU count).
+constexpr int DOVE_MAX_DEVICES = 32;
 struct PerDeviceOnce {
-  bool done[32] = {};
+  std::atomic<bool> done[DOVE_MAX_DEVICES] = {};
+  // true for exactly one caller per device - two host threads driving different (or the same) devices may race here; setting the
+  // attribute twice would be harmless, a torn read of a plain bool was not guaranteed to be
   bool first() {
     int d = 0;
     (void)hipGetDevice(&d);
-    if (d < 0 || d >= 32) return true;
-    if (done[d]) return false;
-    done[d] = true;
-    return true;
+    if (d < 0 || d >= DOVE_MAX_DEVICES) return true;
+    return !done[d].exchange(true, std::memory_order_acq_rel);
   }
 };
 

@@ -1736,18 +1736,21 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
 }
 
 // ---- host side -------------------------------------------------------------------------------
-static bf16_t* g_zero_page[16] = {nullptr};
+static std::atomic<bf16_t*> g_zero_page[DOVE_MAX_DEVICES] = {};
 
 static const bf16_t* zero_page() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!g_zero_page[dev]) {
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DOVE_MAX_DEVICES) return nullptr;
+  bf16_t* z = g_zero_page[dev].load(std::memory_order_acquire);
+  if (!z) {
     void* p = nullptr;
     if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
     if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
-    g_zero_page[dev] = (bf16_t*)p;
+    bf16_t* expect = nullptr;
+    if (g_zero_page[dev].compare_exchange_strong(expect, (bf16_t*)p, std::memory_order_acq_rel)) z = (bf16_t*)p;
+    else { (void)hipFree(p); z = expect; }                      // another host thread was first
   }
-  return g_zero_page[dev];
+  return z;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1884,16 +1887,16 @@ static int launch_igemm(const IgemmArgs& a, unsigned grid, bool fast, hipStream_
 }
 
 static int cu_count() {
-  static int cus[16] = {0};
+  static std::atomic<int> cus[DOVE_MAX_DEVICES] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (!cus[dev]) {
-    int n = 256;
+  int n = (dev >= 0 && dev < DOVE_MAX_DEVICES) ? cus[dev].load(std::memory_order_relaxed) : 0;
+  if (!n) {
+    n = 256;
     (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    cus[dev] = n;
+    if (dev >= 0 && dev < DOVE_MAX_DEVICES) cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus[dev];
+  return n;
 }
 
 extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {

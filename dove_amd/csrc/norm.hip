@@ -636,6 +636,8 @@ struct UlyPlaceArgs {
   long long N, Npad;
   long long bound[17];        // rows [bound[i], bound[i+1]) come from rank i
   long long off[17];          // element offset of rank i's block in a receive buffer
+  int extra;                  // 1: every source block carries ONE extra row per head (q, k) / column (v) behind its counts[i] rows - the
+  float* norm2_out;           //    K block's holds that rank's (max |q|^2, max |k|^2) of the head as two floats -> norm2_out [hloc][2] = max over ranks
 };
 __device__ __forceinline__ int uly_rank(const UlyPlaceArgs& a, long long n) {
   int i = 0;
@@ -644,6 +646,17 @@ __device__ __forceinline__ int uly_rank(const UlyPlaceArgs& a, long long n) {
 }
 __global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.y == 3) {                                        // the score bound that rode in the K blocks' extra rows
+    if (t >= a.hloc * 2) return;
+    const int h = (int)(t >> 1), e = (int)(t & 1);
+    float m = 0.f;
+    for (int i = 0; i < a.world; ++i) {
+      const long long ci = a.bound[i + 1] - a.bound[i];
+      m = fmaxf(m, ((const float*)(a.rk + a.off[i] + ((long long)h * (ci + 1) + ci) * 64))[e]);
+    }
+    a.norm2_out[t] = m;
+    return;
+  }
   if (blockIdx.y < 2) {                                         // Q', K': one 16-byte chunk (8 of the 64 d) of one row
     const long long total = (long long)a.hloc * a.N * 8;
     if (t >= total) return;
@@ -651,7 +664,7 @@ __global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a
     const long long n = (t >> 3) % a.N;
     const int h = (int)((t >> 3) / a.N);
     const int i = uly_rank(a, n);
-    const long long ci = a.bound[i + 1] - a.bound[i];
+    const long long ci = a.bound[i + 1] - a.bound[i] + a.extra;
     const bf16_t* src = (blockIdx.y == 0 ? a.rq : a.rk) + a.off[i] + ((long long)h * ci + (n - a.bound[i])) * 64 + c * 8;
     bf16_t* dst = (blockIdx.y == 0 ? a.Qh : a.Kh) + ((long long)h * a.Npad + n) * 64 + c * 8;
     *(uint4*)dst = *(const uint4*)src;
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a
       v[e] = 0;
       if (n < a.N) {
         const int i = uly_rank(a, n);
-        const long long ci = a.bound[i + 1] - a.bound[i];
+        const long long ci = a.bound[i + 1] - a.bound[i] + a.extra;
         v[e] = a.rv[a.off[i] + ((long long)h * 64 + d) * ci + (n - a.bound[i])];
       }
     }
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a
   }
 }
 extern "C" int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, const long long* counts, int world, int hloc, long long N,
-                                       long long Npad, void* Qh, void* Kh, void* Vt, void* stream) {
+                                       long long Npad, void* Qh, void* Kh, void* Vt, float* norm2_out, void* stream) {
   DOVE_CHECK_ARG(rq && rk && rv && counts && Qh && Kh && Vt, "ulysses_place: null pointer");
   DOVE_CHECK_ARG(world >= 1 && world <= 16 && hloc >= 1 && N > 0 && Npad >= N && Npad % 16 == 0, "ulysses_place: bad shape (world %d, hloc %d)", world, hloc);
   UlyPlaceArgs a;
@@ -693,13 +706,15 @@ extern "C" int dove_ulysses_place_bf16(const void* rq, const void* rk, const voi
   for (int i = 0; i < world; ++i) {
     DOVE_CHECK_ARG(counts[i] >= 0, "ulysses_place: negative row count");
     a.bound[i] = b; a.off[i] = o;
-    b += counts[i]; o += counts[i] * hloc * 64;
+    b += counts[i]; o += (counts[i] + (norm2_out ? 1 : 0)) * hloc * 64;
   }
+  a.extra = norm2_out ? 1 : 0;
+  a.norm2_out = norm2_out;
   a.bound[world] = b;
   DOVE_CHECK_ARG(b == N, "ulysses_place: the ranks' row counts add up to %lld, not N = %lld", b, N);
   const long long tq = (long long)hloc * N * 8, tv = (long long)hloc * 64 * (Npad >> 2);
   const long long tmax = tq > tv ? tq : tv;
-  dim3 grid((unsigned)((tmax + 255) / 256), 3);
+  dim3 grid((unsigned)((tmax + 255) / 256), norm2_out ? 4 : 3);
   hipLaunchKernelGGL(ulysses_place_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   DOVE_CHECK_LAUNCH("dove_ulysses_place_bf16");
   return DOVE_OK;

@@ -118,16 +118,6 @@ def _all_to_all(out, inp, out_splits, in_splits, group):
     out.copy_(h)
 
 
-def _all_reduce_max(t, group):
-    """In place element-wise maximum of a small fp32 tensor over the group (exact: every rank ends with the same bits)."""
-    if _direct(group) or not t.is_cuda:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        return
-    h = t.cpu()
-    dist.all_reduce(h, op=dist.ReduceOp.MAX, group=group)
-    t.copy_(h)
-
-
 def _broadcast(t, src, group):
     """In place on ``t`` (contiguous)."""
     if _direct(group) or not t.is_cuda:
@@ -138,13 +128,30 @@ def _broadcast(t, src, group):
     t.copy_(h)
 
 
+_group_serial: "weakref.WeakKeyDictionary" = None
+_group_count = [0]
+
+
 def _group_key(group):
-    """Stable identity of a process group for plan caches (``id(group)`` can be reused after a group is destroyed)."""
+    """Identity of a process group for plan caches and the poison list: its rank tuple and backend (``id(group)`` alone can be reused
+    after a group is destroyed) plus a serial number handed out the first time THIS group object is seen - a group re-created over the
+    same ranks (what the poison message asks for) is a new object, gets a new serial, and starts with a clean record."""
+    global _group_serial
+    import weakref
+    if _group_serial is None:
+        _group_serial = weakref.WeakKeyDictionary()
     g = group if group is not None else dist.group.WORLD
-    return (tuple(dist.get_process_group_ranks(g)), dist.get_backend(g))
+    try:
+        n = _group_serial.get(g)
+        if n is None:
+            _group_count[0] += 1
+            n = _group_serial[g] = _group_count[0]
+    except TypeError:                                     # a group type that cannot be weakly referenced: fall back to the object id
+        n = id(g)
+    return (tuple(dist.get_process_group_ranks(g)), dist.get_backend(g), n)
 
 
-_poisoned: set = set()          # groups on which a sharded call failed with receives still posted
+_poisoned: set = set()          # groups on which a sharded call failed part-way (peers may be mismatched from then on)
 
 
 # ---- (A) chunk farm ---------------------------------------------------------------------------------
@@ -277,10 +284,12 @@ class HaloCache(dict):
             HaloCache._plans[self.plan_key] = list(self._record)
 
     def abandon(self):
-        """A stage failed part-way: forget the plan; receives that are still posted cannot be recalled and would pair with the
-        NEXT call's halos, so the group is refused from now on (``_run_sharded``) instead of computing on stale buffers."""
+        """A stage failed part-way: forget the plan and refuse the group from now on (``_run_sharded``) instead of computing on stale
+        buffers - receives that are still posted cannot be recalled and would pair with the NEXT call's halos."""
         HaloCache._plans.pop(self.plan_key, None)
-        if self._posted:
+        # ANY failure inside a multi-rank stage can leave the peers mismatched (a blocking receive of the recording pass that never
+        # returned, sends still in flight, receives still posted): the next sharded call could pair its halos with stale messages
+        if self.world > 1:
             _poisoned.add(_group_key(self.group))
         self._posted.clear()
         self._sends.clear()
@@ -343,7 +352,7 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
     gn_group = _side_group(group) if paired else group
     gkey = _group_key(group)
     if gkey in _poisoned:
-        raise RuntimeError("dove_amd.dist: an earlier sharded call on this process group failed with halo receives still posted; "
+        raise RuntimeError("dove_amd.dist: an earlier sharded call on this process group failed part-way (its peers may hold unmatched halo messages); "
                            "destroy and re-create the process group before the next sharded call")
     cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, gkey))
     if not paired or gn_group is not None:
@@ -575,19 +584,24 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     # the re-interleave of the received [source rank][head][rows] blocks into the kernel's [head][all rows] layout (one launch).
     z = lambda *shp: torch.zeros(*shp, dtype=torch.bfloat16, device=dev)   # noqa: E731
     e = lambda *shp: torch.empty(*shp, dtype=torch.bfloat16, device=dev)   # noqa: E731
-    Ql, Kl, Vl = e(heads, nloc, 64), e(heads, nloc, 64), e(heads, 64, nloc)
+    # one extra row per head (column for V^T) behind the nloc rows: the K row carries this rank's score-bound pair of the head to the rank
+    # that owns the head (dove_ulysses_place_bf16), so the bound needs no collective of its own
+    Ql, Kl, Vl = z(heads, nloc + 1, 64), z(heads, nloc + 1, 64), z(heads, 64, nloc + 1)
     Qh, Kh, Vt = z(hloc, npad, 64), z(hloc, npad, 64), z(hloc, 64, npad)     # pad rows / columns stay zero across layers
     qscale = (tr.hd ** -0.5) * math.log2(math.e)
-    blk_in = [c * hloc * 64 for c in counts]                    # elements I receive from each source rank
-    blk_out = [nloc * hloc * 64] * world
-    rq, rk, rv = e(N * hloc * 64), e(N * hloc * 64), e(N * hloc * 64)
+    blk_in = [(c + 1) * hloc * 64 for c in counts]              # elements I receive from each source rank (rows + the extra row)
+    blk_out = [(nloc + 1) * hloc * 64] * world
+    ret_in, ret_out = [c * hloc * 64 for c in counts], [nloc * hloc * 64] * world     # the attention output's way back: rows only
+    rq, rk, rv = e((N + world) * hloc * 64), e((N + world) * hloc * 64), e((N + world) * hloc * 64)
     att = e(N, hloc * 64)
     back = e(nloc * hloc * 64 * world)
     att_loc = e(nloc, D)
-    # per-head score bound of the attention kernel (max squared q / k row norms): every rank takes the maximum over ITS rows of all heads,
-    # the element-wise maximum over the ranks is what one GPU computes over all rows (bit for bit), and my heads' slice goes to the kernel
+    # per-head score bound of the attention kernel (max squared q / k row norms): every rank takes the maximum over ITS rows of all heads;
+    # the element-wise maximum over the ranks is what one GPU computes over all rows (bit for bit).  The pairs travel in the K blocks of
+    # the all-to-all and the receive side reduces them for its heads
     norm2 = torch.empty(heads, 2, dtype=torch.float32, device=dev)
-    h0 = dist.get_rank(group) * hloc
+    norm2_mine = torch.empty(hloc, 2, dtype=torch.float32, device=dev)
+    k_extra = Kl[:, nloc, :4]                                   # [heads, 4] bf16 slots = two floats per head
 
     def a2a(out, inp, out_splits, in_splits):
         _all_to_all(out, inp, out_splits, in_splits, group)
@@ -595,18 +609,18 @@ def dit_forward_ulysses(tr, hidden, text, t, rope, group=None):
     for blk, md in zip(tr.blocks, blocks_mod):
         n1 = ops.layernorm_modulate(hs, blk["ln1"][0], blk["ln1"][1], tr.eps, md["m1"], lt_loc)
         qkv = ops.linear(n1, blk["qkv"])
-        ops.qkv_post(qkv, nloc, nloc, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
+        ops.qkv_post(qkv, nloc, nloc + 1, heads, lt_loc, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos_l, sin_l,
                      qscale, 1e-6, Ql, Kl, Vl, v_order=0, norm2=norm2)   # natural key order: the pieces are assembled below
-        _all_reduce_max(norm2, group)
+        k_extra.view(torch.float32).copy_(norm2)
         a2a(rq, Ql.view(-1), blk_in, blk_out)
         a2a(rk, Kl.view(-1), blk_in, blk_out)
         a2a(rv, Vl.view(-1), blk_in, blk_out)
         # [source rank][hloc][rows of that rank][64] (V^T: [hloc][64][rows]) -> the kernel's [hloc][all rows][64] / quad-swapped
         # [hloc][64][all rows] with zero pad columns: ONE launch (was 3 x world slice copies + a pad clear + an in-place swap)
-        ops.ulysses_place(rq, rk, rv, counts, hloc, N, npad, Qh, Kh, Vt)
-        ops.attention(Qh, Kh, Vt, N, npad, hloc, att, norm2=norm2[h0:h0 + hloc])
+        ops.ulysses_place(rq, rk, rv, counts, hloc, N, npad, Qh, Kh, Vt, norm2_out=norm2_mine)
+        ops.attention(Qh, Kh, Vt, N, npad, hloc, att, norm2=norm2_mine)
         # heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
-        a2a(back, att.view(-1), blk_out, blk_in)
+        a2a(back, att.view(-1), ret_out, ret_in)
         # [source rank = head group][my rows][hloc*64] -> [my rows][all heads]: one strided copy
         att_loc.view(nloc, world, hloc * 64).copy_(back.view(world, nloc, hloc * 64).permute(1, 0, 2))
         ops.linear(att_loc, blk["out"], resid=hs, gate=md["gate1"], gate_split=lt_loc, out=hs)

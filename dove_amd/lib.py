@@ -78,7 +78,7 @@ SIGNATURES = {
     "dove_layernorm_modulate_bf16": [_VP, _VP, _LL, _I, _F, _VP, _VP, _VP, _LL, _VP],
     "dove_qkv_post_bf16": [_VP, _LL, _LL, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _I, _VP, _VP],
     "dove_vt_quad_swap_bf16": [_VP, _LL, _LL, _VP],
-    "dove_ulysses_place_bf16": [_VP, _VP, _VP, C.POINTER(C.c_longlong), _I, _I, _LL, _LL, _VP, _VP, _VP, _VP],
+    "dove_ulysses_place_bf16": [_VP, _VP, _VP, C.POINTER(C.c_longlong), _I, _I, _LL, _LL, _VP, _VP, _VP, _VP, _VP],
     "dove_cl_im2col3x3_from_ncthw": [_VP, _I, _I, _I, _I, _I, _I, _F, _F, _VP, _VP],
     "dove_conv_out_gather": [_VP, _LL, _I, _I, _I, _I, _VP, _F, _F, _F, _F, _VP, _I, _VP],
     "dove_attention_fwd_bf16": [_VP, _VP, _VP, _VP, _LL, _LL, _I, _I, _LL, _VP, _VP],

@@ -336,17 +336,22 @@ def vt_quad_swap(Vt):
     return Vt
 
 
-def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
+def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt, norm2_out=None):
     """Receive side of the Ulysses all-to-all (include/dove_hip.h dove_ulysses_place_bf16): per-source-rank blocks of my heads ->
-    the attention kernel's head-major operands (V^T quad-swapped, pad columns zero) in one launch."""
-    L.require_cuda(rq, rk, rv, Qh, Kh, Vt)
+    the attention kernel's head-major operands (V^T quad-swapped, pad columns zero) in one launch.  ``norm2_out`` (fp32 [hloc, 2]): the
+    blocks carry one extra row per head and the K blocks' extra rows the ranks' score-bound pairs; their maximum is written here."""
+    L.require_cuda(rq, rk, rv, Qh, Kh, Vt, norm2_out)
+    if norm2_out is not None:
+        assert norm2_out.dtype == torch.float32 and norm2_out.shape == (hloc, 2)
     cnt = (C.c_longlong * len(counts))(*[int(c) for c in counts])
     L.check(L.load().dove_ulysses_place_bf16(L.ptr(rq), L.ptr(rk), L.ptr(rv), cnt, len(counts), hloc, N, Npad, L.ptr(Qh), L.ptr(Kh), L.ptr(Vt),
-                                             L.stream_ptr()), "dove_ulysses_place_bf16")
+                                             L.ptr(norm2_out), L.stream_ptr()), "dove_ulysses_place_bf16")
 
 
 def attention(Qh, Kh, Vt, N, Npad, heads, out, norm2=None):
-    """``norm2`` (fp32 [heads, 2] of THESE heads, from ``qkv_post``): constant-shift softmax instead of the running maximum."""
+    """``norm2`` (fp32 [heads, 2] of THESE heads, from the ``qkv_post`` call that produced Qh / Kh - or the element-wise maximum over the
+    ranks sharing the rows): constant-shift softmax instead of the running maximum.  A stale or sliced array that under-states the norms
+    silently breaks the softmax scaling (include/dove_hip.h): pass None when in doubt."""
     L.require_cuda(Qh, Kh, Vt, out, norm2)
     if norm2 is not None:
         assert norm2.dtype == torch.float32 and norm2.shape == (heads, 2) and norm2.is_contiguous()

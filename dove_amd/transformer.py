@@ -57,6 +57,11 @@ class CogVideoXTransformer3DModel:
             raise ValueError(f"attention_precision must be 'bf16' or 'mxfp8', got {attention_precision!r}")
         self.linear_precision = linear_precision
         self.attention_precision = attention_precision
+        # the bf16 attention kernel takes a per-head score bound from qkv_post and runs heads whose bound is <= 40 with a CONSTANT softmax
+        # shift (csrc/attention.hip): which heads do depends on the weights (the q / k LayerNorm gains).  False hands no bound over: every
+        # head keeps the running maximum (bench.py times both and reports the fraction; results agree to fp32 rounding of the row sums)
+        self.attn_score_bound = True
+        self.attn_bound_trace = None      # a list: every layer appends its [heads, 2] bound array (bench.py: share of heads on the fast path)
         self._mod_cache = {}
         self._bufs = {}
         self._pack(state_dict)
@@ -230,7 +235,9 @@ class CogVideoXTransformer3DModel:
             else:
                 ops.qkv_post(qkv, N, npad, Lh, Lt, blk["nq"][0], blk["nq"][1], blk["nk"][0], blk["nk"][1], cos, sin, qscale,
                              1e-6, Qh, Kh, Vt, norm2=norm2)
-                att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1, norm2=norm2)   # reuse n1's storage for the attention output
+                if self.attn_bound_trace is not None:
+                    self.attn_bound_trace.append(norm2.clone())
+                att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1, norm2=norm2 if self.attn_score_bound else None)   # reuse n1's storage for the attention output
             big(att, blk["out"], resid=hs, gate=md["gate1"], gate_split=Lt, out=hs)
             n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
             f1 = big(n2, blk["ff1"], act=1)

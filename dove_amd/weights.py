@@ -168,7 +168,8 @@ class LazyStateDict:
     def __getitem__(self, name):
         t = random_state_dict({name: self._shapes[name]}, self._seed, self._device, self._dtype)[name]
         if name in self._scale:
-            t = t * self._scale[name]
+            sc = self._scale[name]                        # a number, or a tensor broadcast over the weight (per-channel factors)
+            t = t * (sc.to(t.device, t.dtype) if torch.is_tensor(sc) else sc)
         return t if self._to is None else t.to(self._to)
 
     def get(self, name, default=None):

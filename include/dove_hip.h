@@ -163,15 +163,22 @@ int dove_vt_quad_swap_bf16(void* Vt, long long rows, long long Npad, void* strea
  * several GPUs): rq, rk = per source rank i the block [hloc][counts[i]][64], rv = [hloc][64][counts[i]] (natural key order), blocks in
  * rank order -> Qh, Kh [hloc][Npad][64] and Vt [hloc][64][Npad] quad-swapped with zero pad columns: the operands of
  * dove_attention_fwd_bf16 for this rank's hloc heads over all N = sum(counts) rows.  counts is a HOST array of `world` entries. */
+/* norm2_out (may be NULL; ABI 12): float [hloc][2].  When given, every source block carries ONE extra row per head (rq, rk: [hloc][counts[i] + 1][64])
+ * / column (rv: [hloc][64][counts[i] + 1]) behind its rows, and the extra row of the K block starts with two floats: that rank's
+ * (max |q row|^2, max |k row|^2) of the head over ITS rows (dove_qkv_post_bf16's norm2).  norm2_out = their maximum over the ranks = what one
+ * GPU computes over all rows, exactly - the attention's score bound rides in the all-to-all payload instead of a collective of its own. */
 int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, const long long* counts, int world, int hloc, long long N,
-                            long long Npad, void* Qh, void* Kh, void* Vt, void* stream);
+                            long long Npad, void* Qh, void* Kh, void* Vt, float* norm2_out, void* stream);
 
 /* F.scaled_dot_product_attention (no mask, non-causal) on the operands above, Vt in QUAD-SWAPPED key order; Qh carries
  * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64).
  * norm2 (may be NULL): float [heads][2] = max squared row norms of this call's Qh / Kh heads (dove_qkv_post_bf16).  With it, every
  * score of head h is bounded by b = 1.01 sqrt(norm2[h][0] norm2[h][1]) (Cauchy-Schwarz) and the softmax runs with that constant shift
- * instead of a running maximum (the constant cancels in O / l): -7 % kernel time.  Heads with b > 60 - where exp2 could leave the
- * normal fp32 range for anti-aligned rows - and calls with norm2 == NULL use the running maximum. */
+ * instead of a running maximum (the constant cancels in O / l): -7 % kernel time.  Heads with b > 40 (a row of all anti-aligned keys has
+ * every probability near 2^-2b: 2^-80 stays far inside the normal fp32 / bf16 range), heads with a non-finite bound and calls with
+ * norm2 == NULL use the running maximum.  CONTRACT: norm2 must be the array the dove_qkv_post_bf16 call that produced THESE Qh / Kh
+ * filled (or the element-wise maximum over the ranks that share the rows): a stale or sliced array that under-states a head's norms
+ * makes exp2 overflow for that head's largest scores, with nothing to catch it. */
 int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
                             int heads, int head_dim, long long ldo, const float* norm2, void* stream);
 

@@ -230,15 +230,22 @@ def vt_quad_swap(Vt):
     return Vt
 
 
-def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt):
-    """dove_ulysses_place_bf16: blocks [rank i][hloc][c_i][64] / [hloc][64][c_i] -> [hloc][Npad][64] / [hloc][64][Npad] (quad-swapped, zero pad)."""
+def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt, norm2_out=None):
+    """dove_ulysses_place_bf16: blocks [rank i][hloc][c_i][64] / [hloc][64][c_i] -> [hloc][Npad][64] / [hloc][64][Npad] (quad-swapped, zero pad).
+    With ``norm2_out`` every block has one extra row / column per head and the K block's extra row starts with that rank's two fp32 norms."""
     off = b = 0
+    x = 0 if norm2_out is None else 1
     Vt.zero_()
+    if x:
+        norm2_out.zero_()
     for c in counts:
-        n = c * hloc * 64
-        Qh[:, b:b + c] = rq[off:off + n].view(hloc, c, 64)
-        Kh[:, b:b + c] = rk[off:off + n].view(hloc, c, 64)
-        Vt[:, :, b:b + c] = rv[off:off + n].view(hloc, 64, c)
+        n = (c + x) * hloc * 64
+        Qh[:, b:b + c] = rq[off:off + n].view(hloc, c + x, 64)[:, :c]
+        kb = rk[off:off + n].view(hloc, c + x, 64)
+        Kh[:, b:b + c] = kb[:, :c]
+        Vt[:, :, b:b + c] = rv[off:off + n].view(hloc, 64, c + x)[:, :, :c]
+        if x:
+            norm2_out.copy_(torch.maximum(norm2_out, kb[:, c, :4].contiguous().view(torch.float32)))
         off += n
         b += c
     vt_quad_swap(Vt)

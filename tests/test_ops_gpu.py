@@ -446,9 +446,9 @@ def test_attention_spiked_rows():
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
     torch.cuda.synchronize()
     close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
-    # with the score bound: the spikes push it far above 60, so these heads must take the running-maximum path by themselves
+    # with the score bound: the spikes push it far above 40, so these heads must take the running-maximum path by themselves
     n2 = _norm2(Q, K, N).cuda()
-    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().min()) > 60.0
+    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().min()) > 40.0
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
     close("attention_spike_bound_fallback", got, ref, rtol=3e-2, afrac=8e-3)
@@ -460,8 +460,8 @@ def _norm2(Q, K, N):
 
 def test_attention_loose_bound():
     """Constant-shift softmax with a bound far above every real score: one long query row and one long key row that are orthogonal put
-    the Cauchy-Schwarz bound at ~50 (in base-2 exponent units) while the scores stay within +-3 - every probability is then ~2^-47
-    before the normalisation, which must not cost precision (fp32 range, bf16 keeps its 8 relative bits)."""
+    the Cauchy-Schwarz bound at ~36 (in base-2 exponent units, just under the kernel's cutoff of 40) while the scores stay within +-3 -
+    every probability is then ~2^-33 before the normalisation, which must not cost precision (fp32 range, bf16 keeps its 8 relative bits)."""
     N, heads = 700, 2
     npad = 768
     g = torch.Generator().manual_seed(23)
@@ -471,21 +471,56 @@ def test_attention_loose_bound():
     q = torch.randn(heads, N, 64, generator=g) * 0.3
     k = torch.randn(heads, N, 64, generator=g) * 0.3
     q[:, 11] = 0
-    q[:, 11, 0] = 7.0
+    q[:, 11, 0] = 6.0
     k[:, :, 0] = 0                                  # nothing answers the long query
     k[:, 500] = 0
-    k[:, 500, 1] = 7.0
+    k[:, 500, 1] = 6.0
     q[:, :, 1] = 0                                  # and nothing asks for the long key
     Q[:, :N], K[:, :N] = q.to(BF), k.to(BF)
     V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
     E.vt_quad_swap(V)
     n2 = _norm2(Q, K, N).cuda()
     b = 1.01 * (n2[:, 0] * n2[:, 1]).sqrt()
-    assert 45.0 < float(b.min()) and float(b.max()) < 60.0, b
+    assert 33.0 < float(b.min()) and float(b.max()) < 40.0, b
     ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
     close("attention_loose_bound", got, ref, rtol=3e-2, afrac=8e-3)
+
+
+def test_attention_bound_anti_aligned_at_cutoff():
+    """The adversarial case for the constant-shift softmax: EVERY key of a head is anti-aligned with EVERY query (q ~ +a e0, k ~ -a e0), so
+    every score sits at -b / 1.01 and every probability at 2^(-2b) before the normalisation, with b just under the kernel's cutoff (40):
+    2^-78 must still normalise to the exact softmax.  Head 1 has the same structure with b just ABOVE the cutoff: it must fall back to the
+    running maximum inside the same launch.  (norm2 must describe the Qh / Kh of the call: include/dove_hip.h.)"""
+    N, heads = 1000, 2
+    npad = 1024
+    g = torch.Generator().manual_seed(29)
+    Q = torch.zeros(heads, npad, 64, dtype=BF)
+    K = torch.zeros(heads, npad, 64, dtype=BF)
+    V = torch.zeros(heads, 64, npad, dtype=BF)
+    q = torch.randn(heads, N, 64, generator=g) * 0.15
+    k = torch.randn(heads, N, 64, generator=g) * 0.15
+    for h, a in enumerate((6.1, 6.6)):
+        q[h, :, 0] = a
+        k[h, :, 0] = -a
+    Q[:, :N], K[:, :N] = q.to(BF), k.to(BF)
+    V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
+    E.vt_quad_swap(V)
+    n2 = _norm2(Q, K, N).cuda()
+    b = 1.01 * (n2[:, 0] * n2[:, 1]).sqrt()
+    assert 36.0 < float(b[0]) < 40.0 < float(b[1]) < 50.0, b
+    ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    close("attention_anti_aligned", got, ref, rtol=3e-2, afrac=8e-3)
+    # a non-finite bound must not select the constant shift
+    bad = n2.clone()
+    bad[0, 0] = float("nan")
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=bad)
+    torch.cuda.synchronize()
+    close("attention_nan_bound", got, ref, rtol=3e-2, afrac=8e-3)
 
 
 @pytest.mark.parametrize("cin,cout,k,T,H,W,up,resid", [
@@ -845,7 +880,7 @@ def test_prodshape_attention_18226_sampled():
     npad = (N + 127) // 128 * 128
     g = torch.Generator().manual_seed(131)
     q = (torch.randn(heads, N, 64, generator=g) * 0.5).to(BF)          # Qh carries scale * log2(e): scores ~ N(0, 4) in base 2
-    k = (torch.randn(heads, N, 64, generator=g) * 0.7).to(BF)          # |q| |k| stays below the 60 above which the bound is not used
+    k = (torch.randn(heads, N, 64, generator=g) * 0.7).to(BF)          # |q| |k| stays below the 40 above which the bound is not used
     v = torch.randn(heads, 64, N, generator=g).to(BF)
     Q = torch.zeros(heads, npad, 64, dtype=BF)
     K = torch.zeros(heads, npad, 64, dtype=BF)

@@ -221,3 +221,200 @@ def test_mxfp8_dit_psnr_gate(full, attn):
     # plus a bound on the velocity error so a broken scale / layout (O(1) error) cannot hide behind the decoder
     assert e8 < 5.0 * e16 + 1e-2, (e8, e16)
     assert p816 > 35.0 and p8 > 35.0, (p8, p16, p816)
+
+
+# ---- heavy-tailed weights: the nearest thing to a trained checkpoint's statistics obtainable offline --------------------------------
+OUTLIER_CH = (5, 77, 1024, 1999, 2500, 3071)        # hidden channels that carry "massive activations"
+
+
+def heavy_tail_scales(v, t, seed=5):
+    """Per-tensor factors on top of the N(0, 1/fan_in) init: six hidden channels x50 in patch_embed.proj and in every block's ff.net.2
+    (massive-activation channels on the residual stream), six output channels x50 in the VAE mid-block convs (an outlier channel owns its
+    GroupNorm group's variance), LayerNorm gains log-uniform in [0.3, 3] (norm1 / norm2 / norm_final) and [0.5, 4] (norm_q / norm_k)."""
+    g = torch.Generator().manual_seed(seed)
+    D = t["num_attention_heads"] * t["attention_head_dim"]
+
+    def rows(n, idx, k=50.0):
+        f = torch.ones(n)
+        f[list(idx)] = k
+        return f
+
+    def loguni(n, lo, hi):
+        return torch.exp(torch.rand(n, generator=g) * (torch.log(torch.tensor(hi)) - torch.log(torch.tensor(lo))) + torch.log(torch.tensor(lo)))
+
+    sc_t = {"patch_embed.proj.weight": rows(D, OUTLIER_CH)[:, None], "norm_final.weight": loguni(D, 0.3, 3.0)}
+    for i in range(t["num_layers"]):
+        b = f"transformer_blocks.{i}."
+        sc_t[b + "ff.net.2.weight"] = rows(D, OUTLIER_CH)[:, None]
+        sc_t[b + "norm1.norm.weight"] = loguni(D, 0.3, 3.0)
+        sc_t[b + "norm2.norm.weight"] = loguni(D, 0.3, 3.0)
+        sc_t[b + "attn1.norm_q.weight"] = loguni(t["attention_head_dim"], 0.5, 4.0)
+        sc_t[b + "attn1.norm_k.weight"] = loguni(t["attention_head_dim"], 0.5, 4.0)
+    cm = v["block_out_channels"][-1]
+    sc_v = {}
+    for side in ("encoder", "decoder"):
+        for j in range(2):
+            for c in ("conv1", "conv2"):
+                sc_v[f"{side}.mid_block.resnets.{j}.{c}.conv.weight"] = rows(cm, (3, 100, 257, 300, 444, 511))[:, None, None, None, None]
+    return sc_v, sc_t
+
+
+@pytest.fixture(scope="module")
+def heavy(golden_dir):
+    from safetensors.torch import load_file
+    v, t, s = config.default_configs()
+    seed = 78
+    sc_v, sc_t = heavy_tail_scales(v, t)
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
+    for k, f in sc_v.items():
+        wv[k] = wv[k] * f
+    for k in ("decoder.conv_out.conv.weight", "decoder.conv_out.conv.bias"):
+        wv[k] = wv[k] * CONV_OUT_SCALE
+    wt_gpu = weights.LazyStateDict(weights.dit_param_shapes(t), seed, device="cuda", scale=sc_t)
+    pipe = CogVideoXPipeline(AutoencoderKLCogVideoX(v, wv, "cuda"), CogVideoXTransformer3DModel(t, wt_gpu, "cuda"), CogVideoXDPMScheduler(**s))
+    text = load_file(os.path.join(golden_dir, "empty_prompt_embedding.safetensors"))["prompt_embedding"].clone()
+    text[17] = text[17] * 30                                     # one text row far out of scale
+    F, H, W = 9, 256, 256
+    video = synth_clip(F, H, W, seed=4)
+    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=torch.Generator().manual_seed(10))
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    tr32, trbf = {}, {}
+    t0 = time.time()
+    ref = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt_gpu.moved("cpu")), s, video, text.float()[None], noise, trace=tr32)
+    refbf = odit.process_video(OracleVAE(v, wv, torch.bfloat16), odit.OracleDiT(t, wt_gpu.moved("cpu"), torch.bfloat16), s, video, text[None], noise,
+                               trace=trbf)
+    print(f"[heavy] fp32 + bf16-emulated oracle, 9x256x256 / 42 layers, heavy-tailed weights: {time.time() - t0:.1f} s")
+    return dict(pipe=pipe, cfg=(v, t, s), wv=wv, wt=wt_gpu, text=text, video=video, noise=noise, ref=ref, refbf=refbf, tr32=tr32, trbf=trbf)
+
+
+def test_heavy_tailed_weights_stagewise(heavy):
+    """The 42-layer stage-wise gates of test_e2e_256_north_star_tolerance_vs_bf16_reference, UNCHANGED (every stage <= 1.25 x the bf16
+    reference's own error + 1e-3; every residual stream <= 1.5 x + 2e-3; PSNR >= reference - 0.05 dB), on weights with seeded outliers:
+    massive-activation channels (x50) on the residual stream from patch_embed.proj and every ff.net.2, outlier channels in the VAE
+    mid-block convs, LayerNorm gains spread over a decade, q / k gains up to 4 (peaky attention rows; heads on either side of the
+    constant-shift cutoff), one text row x30.  Random-init N(0, 0.02^2)-style weights never show the kernels such tensors."""
+    pipe, text, video, noise, ref, refbf, tr32, trbf = (heavy[k] for k in ("pipe", "text", "video", "noise", "ref", "refbf", "tr32", "trbf"))
+    tr = pipe.transformer
+    tr.attn_bound_trace = []
+    st = hip_stages(pipe, video.cuda(), text, noise.cuda())
+    bt = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
+    tr.attn_bound_trace = None
+    got = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all())
+    hs = tr32["block41"][0]
+    ratio = float(hs[:, list(OUTLIER_CH)].abs().mean() / hs.abs().mean())
+    sat = float(((ref <= 0) | (ref >= 1)).float().mean())
+    keys = ("moments", "latent", "v", "x0", "decoded")
+    eh = {k: rms_rel(st[k], tr32[k]) for k in keys}
+    eb = {k: rms_rel(trbf[k], tr32[k]) for k in keys}
+    p_hip, p_bf = psnr(got.float().cpu(), ref), psnr(refbf.float(), ref)
+    print(f"[heavy] outlier channels carry {ratio:.1f} x the mean |residual|; attention score bound min / median / max "
+          f"{float(bt.min()):.1f} / {float(bt.median()):.1f} / {float(bt.max()):.1f}, constant-shift share {float((bt <= 40).float().mean()):.2f}; "
+          f"saturated pixels {100 * sat:.1f} %")
+    print(f"[heavy] PSNR vs fp32 oracle: hip {p_hip:.3f} dB, bf16 reference {p_bf:.3f} dB ({p_hip - p_bf:+.3f} dB)")
+    print("[heavy] rms-rel vs fp32 oracle (hip | bf16 reference): " + "  ".join(f"{k}:{eh[k]:.2e}|{eb[k]:.2e}" for k in keys))
+    rows = []
+    for name in ["embed"] + [f"block{i}" for i in range(42)]:
+        r32 = tr32[name][0]
+        rows.append((name, rms_rel(st["blocks"][name], r32), rms_rel(trbf[name][0], r32)))
+    print("[heavy] residual stream (hip | bf16 reference): " + "  ".join(f"{n}:{a:.1e}|{b:.1e}" for n, a, b in rows[::6] + rows[-1:]))
+    assert ratio > 5.0, "the outlier channels did not materialise on the residual stream"
+    assert p_hip >= p_bf - 0.05, (p_hip, p_bf)
+    for k in keys:
+        assert eh[k] <= 1.25 * eb[k] + 1e-3, (k, eh[k], eb[k])
+    for name, a, b in rows:
+        assert a <= 1.5 * b + 2e-3, (name, a, b)
+
+
+def test_heavy_tailed_weights_mxfp8_velocity(heavy):
+    """configs[4] on the same heavy-tailed weights: MXFP8 linears + attention, velocity error <= 5 x the bf16 path's + 1e-2 (the gate of
+    test_mxfp8_dit_psnr_gate, unchanged) - per-32-element block scales are what has to absorb the x50 channels."""
+    pipe, (v, t, s), text, tr32 = heavy["pipe"], heavy["cfg"], heavy["text"], heavy["tr32"]
+    tr8 = CogVideoXTransformer3DModel(t, heavy["wt"], "cuda", linear_precision="mxfp8", attention_precision="mxfp8")
+    latent = tr32["latent"]
+    B, T, C, h, w = latent.shape
+    rope = odit.rope_3d(64, T // 2, h // 2, w // 2)
+    kw = dict(hidden_states=latent.cuda().to(torch.bfloat16), encoder_hidden_states=text[None].cuda(), timestep=torch.tensor([399]).cuda(),
+              image_rotary_emb=tuple(r.cuda() for r in rope), return_dict=False)
+    v8 = tr8(**kw)[0]
+    v16 = pipe.transformer(**kw)[0]
+    torch.cuda.synchronize()
+    e8, e16 = rms_rel(v8, tr32["v"]), rms_rel(v16, tr32["v"])
+    print(f"[heavy mxfp8] velocity rms-rel vs fp32 oracle: mxfp8 {e8:.3e}  bf16 {e16:.3e}")
+    assert bool(torch.isfinite(v8).all())
+    assert e8 < 5.0 * e16 + 1e-2, (e8, e16)
+
+
+def test_dit_mixed_softmax_paths_wide_qk_gains(golden_dir):
+    """The bf16 attention kernel picks its softmax PER HEAD from the weights: constant shift when the score bound 1.01 |q|max |k|max is
+    <= 40, running maximum otherwise.  Random-init LayerNorm gains of 1 put every head on the fast path, so here norm_q / norm_k get
+    gains log-uniform in [0.5, 4] and norm_k is then rescaled so that the MEDIAN head of each layer sits at the cutoff: both paths and
+    their per-head mix run inside one launch (asserted from the bound arrays), at N = 4458 tokens, 2 layers of the full-width DiT,
+    against the fp32 oracle with the bf16-emulated reference as the yardstick (<= 1.5 x + 2e-3 per residual stream)."""
+    from safetensors.torch import load_file
+    v, t, s = config.default_configs()
+    t["num_layers"] = 2
+    seed = 91
+    g = torch.Generator().manual_seed(6)
+    hd = t["attention_head_dim"]
+
+    def loguni(n, lo, hi):
+        lo, hi = torch.log(torch.tensor(lo)), torch.log(torch.tensor(hi))
+        return torch.exp(torch.rand(n, generator=g) * (hi - lo) + lo)
+
+    sc = {}
+    for i in range(2):
+        b = f"transformer_blocks.{i}.attn1."
+        sc[b + "norm_q.weight"], sc[b + "norm_k.weight"] = loguni(hd, 0.5, 4.0), loguni(hd, 0.5, 4.0)
+    text = load_file(os.path.join(golden_dir, "empty_prompt_embedding.safetensors"))["prompt_embedding"]
+    latent = torch.randn(1, 4, 16, 92, 92, generator=g)          # 2 x 46 x 46 = 4232 video tokens + 226 text rows
+    rope = odit.rope_3d(64, 2, 46, 46)
+    ts = torch.tensor([399])
+    kw = dict(hidden_states=latent.cuda().to(torch.bfloat16), encoder_hidden_states=text[None].cuda(), timestep=ts.cuda(),
+              image_rotary_emb=tuple(r.cuda() for r in rope), return_dict=False)
+
+    def build(scale):
+        wt = weights.LazyStateDict(weights.dit_param_shapes(t), seed, device="cuda", scale=scale)
+        return wt, CogVideoXTransformer3DModel(t, wt, "cuda")
+
+    def bounds(tr):
+        tr.attn_bound_trace = []
+        blocks = {}
+        vh = tr(**kw, _trace=blocks)[0]
+        torch.cuda.synchronize()
+        b = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
+        tr.attn_bound_trace = None
+        return vh, blocks, b
+
+    # calibration, layer by layer (layer 1's input depends on layer 0's attention): scale k's LayerNorm (weight AND bias: k -> f k exactly)
+    for i in range(2):
+        _, tr = build(sc)
+        _, _, b = bounds(tr)
+        f = 40.0 / float(b[i].median())
+        for nm in ("norm_k.weight", "norm_k.bias"):
+            key = f"transformer_blocks.{i}.attn1.{nm}"
+            sc[key] = sc.get(key, 1.0) * f
+        del tr
+    wt, tr = build(sc)
+    vh, blocks, b = bounds(tr)
+    frac = (b <= 40.0).float().mean(dim=1)
+    print(f"[mixed softmax] score bounds per layer: min {b.min(dim=1).values.tolist()} max {b.max(dim=1).values.tolist()}; constant-shift share {frac.tolist()}")
+    assert all(0.15 < float(x) < 0.85 for x in frac), f"no per-head mix of the two softmax paths: {frac.tolist()}"
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    tr32, trbf = {}, {}
+    v32 = odit.OracleDiT(t, wt.moved("cpu")).forward(latent, text.float()[None], ts, rope, tr32)
+    vbf = odit.OracleDiT(t, wt.moved("cpu"), torch.bfloat16).forward(latent, text[None], ts, rope, trbf)
+    for name in ("embed", "block0", "block1"):
+        r32 = tr32[name][0]
+        eh, eb = rms_rel(blocks[name], r32), rms_rel(trbf[name][0], r32)
+        print(f"[mixed softmax] {name}: hip {eh:.2e}  bf16 reference {eb:.2e}")
+        assert eh <= 1.5 * eb + 2e-3, (name, eh, eb)
+    ev, evb = rms_rel(vh, v32), rms_rel(vbf, v32)
+    print(f"[mixed softmax] velocity: hip {ev:.2e}  bf16 reference {evb:.2e}")
+    assert ev <= 1.5 * evb + 2e-3, (ev, evb)
+    # the same forward with NO bound handed over (running maximum in every head) is the same function
+    tr.attn_score_bound = False
+    v_rm = tr(**kw)[0]
+    torch.cuda.synchronize()
+    assert rms_rel(v_rm, vh) < 5e-3, rms_rel(v_rm, vh)

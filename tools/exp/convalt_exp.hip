@@ -1,0 +1,164 @@
+// EXPERIMENT (tools/convalt.py): two structural alternatives for the dominant kernel (conv3x3_halo4x), measured on a model of its K walk:
+// one wave per SIMD (256 threads, 1 workgroup per CU, 512 registers per lane), 256 accumulator registers, every operand fragment read
+// from LDS with ds_read_b128, one barrier per 32-MFMA step, no global traffic (the LDS-DMA staging of the real kernel is not modelled: the
+// model is an UPPER bound for both variants).
+//
+//  MODE 0  baseline: halo4x's register tile - 4 x 4 accumulator blocks of 32 x 32, 8 fragment reads per 16 MFMAs (1 read : 2 MFMA... per
+//          step 16 reads : 32 MFMAs)
+//  MODE 1   the same walk with GroupNorm-apply + SiLU done IN LDS on the staged halo slab: in 6 of the 9 steps of a
+//          group every lane rewrites the two 16-byte slots it staged (ds_read_b128, a / b of its 8 channels from a table in LDS, 8 x
+//          (x a + b), SiLU = mul, v_exp, add, v_rcp, mul, border mask, 4 v_cvt_pk, ds_write_b128), interleaved one slice per MFMA gap
+//  MODE 2   Winograd F(2x2, 3x3): 16 transform-domain positions are 16 INDEPENDENT GEMMs, so the 256 accumulator
+//          registers hold 16 blocks that share NO operand: every MFMA needs its own A and its own B fragment (2 reads : 1 MFMA)
+//  MODE 3  Winograd F(2, 3) along W only (4 positions, 1.5 x fewer MACs): 4 positions x (2 x 2 blocks): 1 read : 1 MFMA
+//  MODE 4  baseline tile with NO fragment reads in the loop (registers only): the matrix pipe's own rate in this harness
+// Per mode the host reports ns per 32-MFMA step and the equivalent dense rate; speed-up of a variant = (MAC reduction) x (rate ratio).
+#include "../../dove_amd/csrc/common.h"
+
+constexpr int LDS_BYTES = 147456;          // as halo4x: forces one workgroup per CU
+
+__device__ __forceinline__ bf16x8 lds128(const char* smem, int off) { return *(const bf16x8*)(smem + off); }
+
+// one slice of the GN-apply rewrite: element e (0..7) of the lane's 16-byte slot
+struct GnSlot { uint4 raw; f32x4 a0, a1, b0, b1; float f[8]; };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restrict__ init, float* __restrict__ out, int groups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // fill LDS with N(0,1)-like bf16 (the matrix pipes throttle with operand toggling: constants would flatter every variant)
+  for (int i = tid; i < LDS_BYTES / 16; i += 256) ((uint4*)smem)[i] = ((const uint4*)init)[(blockIdx.x * 131 + i) % 8192];
+  __syncthreads();
+  f32x16 acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int abase = ((4 * wave) * 34 + l31) * 80 + hi * 16;           // halo rows of 80 B, like the product kernel
+  const int bbase = 98304 + l31 * 64 + hi * 16;                        // weight ring behind the two halo buffers
+  const int slot0 = (wave * 64 + lane) * 16;                           // the lane's own staged slot of a round
+  const int tab = 147456 - 4096 + (lane & 3) * 64;                     // a[8], b[8] of the lane's channel chunk
+  float sink = 0.f;
+
+  for (int g = 0; g < groups; ++g) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int toff = (tap / 3) * 34 * 80 + (tap % 3) * 80;
+      if (MODE == 0 || MODE == 1 || MODE == 4) {
+        bf16x8 xf[2][4], wf[2][4];
+        if (MODE != 4) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              xf[kk][p] = lds128(smem, abase + toff + p * 34 * 80 + kk * 32);
+              wf[kk][p] = lds128(smem, bbase + (tap % 6) * 8192 + p * 2048 + kk * 32);
+            }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { xf[kk][p] = lds128(smem, abase + p * 128 + kk * 32); wf[kk][p] = lds128(smem, bbase + p * 2048 + kk * 32); }
+          if (g > 0 || tap > 0) {                                      // registers only after the first step
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+              for (int p = 0; p < 4; ++p) { asm volatile("" : "+v"(xf[kk][p]), "+v"(wf[kk][p])); }
+          }
+        }
+        const bool rewrite = MODE == 1 && tap >= 2 && tap <= 7;        // rounds staged two steps earlier have landed
+        GnSlot s0, s1;
+        if (rewrite) {
+          s0.raw = *(const uint4*)(smem + 49152 + (2 * (tap - 2)) * 4096 + slot0);
+          s1.raw = *(const uint4*)(smem + 49152 + (2 * (tap - 2) + 1) * 4096 + slot0);
+          s0.a0 = *(const f32x4*)(smem + tab); s0.a1 = *(const f32x4*)(smem + tab + 16); s0.b0 = *(const f32x4*)(smem + tab + 32); s0.b1 = *(const f32x4*)(smem + tab + 48);
+          s1.a0 = s0.a0; s1.a1 = s0.a1; s1.b0 = s0.b0; s1.b1 = s0.b1;
+          unpack8(s0.raw, s0.f); unpack8(s1.raw, s1.f);
+        }
+        const bool inside = ((lane * 7 + tap) & 31) != 0;              // border mask stand-in (per lane)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              acc[i * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][p], acc[i * 4 + p], 0, 0, 0);
+              if (rewrite) {                                           // one slice of the rewrite per MFMA gap: 16 slices = 2 slots x 8 elements
+                const int q = (kk * 16 + i * 4 + p);
+                if (q < 16) {
+                  GnSlot& s = (q < 8) ? s0 : s1;
+                  const int e = q & 7;
+                  const float a = e < 4 ? s.a0[e & 3] : s.a1[e & 3], b = e < 4 ? s.b0[e & 3] : s.b1[e & 3];
+                  const float y = s.f[e] * a + b;
+                  s.f[e] = inside ? silu_f(y) : 0.f;
+                }
+              }
+            }
+        if (rewrite) {
+          *(uint4*)(smem + 49152 + (2 * (tap - 2)) * 4096 + slot0) = pack8(s0.f);
+          *(uint4*)(smem + 49152 + (2 * (tap - 2) + 1) * 4096 + slot0) = pack8(s1.f);
+        }
+      } else if (MODE == 2) {
+        // 16 positions, one 32 x 32 block each: A and B fragment per MFMA
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int pos = 0; pos < 16; ++pos) {
+            const bf16x8 xv = lds128(smem, abase + (pos & 3) * 34 * 80 + (pos >> 2) * 160 + kk * 32 + toff % 2720);
+            const bf16x8 wv = lds128(smem, bbase + (tap % 6) * 8192 + (pos & 3) * 2048 + (pos >> 2) * 512 + kk * 32);
+            acc[pos] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xv, acc[pos], 0, 0, 0);
+          }
+      } else if (MODE == 3) {
+        // 4 positions, 2 x 2 blocks each: 4 fragment reads per 4 MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int pos = 0; pos < 4; ++pos) {
+            bf16x8 xv[2], wv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              xv[j] = lds128(smem, abase + pos * 34 * 80 + j * 160 + kk * 32 + toff % 2720);
+              wv[j] = lds128(smem, bbase + (tap % 6) * 8192 + pos * 2048 + j * 512 + kk * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int p = 0; p < 2; ++p) acc[pos * 4 + i * 2 + p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i], xv[p], acc[pos * 4 + i * 2 + p], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // (no drain inside the loop: fp32 accumulators of N(0,1) products stay far inside the range over 10^5 steps)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[k][r];
+    out[((size_t)blockIdx.x * 16 + k) * 256 + tid] = t + sink;
+  }
+}
+
+extern "C" void dove_set_error(const char*, ...) {}
+template <int MODE>
+static int launch(const void* init, void* out, int groups, int blocks, hipStream_t s) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)convalt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); once = true; }
+  hipLaunchKernelGGL((convalt_kernel<MODE>), dim3(blocks), dim3(256), LDS_BYTES, s, (const bf16_t*)init, (float*)out, groups);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int convalt(int mode, const void* init, void* out, int groups, int blocks, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (mode) {
+    case 0: return launch<0>(init, out, groups, blocks, s);
+    case 1: return launch<1>(init, out, groups, blocks, s);
+    case 2: return launch<2>(init, out, groups, blocks, s);
+    case 3: return launch<3>(init, out, groups, blocks, s);
+    case 4: return launch<4>(init, out, groups, blocks, s);
+    default: return -1;
+  }
+}
