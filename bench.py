@@ -283,7 +283,7 @@ def main():
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         all_igemm = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         # PMC-derived fields are NOT measured in this run: they are replayed from the committed summary of a separate
-        # `rocprofv3 --pmc` pass over this same command (tools/gpu_pmc_bench.sh) and labelled as such
+        # `rocprofv3 --pmc` pass over this same command (tools/runs/gpu_pmc_bench.sh) and labelled as such
         traffic = None
         pmc_busy = None
         pmc_src = None
@@ -298,7 +298,7 @@ def main():
             seen = len(dom) // max(args.steps, 1)
             if pk is None or int(pk.get("launches", -1)) != seen:
                 pmc_src = (f"profiles/pmc_traffic.json NOT replayed: it holds {None if pk is None else pk.get('launches')} launches of {DOM} per clip, "
-                           f"this run made {seen} - re-run tools/gpu_pmc_bench.sh")
+                           f"this run made {seen} - re-run tools/runs/gpu_pmc_bench.sh")
                 pj = None
         if os.path.exists(pmc) and pj is not None:
             traffic = pj.get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
@@ -327,7 +327,7 @@ def main():
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
                          "share_of_step_time": dom_ms / (elapsed * 1e3),
                          # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) from profiles/pmc_traffic.json
-                         # (separate rocprofv3 --pmc pass over this command, tools/gpu_pmc_bench.sh)
+                         # (separate rocprofv3 --pmc pass over this command, tools/runs/gpu_pmc_bench.sh)
                          "mfma_pipe_busy_frac_pmc": pmc_busy,
                          "all_igemm_kernels": {"achieved": all_igemm, "frac": all_igemm / MFMA_BF16_PEAK_TFLOPS,
                                                "share_of_step_time": tot_ms / (elapsed * 1e3), "launches": len(records) // max(args.steps, 1)},

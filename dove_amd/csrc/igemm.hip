@@ -18,242 +18,12 @@
 // double-buffered with one barrier per K-step.  MFMA operands are swapped (A = weights, B = pixels) so
 // each lane ends up with 4 consecutive output channels of one pixel -> 8-byte epilogue stores.
 // Epilogue: +bias, GELU(tanh), residual add, row-class-dependent gate (AdaLN-Zero), bf16 store.
-#include <stdlib.h>
+#include "igemm_args.h"
 
-#include <type_traits>
-
-#include "common.h"
-#include "../../include/dove_hip.h"
-
-// tools/*_timing.py hand a device buffer to the NEXT conv call (per-phase s_memtime logs / ablation operands).  It used to be a field
-// of dove_conv_desc; the product struct no longer carries it - the hook exists in libdove_hip_timing.so only.
 #ifdef DOVE_TIMING_BUILD
-static void* g_timing_debug_buf = nullptr;
+void* g_timing_debug_buf = nullptr;
 extern "C" int dove_timing_set_debug_buf(void* p) { g_timing_debug_buf = p; return 0; }
-#define DOVE_DBG_BUF g_timing_debug_buf
-#else
-#define DOVE_DBG_BUF ((void*)nullptr)
 #endif
-
-// Work-skipping ablation switches and s_memtime phase logs exist ONLY in a -DDOVE_TIMING_BUILD library (built by the
-// tools/*_timing.py helpers into a separate file); in the product build DOVE_DBG() is the constant 0, the branches fold
-// away, no timing instantiation is emitted and no environment variable can make a kernel skip work.
-#ifdef DOVE_TIMING_BUILD
-#define DOVE_DBG(a) ((a).debug)
-#else
-#define DOVE_DBG(a) 0
-#endif
-
-struct IgemmArgs {
-  const bf16_t* x;
-  const bf16_t* cache;
-  const bf16_t* w;
-  const float* bias;
-  const bf16_t* resid;
-  const float* gate;
-  bf16_t* out;
-  const bf16_t* zero;
-  int T_out, H_out, W_out;
-  int T_in, H_in, W_in;
-  int Cin, Cout_pad, Cout_st;
-  int kt, kh, kw, stride, pad_h, pad_w, up, tmode, act;
-  long long ldo, ldr;
-  long long gate_split;
-  int tw_log2, tiles_w, tiles_h, tiles_n;
-  int debug;  // -DDOVE_TIMING_BUILD only (tools/, never the product library): 1 skip A loads, 2 skip B loads, 4 skip MFMA
-  float* gn_partial;   // conv3x3_halo4x only: fused GroupNorm(32) partial sums of the stored output, [rows][32][2]
-  int cpg_log;         // log2(channels per group) = log2(Cout / 32)
-  int out_f32;         // igemm_fast only: `out` is float [..][ldo] (no bf16 rounding): the tap-split conv_out's partial sums
-  int nt_out;          // gemm8p only: nontemporal output stores (outputs larger than the Infinity Cache: see conv_dispatch)
-  // dove_conv_desc.nb independent instances back to back along the frame axis (the tile-batched VAE): T_out / T_in above are the TOTALS
-  // (nb x per-instance), seg_out / seg_in the per-instance frame counts; temporal taps, the conv cache and tmode are per instance
-  int seg_out, seg_in;
-  long long cache_bs;  // elements between two instances' cache frames
-};
-
-// frame of the INPUT a temporal tap reads: output frame t (global index over all instances), tap dt of kt (causal: taps before an
-// instance's first frame come from its conv cache, or replicate its frame 0), or the tmode map of the upsample convs (kt == 1)
-__device__ __forceinline__ const bf16_t* igemm_src_frame(const IgemmArgs& a, int t, int dt, long long frame_elems) {
-  const int b = a.seg_out == a.T_out ? 0 : t / a.seg_out;
-  const int tl = t - b * a.seg_out;
-  const long long f0 = (long long)b * a.seg_in;
-  if (a.kt > 1) {
-    const int fv = tl + dt - (a.kt - 1);
-    if (fv >= 0) return a.x + (f0 + fv) * frame_elems;
-    if (a.cache) return a.cache + (long long)b * a.cache_bs + (long long)(a.kt - 1 + fv) * frame_elems;
-    return a.x + f0 * frame_elems;
-  }
-  const int tin = a.tmode == 0 ? tl : (a.tmode == 1 ? (tl >> 1) : (tl == 0 ? 0 : 1 + ((tl - 1) >> 1)));
-  return a.x + (f0 + tin) * frame_elems;
-}
-
-template <int BN, int BK>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-  constexpr int BM = 128;
-  constexpr int CPR = BK / 8;                  // 16-byte chunks per tile row
-  constexpr int CPR_LOG = (BK == 64) ? 3 : 2;
-  constexpr int RPG = 256 / CPR;               // tile rows covered by one 256-lane glds pass
-  constexpr int NA = BM / RPG;                 // A passes per K-step
-  constexpr int B_SLOTS = BN * CPR;
-  constexpr int NB = (B_SLOTS + 255) / 256;
-  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int WN = (BN >= 128) ? 2 : 1, WM = 4 / WN;
-  constexpr int PT = (BM / WM) / 32, CT = (BN / WN) / 32;
-  constexpr int KK = BK / 16;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-
-  unsigned rest = xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = rest % a.tiles_n; rest /= a.tiles_n;
-  const int twi = rest % a.tiles_w; rest /= a.tiles_w;
-  const int thi = rest % a.tiles_h;
-  const int t = rest / a.tiles_h;
-  const int n0 = tn * BN;
-  const int TWm = (1 << a.tw_log2) - 1;
-  const int oh0 = thi * (128 >> a.tw_log2), ow0 = twi << a.tw_log2;
-  const int H_eff = a.H_in << a.up, W_eff = a.W_in << a.up;
-
-  // ---- per-thread staging geometry (fixed for the whole K loop) ----
-  const int cs = tid & (CPR - 1);
-  const int rsub = tid >> CPR_LOG;
-  const int c = (BK == 64) ? (cs ^ ((rsub >> 1) & 7)) : (cs ^ ((rsub >> 2) & 3));
-  int ih0[NA], iw0[NA];
-  bool mval[NA];
-#pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int m = j * RPG + rsub;
-    const int oh = oh0 + (m >> a.tw_log2), ow = ow0 + (m & TWm);
-    mval[j] = (oh < a.H_out) && (ow < a.W_out);
-    ih0[j] = oh * a.stride - a.pad_h;
-    iw0[j] = ow * a.stride - a.pad_w;
-  }
-  const long long frame_elems = (long long)a.H_in * a.W_in * a.Cin;
-  const int kc_per_tap = a.Cin / BK;
-  const int nk = a.kt * a.kh * a.kw * kc_per_tap;
-
-  auto stage = [&](int buf, int tap, int kc) {
-    const int dw = tap % a.kw;
-    const int dh = (tap / a.kw) % a.kh;
-    const int dt = tap / (a.kw * a.kh);
-    const bf16_t* fp = igemm_src_frame(a, t, dt, frame_elems);
-    const int k0 = kc * BK + c * 8;
-    char* As = smem + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const int ih = ih0[j] + dh, iw = iw0[j] + dw;
-      const bool ok = mval[j] && ((unsigned)ih < (unsigned)H_eff) && ((unsigned)iw < (unsigned)W_eff);
-      const long long off = ((long long)(ih >> a.up) * a.W_in + (iw >> a.up)) * a.Cin + k0;
-      const bf16_t* src = ok ? (fp + off) : a.zero;
-      glds16(src, As + (j * 256 + wave * 64) * 16);
-    }
-    char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j * 256 + wave * 64 < B_SLOTS) {
-        const int row = j * RPG + rsub;
-        const bf16_t* src = a.w + ((long long)tap * a.Cout_pad + n0 + row) * a.Cin + k0;
-        glds16(src, Bs + (j * 256 + wave * 64) * 16);
-      }
-    }
-  };
-
-  f32x16 acc[CT][PT];
-#pragma unroll
-  for (int i = 0; i < CT; ++i)
-#pragma unroll
-    for (int p = 0; p < PT; ++p)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  stage(0, 0, 0);
-  int tap_n = 0, kc_n = 1;  // coordinates of the NEXT K-step to stage
-  if (kc_n == kc_per_tap) { kc_n = 0; tap_n = 1; }
-
-  for (int it = 0; it < nk; ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 1 < nk) {
-      stage((it + 1) & 1, tap_n, kc_n);
-      if (++kc_n == kc_per_tap) { kc_n = 0; ++tap_n; }
-    }
-    const char* As = smem + (it & 1) * STAGE;
-    const char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const int chunk = kk * 2 + hi;
-      bf16x8 xf[PT], wf[CT];
-#pragma unroll
-      for (int p = 0; p < PT; ++p) {
-        const int row = wm * (BM / WM) + p * 32 + l31;
-        const int sc = (BK == 64) ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
-        xf[p] = *(const bf16x8*)(As + row * (BK * 2) + sc * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < CT; ++i) {
-        const int row = wn * (BN / WN) + i * 32 + l31;
-        const int sc = (BK == 64) ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
-        wf[i] = *(const bf16x8*)(Bs + row * (BK * 2) + sc * 16);
-      }
-#pragma unroll
-      for (int i = 0; i < CT; ++i)
-#pragma unroll
-        for (int p = 0; p < PT; ++p)
-          acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
-    }
-  }
-
-  // ---- epilogue: lane holds pixel (lane&31), channels 8*g + 4*(lane>>5) + {0..3} of each 32x32 tile ----
-#pragma unroll
-  for (int p = 0; p < PT; ++p) {
-    const int m = wm * (BM / WM) + p * 32 + l31;
-    const int oh = oh0 + (m >> a.tw_log2), ow = ow0 + (m & TWm);
-    if (!((oh < a.H_out) && (ow < a.W_out))) continue;
-    const long long pix = ((long long)t * a.H_out + oh) * a.W_out + ow;
-    const float* gate = a.gate ? (a.gate + (pix < a.gate_split ? 0 : a.Cout_pad)) : nullptr;
-#pragma unroll
-    for (int i = 0; i < CT; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cb = n0 + wn * (BN / WN) + i * 32 + 8 * g + 4 * hi;
-        if (cb >= a.Cout_st) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][p][g * 4 + e];
-        if (a.bias) {
-          const f32x4 b = *(const f32x4*)(a.bias + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-        if (a.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_f(v[e]);
-        }
-        if (a.resid) {
-          const uint2 rr = *(const uint2*)(a.resid + pix * a.ldr + cb);
-          float r[4] = {__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u),
-                        __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
-          if (gate) {
-            const f32x4 gg = *(const f32x4*)(gate + cb);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = r[e] + gg[e] * v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          }
-        }
-        uint2 o;
-        o.x = pack_bf2(v[0], v[1]);
-        o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(a.out + pix * a.ldo + cb) = o;
-      }
-    }
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Fast path (up == 0: every conv except the upsample-fused one, and every linear).
@@ -266,7 +36,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 //   * tap / channel-chunk / frame advance is scalar state (SGPR adds), the K offset rides in soffset;
 //   * ds_read addresses are per-lane constants + compile-time (buffer, operand) immediates (loop unrolled x2).
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int BN, int BK>
 struct FastCfg {
@@ -449,7 +218,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const IgemmArgs a) {
     compute(B0{});
   }
 
-  // ---- epilogue (identical to igemm_kernel) ----
+  // ---- epilogue (the generic one: igemm_legacy.hip's igemm_kernel has the same) ----
 #pragma unroll
   for (int p = 0; p < PT; ++p) {
     const int m = wm * (Cf::BM / Cf::WM) + p * 32 + l31;
@@ -1059,385 +828,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 //   gemm4x_kernel (round 2's kernel, TIMING build only, for the within-run A/B of tools/gemm8p_ab.py): ONE wave per SIMD (512-register
 //     budget), 4 waves = 2 x 2 wave tiles of 128 x 128, 4-stage K-32 ring staged 3 steps ahead with counted vmcnt, fragments
 //     register-pipelined across the single per-step barrier, pinned MFMA / VMEM / DS interleave.
-namespace gemm4x {
-constexpr int BM = 256, BN = 256, BK = 32, ROWB = 64;
-constexpr int A_ST = BM * ROWB, ST = A_ST + BN * ROWB;      // 16384 + 16384 per stage
-constexpr int NST = 4;
-constexpr int EPI = NST * ST;                                // epilogue staging: 4 waves x 32 rows x 256 B (XOR-swizzled)
-constexpr int LDS_BYTES = EPI + 4 * 8192;                    // 163840 = all of a CU's LDS
-}  // namespace gemm4x
-struct G4Tile { int m0, n0; };
-struct G4Const { int ntiles, G, tiles_n, nk4, K; long long M; };
-struct G4State {                                             // the operand chunk (4 K-steps) being staged next
-  int n_tile, n_k4;
-  bool n_on;
-  const bf16_t *a_base, *w_base;
-  int a_nrec, w_nrec, soff;
-};
-__device__ __forceinline__ G4Tile g4_decode(const G4Const& k, int id) {
-  const unsigned rest = xcd_remap((unsigned)(id < k.ntiles ? id : k.ntiles - 1), (unsigned)k.ntiles);
-  // rasterisation: groups of GM row-tiles, row-tile fastest inside a group - the 32 CUs of an XCD (32 consecutive logical
-  // tiles) then cover 8 x 4 tiles, i.e. 12 distinct operand panels per K step instead of 33, and every weight panel is
-  // re-read from HBM / MALL once per 8 row-tiles instead of once per row-tile
-  // (narrow outputs - N = 3072: 12 column tiles - keep the plain column-fastest order: their whole weight matrix is
-  //  re-used by 2-3 row-tiles of the same XCD batch anyway and the plain order measured 3 % faster there)
-  const unsigned GM = k.tiles_n > 16 ? 8u : 1u;
-  const unsigned tiles_m = (unsigned)(k.ntiles / k.tiles_n);
-  const unsigned per_group = GM * (unsigned)k.tiles_n;
-  const unsigned group = rest / per_group, within = rest - group * per_group;
-  const unsigned left = tiles_m - group * GM;
-  const unsigned gm = left < GM ? left : GM;
-  G4Tile q;
-  q.m0 = __builtin_amdgcn_readfirstlane((int)(group * GM + within % gm) * gemm4x::BM);
-  q.n0 = __builtin_amdgcn_readfirstlane((int)(within / gm) * gemm4x::BN);
-  return q;
-}
-__device__ __forceinline__ void g4_open_tile(G4State& s, const IgemmArgs& a, const G4Const& k, int id) {
-  s.n_tile = id;
-  s.n_on = id < k.ntiles;
-  const G4Tile q = g4_decode(k, id);
-  const long long left = k.M - q.m0;
-  const int rows = left < gemm4x::BM ? (int)left : gemm4x::BM;
-  s.a_base = a.x + (long long)q.m0 * k.K;
-  s.w_base = a.w + (long long)q.n0 * k.K;
-  s.a_nrec = s.n_on ? rows * k.K * 2 : 0;                     // rows past M: offset >= num_records -> zeros in LDS
-  s.w_nrec = s.n_on ? gemm4x::BN * k.K * 2 : 0;
-  s.n_k4 = 0;
-  s.soff = 0;
-}
-__device__ __forceinline__ void g4_advance(G4State& s, const IgemmArgs& a, const G4Const& k) {
-  if (++s.n_k4 == k.nk4) g4_open_tile(s, a, k, s.n_tile + k.G);
-  s.soff = s.n_k4 * (4 * gemm4x::ROWB);
-}
-
-#ifdef DOVE_TIMING_BUILD
-// kSched: where a K step's 8 LDS-DMA instructions sit among its 32 MFMAs.
-//   1 (product): eight FENCED groups of { 1 LDS-DMA, 2 fragment reads, 4 MFMAs } with a sched_barrier between groups.  The four waves of
-//      a workgroup run a step in lockstep, so a burst of 8 DMAs per wave is 32 KB through the CU's one address path (~16 clocks per
-//      1 KB instruction) inside ~256 clocks; one per 128 clocks and wave keeps that path at half load.  Fragment reads are ordered so
-//      that no MFMA waits for a read issued in the group right before it (all four x fragments first, then the w fragments in the
-//      order the MFMA rows use them).  +4.5-7 % on the DiT linears within a run (profiles/r03_gemm4x_sched.log).
-//   0 (round-2 order, kept for the A/B in the timing library): the DMAs asked for in gaps 8-15 by sched_group_barrier - which hipcc
-//      turns into a burst right behind the step barrier whatever pattern is requested (three patterns tried): only a sched_barrier
-//      fence keeps an LDS-DMA where the source puts it.
-template <bool kAct, bool kGate, bool kTiming = false, int kSched = 1>
-__global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long long M) {
-  using namespace gemm4x;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __builtin_assume(wave >= 0 && wave < 4);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  G4Const kc;
-  kc.K = a.Cin;
-  kc.M = M;
-  kc.tiles_n = a.tiles_n;
-  kc.ntiles = (int)((M + BM - 1) / BM) * a.tiles_n;
-  kc.G = (int)gridDim.x;
-  kc.nk4 = a.Cin / (4 * BK);
-  const int ntiles = kc.ntiles, G = kc.G, nk4 = kc.nk4;
-
-  // staging lane offsets (same for x and w: both are K-contiguous rows): wave w moves rows 64w .. 64w+63 of either tile,
-  // 16 rows x 4 chunks per instruction; the source chunk is XOR-swizzled so the fragment reads are bank-conflict free
-  unsigned voff[4];
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int row = (wave * 4 + jj) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);
-    voff[jj] = (unsigned)((row * a.Cin + c * 8) * 2);
-  }
-  // `st` is touched only by the g4_* functions; what the steps consume is copied into plain locals (see conv3x3_halo4x)
-  G4State st;
-  const bf16_t *ca_base = a.x, *cw_base = a.w, *na_base = a.x, *nw_base = a.w;
-  int ca_nrec = 0, cw_nrec = 0, c_soff = 0, na_nrec = 0, nw_nrec = 0, n_soff = 0;
-  auto publish = [&](const G4State& q) {                      // cur <- nxt, nxt <- q
-    ca_base = na_base; cw_base = nw_base; ca_nrec = na_nrec; cw_nrec = nw_nrec; c_soff = n_soff;
-    na_base = q.a_base; nw_base = q.w_base; na_nrec = q.a_nrec; nw_nrec = q.w_nrec; n_soff = q.soff;
-  };
-  auto stage = [&](auto slotc, const bf16_t* ab, int anrec, const bf16_t* wb, int wnrec, int soff) {
-    constexpr int slot = decltype(slotc)::value;
-    const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)ab, (short)0, anrec, 0x00020000);
-    const auto srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)wb, (short)0, wnrec, 0x00020000);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + slot * ST + wave * 4096 + jj * 1024), 16, voff[jj], soff, 0, 0);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + slot * ST + A_ST + wave * 4096 + jj * 1024), 16, voff[jj], soff,
-                                               0, 0);
-  };
-
-  // fragment offsets: token rows wm*128 + p*32 + l31, weight rows wn*128 + i*32 + l31; two bases each so that every slot
-  // is reachable with a 16-bit immediate (slots 2, 3 start at 64 KB)
-  int aoff[2][4][2], boff[2][4][2];
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ra = wm * 128 + p * 32 + l31, rb = wn * 128 + p * 32 + l31;
-      aoff[0][p][kk] = ra * ROWB + (((kk * 2 + hi) ^ ((ra >> 2) & 3)) << 4);
-      boff[0][p][kk] = A_ST + rb * ROWB + (((kk * 2 + hi) ^ ((rb >> 2) & 3)) << 4);
-      aoff[1][p][kk] = aoff[0][p][kk] + 2 * ST;
-      boff[1][p][kk] = boff[0][p][kk] + 2 * ST;
-      // opaque to the optimizer: otherwise it keeps one base per operand and re-derives the rest with a v_add in front
-      // of every ds_read (VALU work and waits inside the MFMA stream)
-      asm volatile("" : "+v"(aoff[0][p][kk]), "+v"(aoff[1][p][kk]), "+v"(boff[0][p][kk]), "+v"(boff[1][p][kk]));
-    }
-  auto load_a = [&](auto kkc, auto slotc, bf16x8 (&xf)[4]) {
-    constexpr int kk = decltype(kkc)::value, slot = decltype(slotc)::value;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + aoff[slot >> 1][p][kk] + (slot & 1) * ST);
-  };
-  auto load_b = [&](auto kkc, auto slotc, bf16x8 (&wf)[4]) {
-    constexpr int kk = decltype(kkc)::value, slot = decltype(slotc)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(smem + boff[slot >> 1][i][kk] + (slot & 1) * ST);
-  };
-  f32x16 acc[4][4];
-  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-
-  // ---- prologue (once per workgroup): K-steps 0, 1, 2 of the first tile ----
-  g4_open_tile(st, a, kc, (int)blockIdx.x);
-  publish(st);                                                // nxt = chunk 0 of the first tile
-  stage(std::integral_constant<int, 0>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff);
-  stage(std::integral_constant<int, 1>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + ROWB);
-  stage(std::integral_constant<int, 2>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + 2 * ROWB);
-  g4_advance(st, a, kc);
-  publish(st);                                                // cur = chunk 0, nxt = its successor
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
-  load_a(I0{}, I0{}, xa);
-  load_b(I0{}, I0{}, wa);
-  unsigned long long tm_wait = 0, tm_bar = 0, tm_walk = 0, tm_epi = 0, tm_n = 0, tm0 = 0, tm1 = 0;
-
-  // one K-step (32 deep) of chunk cur; u = step within the chunk = its ring slot
-  auto step = [&](auto uc) {
-    constexpr int u = decltype(uc)::value;
-    using Slot = std::integral_constant<int, u>;
-    using NSlot = std::integral_constant<int, (u + 1) & 3>;
-    using SSlot = std::integral_constant<int, (u + 3) & 3>;
-    unsigned long long tq0 = 0, tq1 = 0;
-    if (kTiming) { tq0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // all but the previous step's 8 loads have landed,
-    if (kTiming) { tq1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-    __builtin_amdgcn_s_barrier();                               // then the step barrier (LDS hand-off point)
-    if (kTiming) { const unsigned long long tq2 = __builtin_amdgcn_s_memtime(); tm_wait += tq1 - tq0; tm_bar += tq2 - tq1; }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- from here to the end of the step: ONE basic block ----
-    if (kSched == 1) {
-      const bf16_t* sab = u == 0 ? ca_base : na_base;            // step 3 of this chunk / steps 0..2 of the next one
-      const bf16_t* swb = u == 0 ? cw_base : nw_base;
-      const int sanr = u == 0 ? ca_nrec : na_nrec, swnr = u == 0 ? cw_nrec : nw_nrec;
-      const int ssoff = u == 0 ? c_soff + 3 * ROWB : n_soff + (u - 1) * ROWB;
-      const auto srd_a = __builtin_amdgcn_make_buffer_rsrc((void*)sab, (short)0, sanr, 0x00020000);
-      const auto srd_w = __builtin_amdgcn_make_buffer_rsrc((void*)swb, (short)0, swnr, 0x00020000);
-      constexpr int sslot = (u + 3) & 3, slot = u, nslot = (u + 1) & 3;
-#pragma unroll
-      for (int gq = 0; gq < 8; ++gq) {
-        const int i = gq & 3;
-        // this group's two fragment reads: groups 0, 1 (4, 5) all four x fragments of k-half 1 (of the next step's k-half 0), groups
-        // 2, 3 (6, 7) the w fragments; x / w of k-half 0 are dead after group 3
-        auto rd = [&](bf16x8 (&xf)[4], bf16x8 (&wf)[4], int kk, int sl) {
-          if (i < 2) {
-            xf[2 * i] = *(const bf16x8*)(smem + aoff[sl >> 1][2 * i][kk] + (sl & 1) * ST);
-            xf[2 * i + 1] = *(const bf16x8*)(smem + aoff[sl >> 1][2 * i + 1][kk] + (sl & 1) * ST);
-          } else {
-            wf[2 * i - 4] = *(const bf16x8*)(smem + boff[sl >> 1][2 * i - 4][kk] + (sl & 1) * ST);
-            wf[2 * i - 3] = *(const bf16x8*)(smem + boff[sl >> 1][2 * i - 3][kk] + (sl & 1) * ST);
-          }
-        };
-        if (gq < 4) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_a, (lds_ptr_t)(smem + sslot * ST + wave * 4096 + i * 1024), 16, voff[i], ssoff, 0, 0);
-          rd(xb, wb, 1, slot);
-#pragma unroll
-          for (int pp = 0; pp < 4; ++pp) acc[i][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i], xa[pp], acc[i][pp], 0, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_w, (lds_ptr_t)(smem + sslot * ST + A_ST + wave * 4096 + i * 1024), 16, voff[i], ssoff, 0, 0);
-#pragma unroll
-          for (int pp = 0; pp < 4; ++pp) acc[i][pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i], xb[pp], acc[i][pp], 0, 0, 0);
-          rd(xa, wa, 0, nslot);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      return;
-    }
-    if (u == 0) stage(SSlot{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + 3 * ROWB);   // step 3 of this chunk
-    else stage(SSlot{}, na_base, na_nrec, nw_base, nw_nrec, n_soff + (u - 1) * ROWB);    // steps 0..2 of the next one
-    load_a(I1{}, Slot{}, xb);
-    load_b(I1{}, Slot{}, wb);
-    mma(wa, xa);
-    load_a(I0{}, NSlot{}, xa);
-    load_b(I0{}, NSlot{}, wa);
-    mma(wb, xb);
-    {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                // 1 MFMA
-        if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 ds_read (k-half 1 fragments)
-        else {
-          if (i == 8) __builtin_amdgcn_sched_group_barrier(0x004, 8, 0);  // SALU: descriptors before the first load,
-          else __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);         //       then only m0
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 VMEM read (LDS-DMA)
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // next step's k-half 0 fragments
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // epilogue-side lane role: 8 lanes x 8 columns cover 64 columns (128 B) of one output row
-  const int e_px = lane >> 3, e_ch = lane & 7;
-  for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
-    if (kTiming) tm0 = __builtin_amdgcn_s_memtime();
-    const G4Tile c = g4_decode(kc, tile);
-    const int col0 = c.n0 + wn * 128;
-    f32x4 bias_r[2][2], gate_r[2][2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int cb = col0 + h * 64 + e_ch * 8;
-      bias_r[h][0] = bias_r[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias) { bias_r[h][0] = *(const f32x4*)(a.bias + cb); bias_r[h][1] = *(const f32x4*)(a.bias + cb + 4); }
-      if (kGate) {
-#pragma unroll
-        for (int cls = 0; cls < 2; ++cls) {
-          gate_r[cls][h][0] = *(const f32x4*)(a.gate + (long long)cls * a.Cout_pad + cb);
-          gate_r[cls][h][1] = *(const f32x4*)(a.gate + (long long)cls * a.Cout_pad + cb + 4);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
-
-    for (int kq = 0; kq < nk4; ++kq) {
-      step(std::integral_constant<int, 0>{});
-      step(std::integral_constant<int, 1>{});
-      step(std::integral_constant<int, 2>{});
-      step(std::integral_constant<int, 3>{});
-      __builtin_amdgcn_sched_barrier(0);
-      g4_advance(st, a, kc);
-      publish(st);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    if (kTiming) tm1 = __builtin_amdgcn_s_memtime();
-    // ---- epilogue: the wave's 128 x 128 result, one 32-row block x 64 columns at a time through its own 8 KB LDS slice
-    // (fp32, XOR-swizzled 256-B rows), then 16-B stores with 8 lanes covering a full 128-B line ----
-    {
-      char* const eslice = smem + EPI + wave * 8192;
-      unsigned o_off[4], r_off[4];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int px = it * 8 + e_px;
-        o_off[it] = (unsigned)((px * (int)a.ldo + e_ch * 8) * 2);
-        r_off[it] = (unsigned)((px * (int)a.ldr + e_ch * 8) * 2);
-      }
-      auto emit = [&](auto has_resid) {
-        constexpr bool kRes = decltype(has_resid)::value;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const long long row0 = (long long)c.m0 + wm * 128 + p * 32;
-          const long long vl = M - row0;
-          const int rows = vl >= 32 ? 32 : (vl > 0 ? (int)vl : 0);     // rows past M: offset >= num_records -> dropped
-          const auto srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + row0 * a.ldo + col0), (short)0,
-                                                               rows * (int)a.ldo * 2, 0x00020000);
-          const auto srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.resid + row0 * a.ldr + col0 : a.out), (short)0,
-                                                               kRes ? rows * (int)a.ldr * 2 : 0, 0x00020000);
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            u32x4 rr[4];
-            if (kRes) {
-#pragma unroll
-              for (int it = 0; it < 4; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 128, 0);
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-              for (int gq = 0; gq < 4; ++gq) {
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[h * 2 + i2][p][gq * 4 + e];
-                const int ch = i2 * 8 + 2 * gq + hi;                   // 16-B chunk of the 256-B row
-                *(f32x4*)(eslice + l31 * 256 + ((ch ^ (l31 & 15)) << 4)) = o;
-              }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private slice: no barrier needed
-            f32x4 lo[4], hi4[4];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              const int px = it * 8 + e_px;
-              lo[it] = *(const f32x4*)(eslice + px * 256 + (((2 * e_ch) ^ (px & 15)) << 4));
-              hi4[it] = *(const f32x4*)(eslice + px * 256 + (((2 * e_ch + 1) ^ (px & 15)) << 4));
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
-              if (kAct) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { x0[e] = gelu_tanh_f(x0[e]); x1[e] = gelu_tanh_f(x1[e]); }
-              }
-              if (kRes) {
-                const u32x4 r = rr[it];
-                const f32x4 r0 = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
-                                  __uint_as_float(r[1] & 0xffff0000u)};
-                const f32x4 r1 = {__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16),
-                                  __uint_as_float(r[3] & 0xffff0000u)};
-                if (kGate) {
-                  const bool vid = row0 + it * 8 + e_px >= a.gate_split;   // row class: text rows first
-                  const f32x4 g0 = vid ? gate_r[1][h][0] : gate_r[0][h][0];
-                  const f32x4 g1 = vid ? gate_r[1][h][1] : gate_r[0][h][1];
-                  x0 = r0 + g0 * x0;
-                  x1 = r1 + g1 * x1;
-                } else {
-                  x0 += r0;
-                  x1 += r1;
-                }
-              }
-              const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
-              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 128, 0);
-              // store-data hazard (found on MI355X): the 16-B store reads its data VGPRs for the last lanes a few cycles after
-              // issue; the next iteration's first VALU writes re-used them and its fp32 intermediates were stored instead
-              __builtin_amdgcn_sched_barrier(0);
-              asm volatile("s_nop 3" ::: "memory");
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-        }
-      };
-      if (a.resid) emit(std::true_type{});
-      else emit(std::false_type{});
-    }
-    // the counted-vmcnt scheme of the K walk restarts from an empty queue (stores count in vmcnt on gfx9)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (kTiming) { const unsigned long long tm2 = __builtin_amdgcn_s_memtime(); tm_walk += tm1 - tm0; tm_epi += tm2 - tm1; ++tm_n; }
-  }
-  if (kTiming && a.zero && blockIdx.x == 100 && lane == 0) {     // TIMING build: `zero` carries the host's debug buffer
-    unsigned long long* o = (unsigned long long*)a.zero + wave * 8;
-    o[0] = tm_walk; o[1] = tm_wait; o[2] = tm_bar; o[3] = tm_epi; o[4] = tm_n; o[5] = (unsigned long long)nk4 * 4;
-  }
-}
-
-#endif  // DOVE_TIMING_BUILD (gemm4x_kernel)
+// (gemm4x's tile constants, the supertile walk g4_* and IgemmArgs live in igemm_args.h; gemm4x_kernel itself in gemm4x_timing.hip)
 
 // ------------------------------------------------------------------------------------------------
 // gemm8p: gemm4x's GEMM (same 256 x 256 tile, same persistent tile walk and supertile order, same arithmetic: results are bit-identical)
@@ -1873,15 +1264,11 @@ static bool desc_size_ok(const dove_conv_desc* d, const char* who) {
 extern "C" const char* dove_conv_kernel_name(const dove_conv_desc* d) { return desc_size_ok(d, "conv_kernel_name") ? kKernelNames[select_kernel(d)] : ""; }
 
 template <int BN, int BK>
-static int launch_igemm(const IgemmArgs& a, unsigned grid, bool fast, hipStream_t s) {
+static int launch_igemm_fast(const IgemmArgs& a, unsigned grid, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
-    (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }
-  if (fast) hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
+  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16");
   return DOVE_OK;
 }
@@ -2024,29 +1411,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
         // its round-2 DMA order (tools/gemm4x_sched.py); a debug buffer selects the s_memtime instantiations (tools/gemm*_timing.py)
         const char* e8 = getenv("DOVE_GEMM8P");
         if (e8 && atoi(e8) == 0) {
-          static PerDeviceOnce attr4g;
-          if (attr4g.first()) {
-            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-            (void)hipFuncSetAttribute((const void*)(gemm4x_kernel<false, false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
-          }
           const char* es = getenv("DOVE_GEMM4X_SCHED");
-          if (DOVE_DBG_BUF && d->act == 0 && !d->gate) {
-            a.zero = (const bf16_t*)DOVE_DBG_BUF;
-            hipLaunchKernelGGL((gemm4x_kernel<false, false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          } else if (es && atoi(es) == 0 && !d->gate && d->act == 0) {
-            hipLaunchKernelGGL((gemm4x_kernel<false, false, false, 0>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          } else if (d->gate) {
-            hipLaunchKernelGGL((gemm4x_kernel<false, true>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          } else if (d->act == 1) {
-            hipLaunchKernelGGL((gemm4x_kernel<true, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          } else {
-            hipLaunchKernelGGL((gemm4x_kernel<false, false>), dim3(grid4), dim3(256), gemm4x::LDS_BYTES, s, a, M);
-          }
-          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm4x)");
-          return DOVE_OK;
+          int variant = 0;
+          if (DOVE_DBG_BUF && d->act == 0 && !d->gate) { a.zero = (const bf16_t*)DOVE_DBG_BUF; variant = 3; }
+          else if (es && atoi(es) == 0 && !d->gate && d->act == 0) variant = 4;
+          else if (d->gate) variant = 2;
+          else if (d->act == 1) variant = 1;
+          return launch_gemm4x_timing(a, M, grid4, variant, s);
         }
         if (DOVE_DBG_BUF) {
           static PerDeviceOnce attr8t;
@@ -2138,7 +1509,8 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   DOVE_CHECK_ARG(grid > 0 && grid < (1ll << 31), "conv_igemm: grid too large");
   const bool fast = kern == K_IGEMM_FAST;
   const bool bk64 = (d->cin % 64 == 0);
-  if (BN == 128) return bk64 ? launch_igemm<128, 64>(a, (unsigned)grid, fast, s) : launch_igemm<128, 32>(a, (unsigned)grid, fast, s);
-  if (BN == 64) return bk64 ? launch_igemm<64, 64>(a, (unsigned)grid, fast, s) : launch_igemm<64, 32>(a, (unsigned)grid, fast, s);
-  return bk64 ? launch_igemm<32, 64>(a, (unsigned)grid, fast, s) : launch_igemm<32, 32>(a, (unsigned)grid, fast, s);
+  if (!fast) return launch_igemm_legacy(a, (unsigned)grid, BN, bk64, s);        // igemm_legacy.hip
+  if (BN == 128) return bk64 ? launch_igemm_fast<128, 64>(a, (unsigned)grid, s) : launch_igemm_fast<128, 32>(a, (unsigned)grid, s);
+  if (BN == 64) return bk64 ? launch_igemm_fast<64, 64>(a, (unsigned)grid, s) : launch_igemm_fast<64, 32>(a, (unsigned)grid, s);
+  return bk64 ? launch_igemm_fast<32, 64>(a, (unsigned)grid, s) : launch_igemm_fast<32, 32>(a, (unsigned)grid, s);
 }

