@@ -16,13 +16,16 @@ from .rope import prepare_rotary_positional_embeddings
 @torch.no_grad()
 def process_video(pipe, video: torch.Tensor, prompt: str = "", noise_step: int = 0, sr_noise_step: int = 399,
                   empty_prompt_embedding: torch.Tensor = None, posterior_noise: torch.Tensor = None,
-                  generator: torch.Generator = None) -> torch.Tensor:
+                  generator: torch.Generator = None, _stages: dict = None) -> torch.Tensor:
     """video [B,3,F,H,W] in [-1,1] -> SR video [B,3,F,H,W] in [0,1].
 
     ``posterior_noise`` ([B,L,T,h,w]) / ``generator`` make the VAE posterior sample reproducible across devices
-    (the reference draws it from the global RNG, ref :409)."""
+    (the reference draws it from the global RNG, ref :409).  ``_stages`` (parity checks: bench.py): a dict that receives the
+    intermediate tensors under the oracle's trace names - moments, latent, v, x0."""
     video = video.to(pipe.vae.device, dtype=pipe.vae.dtype)
     latent_dist = pipe.vae.encode(video).latent_dist
+    if _stages is not None:
+        _stages["moments"] = latent_dist.parameters
     latent = latent_dist.sample(generator=generator, noise=posterior_noise) * pipe.vae.config.scaling_factor
 
     patch_size_t = pipe.transformer.config.patch_size_t
@@ -64,6 +67,8 @@ def process_video(pipe, video: torch.Tensor, prompt: str = "", noise_step: int =
     latent_generate = pipe.scheduler.get_velocity(predicted, latent, timesteps)
     if patch_size_t is not None and ncopy > 0:
         latent_generate = latent_generate[:, ncopy:]
+    if _stages is not None:
+        _stages.update(latent=latent, v=predicted, x0=latent_generate)
     # decode + (x*0.5+0.5).clamp(0,1) (ref :500-501), the range map fused into the decoder's last layout kernel
     return pipe.decode_latents(latent_generate, _range01=True)
 
