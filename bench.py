@@ -448,6 +448,8 @@ def main():
                 "speedup_vs_headline_this_run": (vsteps * args.frames / tv) / value,
                 "vae_flop_ratio_tiled_over_untiled": ratio,
                 "kernels": {k: {"ms": a[1] / vsteps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // vsteps} for k, a in by_t.items()},
+                "kernels_note": "HIP-event durations per launch, summed; the edge tile classes run on a second stream, so the sums include co-scheduling "
+                                "waits and add up to more than the step (one-stream rocprofv3 summary: profiles/r04_tiled_batched_1stream_kernel_stats.csv)",
                 "psnr_vs_untiled_output_db": float(10 * torch.log10(1.0 / (((o_t.float() - out.float()) ** 2).mean() + 1e-12))),
                 "psnr_note": "tiling is a DIFFERENT function of the clip (GroupNorm statistics per tile, blended seams) - diffusers' too; parity of "
                              "the tiled path is gated against the oracle's tiled restatement (tests/test_e2e_gpu.py::test_vae_tiling*)",
