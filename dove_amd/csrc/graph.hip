@@ -112,6 +112,16 @@ __global__ void tile_gather_kernel(const bf16_t* __restrict__ x, int H, int W, i
     ((uint4*)out)[i] = ((const uint4*)x)[(((long long)(t0 + t) * H + org.oy[n] + yy) * W + org.ox[n] + xx) * C8 + c];
   }
 }
+// GroupNorm pair exchange of a split frame-batch: msg = (sum, sumsq)[32] + element count; the pair's totals = a + b
+__global__ void gn_msg_kernel(const double* __restrict__ sums, double count, double* __restrict__ msg) {
+  const int i = threadIdx.x;
+  if (i < 64) msg[i] = sums[i];
+  else if (i == 64) msg[64] = count;
+}
+__global__ void gn_add_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i < 65) out[i] = a[i] + b[i];
+}
 inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int height, hipStream_t s) {
   const long long n = (long long)(width >> 1) * height;
   const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -223,6 +233,11 @@ struct dove_ctx {
   dove_xfer_fn send_fn = nullptr, recv_fn = nullptr; void* xfer_user = nullptr;
   void* rccl_lib = nullptr; void* rccl_comm = nullptr;
   bool halo_recv = false, halo_send = false;            // set by the batch loop around the rank's first / last batch
+  // a PIECE of a frame-batch split over a rank pair (more ranks than frame-batches: BASELINE configs[2], 8 ranks on 4 batches): GroupNorm
+  // sums are combined with `piece_partner`, Upsample3D is told which piece starts an odd batch (dove_amd/dist.py plan_pieces)
+  int piece_role = 0;                                   // 0: whole batch, 1: head (keeps the first frame single), 2: tail
+  int piece_partner = -1; bool piece_lower = false;
+  dove_group_fn group_begin = nullptr, group_end = nullptr;   // bracket of one exchange for rendezvous transports (RCCL: ncclGroupStart / End)
   // options (dove_set_option)
   bool opt_tiling = false, opt_linear_mx = false, opt_attn_mx = false;
   int sample_h = 480, sample_w = 720;                   // vae/config.json sample_height / sample_width: tile geometry of enable_tiling()
@@ -374,7 +389,14 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   }
   CHK(dove_conv_igemm_bf16(&d, stream));
   if (o.gn_stats) *o.gn_stats = nullptr;
-  if (partial) {
+  if (partial && c->piece_partner >= 0) {
+    // a piece of a split frame-batch: the statistics are the PAIR's - hand the raw fp64 sums of this piece on (norm_silu adds the partner's)
+    double* sums = (double*)c->arena.alloc(64 * sizeof(double));
+    if (!sums) { dove_set_error("workspace exhausted (GroupNorm sums)"); return DOVE_EINVAL; }
+    CHK(dove_groupnorm_sums_from_partials(partial, rows, c->gn_ws, sums, stream));
+    c->arena.release(partial);
+    *o.gn_stats = (float*)sums;
+  } else if (partial) {
     float* st = (float*)c->arena.alloc((size_t)nb * 64 * 4);
     const double count = (double)t_out * ho * wo * (pc.cout_store() / 32);
     CHK(dove_groupnorm_finalize_partials_nb(partial, rows / nb, nb, count, o.gn_eps, c->gn_ws, (size_t)c->gn_ws_rows * 64 * 4, st, stream));
@@ -389,6 +411,39 @@ int linear(dove_ctx* c, const bf16_t* x, long long N, const Packed& pc, ConvOpt 
   Tensor y;
   CHK(conv(c, xt, pc, o, &y, stream));
   *out = y.p;
+  return 0;
+}
+
+// ---- exchanges between ranks, built on the context's send / recv callbacks (dove_comm_init*: RCCL or any transport).  A transport
+// whose sends rendezvous with the matching receive (RCCL) brackets every exchange with group_begin / group_end; a buffering transport
+// (the tests' mailbox) needs no bracket: all sends of an exchange are issued before its receives. ----
+int comm_begin(dove_ctx* c, void* stream) { return c->group_begin ? c->group_begin(c->xfer_user, stream) : 0; }
+int comm_end(dove_ctx* c, void* stream) { return c->group_end ? c->group_end(c->xfer_user, stream) : 0; }
+// symmetric swap with one partner: the lower rank sends first, the higher receives first (deadlock-free also without a bracket)
+int pair_exchange(dove_ctx* c, int partner, bool lower, void* send_buf, void* recv_buf, size_t bytes, void* stream) {
+  CHK(comm_begin(c, stream));
+  if (lower) { CHK(c->send_fn(c->xfer_user, partner, send_buf, bytes, stream)); CHK(c->recv_fn(c->xfer_user, partner, recv_buf, bytes, stream)); }
+  else { CHK(c->recv_fn(c->xfer_user, partner, recv_buf, bytes, stream)); CHK(c->send_fn(c->xfer_user, partner, send_buf, bytes, stream)); }
+  return comm_end(c, stream);
+}
+// all-to-all of byte blocks: block j of `send` (offset soff[j], scnt[j] bytes) goes to rank j, block j of `recv` comes from rank j
+int all_to_all(dove_ctx* c, const void* send, const size_t* soff, const size_t* scnt, void* recv, const size_t* roff, const size_t* rcnt, void* stream) {
+  const int R = c->nranks, me = c->rank;
+  CHK(comm_begin(c, stream));
+  for (int k = 1; k < R; ++k) { const int j = (me + k) % R; if (scnt[j]) CHK(c->send_fn(c->xfer_user, j, (char*)send + soff[j], scnt[j], stream)); }
+  for (int k = 1; k < R; ++k) { const int j = (me - k + R) % R; if (rcnt[j]) CHK(c->recv_fn(c->xfer_user, j, (char*)recv + roff[j], rcnt[j], stream)); }
+  CHK(comm_end(c, stream));
+  if (scnt[me]) HIPCHK(hipMemcpyAsync((char*)recv + roff[me], (const char*)send + soff[me], scnt[me], hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+// all-gather of variable-size blocks: every rank contributes `mine` (cnt[me] bytes) and ends with all blocks at off[j] of `out`
+int all_gather_v(dove_ctx* c, const void* mine, void* out, const size_t* off, const size_t* cnt, void* stream) {
+  const int R = c->nranks, me = c->rank;
+  CHK(comm_begin(c, stream));
+  for (int k = 1; k < R; ++k) { const int j = (me + k) % R; if (cnt[me]) CHK(c->send_fn(c->xfer_user, j, (void*)mine, cnt[me], stream)); }
+  for (int k = 1; k < R; ++k) { const int j = (me - k + R) % R; if (cnt[j]) CHK(c->recv_fn(c->xfer_user, j, (char*)out + off[j], cnt[j], stream)); }
+  CHK(comm_end(c, stream));
+  if (cnt[me] && (const char*)mine != (char*)out + off[me]) HIPCHK(hipMemcpyAsync((char*)out + off[me], mine, cnt[me], hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 
@@ -522,17 +577,101 @@ int dec_batch_frames(const dove_ctx* c, int t) {
   for (int i = 0; i < n_temporal_stages(c); ++i) t = t > 1 ? (t % 2 ? 2 * t - 1 : 2 * t) : 1;
   return t;
 }
-// contiguous groups of frame-batches, one per rank, earlier ranks take the extras (dove_amd.dist.split_batches)
-void rank_batches(const dove_ctx* c, int nb, int* b0, int* b1) {
-  const int base = nb / c->nranks, extra = nb % c->nranks, r = c->rank;
-  *b0 = r * base + (r < extra ? r : extra);
-  *b1 = *b0 + base + (r < extra ? 1 : 0);
+// Work list per rank of the halo-exact VAE (dove_amd/dist.py plan_pieces).  With at most as many ranks as frame-batches every rank gets a
+// contiguous group of whole batches, earlier ranks take the extras.  With more ranks, batches are split in two PIECES on consecutive ranks (a
+// rank pair): the conv halos flow rank -> rank + 1 exactly as between batches, GroupNorm statistics are combined across the pair, Upsample3D is
+// told which piece starts an odd batch.  Split points keep every temporal 2:1 pooling pair inside one piece: pixel-frame batches (encoder) of
+// 8k(+1) frames split at 4k(+1); latent batches (decoder) of 2 or 3 frames split before the last frame.
+struct Piece { int s, e, role, partner; bool lower; };
+int plan_pieces(const std::vector<std::pair<int, int>>& fb, int world, bool enc, std::vector<std::vector<Piece>>* out) {
+  const int nb = (int)fb.size();
+  out->assign(world, {});
+  if (world <= nb) {
+    const int base = nb / world, extra = nb % world;
+    int b = 0, active = 0;
+    for (int r = 0; r < world; ++r) {
+      const int k = base + (r < extra ? 1 : 0);
+      for (int i = 0; i < k; ++i, ++b) (*out)[r].push_back({fb[b].first, fb[b].second, 0, -1, false});
+      if (k) ++active;
+    }
+    return active;
+  }
+  int r = 0;
+  for (int i = 0; i < nb; ++i) {
+    const int s = fb[i].first, e = fb[i].second, n = e - s;
+    const int spare = (world - r) - (nb - i);                     // ranks we can still spend on splitting
+    int head; bool can;
+    if (enc) { head = (n % 2) + 4 * ((n - n % 2) / 8); can = n - (n % 2) >= 8 && (n - n % 2) % 8 == 0; }
+    else { head = n - 1; can = n >= 2; }
+    if (spare >= 1 && can) {
+      const bool odd = n % 2 == 1;
+      (*out)[r].push_back({s, s + head, odd ? 1 : 2, r + 1, true});
+      (*out)[r + 1].push_back({s + head, e, 2, r, false});
+      r += 2;
+    } else {
+      (*out)[r].push_back({s, e, 0, -1, false});
+      r += 1;
+    }
+  }
+  return r;
+}
+// frames a piece of t input frames leaves behind the temporal stages (whole batch: role 0; see Downsample3D / Upsample3D above)
+int piece_out_frames(const dove_ctx* c, bool enc, int t, int role) {
+  if (role == 0) return enc ? enc_batch_frames(c, t) : dec_batch_frames(c, t);
+  for (int i = 0; i < n_temporal_stages(c); ++i) {
+    if (enc) t = t > 1 ? (t % 2 ? 1 + (t - 1) / 2 : t / 2) : 1;  // the split keeps pooling pairs inside a piece: the piece's own parity decides
+    else t = role == 1 ? 2 * t - 1 : 2 * t;
+  }
+  return t;
+}
+// this rank's pieces of a stage (n frames in), the output-frame offset of each, and the number of ranks that got work
+struct RankPlan { std::vector<Piece> mine; std::vector<int> out_first; int active = 1; int total_out = 0; std::vector<int> rank_first, rank_count; };
+void rank_plan(const dove_ctx* c, bool enc, int n, RankPlan* rp) {
+  std::vector<std::pair<int, int>> fb;
+  frame_batches(n, enc ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch, &fb);
+  std::vector<std::vector<Piece>> plan;
+  rp->active = plan_pieces(fb, c->nranks, enc, &plan);
+  rp->rank_first.assign(c->nranks, 0); rp->rank_count.assign(c->nranks, 0);
+  int f = 0;
+  for (int r = 0; r < c->nranks; ++r) {
+    rp->rank_first[r] = f;
+    for (auto& pc : plan[r]) {
+      const int k = piece_out_frames(c, enc, pc.e - pc.s, pc.role);
+      if (r == c->rank) { rp->mine.push_back(pc); rp->out_first.push_back(f); }
+      rp->rank_count[r] += k;
+      f += k;
+    }
+  }
+  rp->total_out = f;
+}
+void set_piece(dove_ctx* c, const Piece* pc) {
+  c->piece_role = pc ? pc->role : 0; c->piece_partner = pc ? pc->partner : -1; c->piece_lower = pc ? pc->lower : false;
 }
 int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::string& name, const Tensor* zq, Tensor* out, void* stream) {
   const float eps = c->cfg.vae_norm_eps;
   float* stats = fused_stats;
   const int nb = c->nb, Ti = x.T / nb;
-  if (!stats) {
+  if (c->piece_partner >= 0) {
+    // this rank holds a PIECE of the frame-batch: whole-batch statistics = my (sum, sumsq, count) + the partner's, same fp64 finalize
+    // (dove_amd/dist.py _run_pieces hook: 65 doubles each way, one round trip per norm)
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = (double*)fused_stats;
+    if (!sums) {
+      sums = (double*)c->arena.alloc(64 * sizeof(double));
+      DOVE_CHECK_ARG(sums, "workspace exhausted (GroupNorm sums)");
+      CHK(dove_groupnorm_sums_bf16(x.p, x.elems() / x.C, (long long)x.H * x.W, x.C, c->gn_ws, c->gn_ws_rows, sums, stream));
+    }
+    double* msg = (double*)c->arena.alloc(3 * 72 * sizeof(double));
+    DOVE_CHECK_ARG(msg, "workspace exhausted (GroupNorm pair message)");
+    double *mine = msg, *theirs = msg + 72, *tot = msg + 144;
+    hipLaunchKernelGGL(gn_msg_kernel, dim3(1), dim3(128), 0, s, sums, (double)(x.elems() / 32), mine);
+    CHK(pair_exchange(c, c->piece_partner, c->piece_lower, mine, theirs, 65 * sizeof(double), stream));
+    hipLaunchKernelGGL(gn_add_kernel, dim3(1), dim3(128), 0, s, c->piece_lower ? mine : theirs, c->piece_lower ? theirs : mine, tot);
+    c->arena.release(sums);
+    stats = (float*)c->arena.alloc(64 * 4);
+    CHK(dove_groupnorm_finalize_sums(tot, 0.0, eps, stats, stream));
+    c->arena.release(msg);
+  } else if (!stats) {
     stats = (float*)c->arena.alloc((size_t)nb * 64 * 4);
     CHK(dove_groupnorm_stats_nb_bf16(x.p, nb, x.elems() / x.C / nb, (long long)x.H * x.W, x.C, eps, c->gn_ws, c->gn_ws_rows, stats, stream));
   }
@@ -583,7 +722,7 @@ void clear_caches(dove_ctx* c);
 struct StageGuard {
   dove_ctx* c;
   explicit StageGuard(dove_ctx* ctx) : c(ctx) {
-    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; }
+    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; set_piece(c, nullptr); }
   }
   ~StageGuard() { if (c) --c->depth; }
 };
@@ -639,7 +778,11 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
       if (hs) { c->arena.release(hs); hs = nullptr; }
       ConvOpt ou; ou.up = 1; ou.pad_h = 1; ou.pad_w = 1; ou.gn_eps = cf.vae_norm_eps; ou.gn_stats = &hs; ou.nb = c->nb;
       const int Ti = h.T / c->nb;
-      if (i < n_tdown && Ti > 1) { ou.tmode = Ti % 2 ? 2 : 1; ou.t_out = Ti % 2 ? 2 * Ti - 1 : 2 * Ti; }
+      if (i < n_tdown && c->piece_role) {
+        // a piece of a split frame-batch: the piece that starts an odd-length batch keeps its first frame single, every other piece doubles
+        // all of its frames - also a single-frame piece, which is not a 1-frame batch (diffusers derives the rule from the BATCH's parity)
+        ou.tmode = c->piece_role == 1 ? 2 : 1; ou.t_out = c->piece_role == 1 ? 2 * Ti - 1 : 2 * Ti;
+      } else if (i < n_tdown && Ti > 1) { ou.tmode = Ti % 2 ? 2 : 1; ou.t_out = Ti % 2 ? 2 * Ti - 1 : 2 * Ti; }
       Tensor u;
       CHK(conv(c, h, c->pc.at(nm), ou, &u, stream));
       free_t(c, h);
@@ -773,7 +916,19 @@ struct Rccl {
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t);
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t);
   int (*CommDestroy)(void*);
+  int (*GroupStart)();
+  int (*GroupEnd)();
 };
+int rccl_group_begin(void* user, void*) {
+  const int rc = ((Rccl*)user)->GroupStart();
+  if (rc) { dove_set_error("ncclGroupStart failed (%d)", rc); return DOVE_ELAUNCH; }
+  return 0;
+}
+int rccl_group_end(void* user, void*) {
+  const int rc = ((Rccl*)user)->GroupEnd();
+  if (rc) { dove_set_error("ncclGroupEnd failed (%d)", rc); return DOVE_ELAUNCH; }
+  return 0;
+}
 struct UniqueId { char b[128]; };   // ncclUniqueId: a 128-byte struct, passed BY VALUE to ncclCommInitRank
 int rccl_send(void* user, int peer, void* p, size_t bytes, void* stream) {
   Rccl* r = (Rccl*)user;
@@ -812,7 +967,12 @@ extern "C" void dove_comm_destroy(dove_ctx* c) {
     delete r;
     c->rccl_comm = nullptr;
   }
-  c->rank = 0; c->nranks = 1; c->send_fn = c->recv_fn = nullptr; c->xfer_user = nullptr;
+  c->rank = 0; c->nranks = 1; c->send_fn = c->recv_fn = nullptr; c->xfer_user = nullptr; c->group_begin = c->group_end = nullptr;
+}
+extern "C" int dove_comm_set_group(dove_ctx* c, dove_group_fn begin, dove_group_fn end) {
+  DOVE_CHECK_ARG(c && ((begin == nullptr) == (end == nullptr)), "dove_comm_set_group: give both callbacks or neither");
+  c->group_begin = begin; c->group_end = end;
+  return DOVE_OK;
 }
 extern "C" int dove_comm_init_custom(dove_ctx* c, int rank, int nranks, dove_xfer_fn send, dove_xfer_fn recv, void* user) {
   DOVE_CHECK_ARG(c && nranks >= 1 && rank >= 0 && rank < nranks, "dove_comm_init_custom: bad rank %d of %d", rank, nranks);
@@ -831,7 +991,9 @@ extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank,
   r->Send = (decltype(r->Send))dlsym(h, "ncclSend");
   r->Recv = (decltype(r->Recv))dlsym(h, "ncclRecv");
   r->CommDestroy = (decltype(r->CommDestroy))dlsym(h, "ncclCommDestroy");
-  if (!init || !r->Send || !r->Recv || !r->CommDestroy) { delete r; dove_set_error("dove_comm_init: RCCL symbols not found"); return DOVE_EINVAL; }
+  r->GroupStart = (decltype(r->GroupStart))dlsym(h, "ncclGroupStart");
+  r->GroupEnd = (decltype(r->GroupEnd))dlsym(h, "ncclGroupEnd");
+  if (!init || !r->Send || !r->Recv || !r->CommDestroy || !r->GroupStart || !r->GroupEnd) { delete r; dove_set_error("dove_comm_init: RCCL symbols not found"); return DOVE_EINVAL; }
   HIPCHK(hipSetDevice(c->device));
   UniqueId id;
   memcpy(&id, nccl_unique_id, sizeof id);
@@ -840,6 +1002,7 @@ extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank,
   dove_comm_destroy(c);
   c->rccl_comm = r;
   c->rank = rank; c->nranks = nranks; c->send_fn = rccl_send; c->recv_fn = rccl_recv; c->xfer_user = r;
+  c->group_begin = rccl_group_begin; c->group_end = rccl_group_end;      // every exchange (pair swap, all-to-all) is one ncclGroup
   return DOVE_OK;
 }
 // frames [first, first + count) of a stage's output that THIS rank produces (stage 0: dove_vae_encode, n = F pixel frames ->
@@ -847,26 +1010,21 @@ extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank,
 // left untouched and are the other ranks' to deliver
 extern "C" int dove_shard_frames(dove_ctx* c, int stage, int n, int* first, int* count) {
   DOVE_CHECK_ARG(c && first && count && n >= 1 && (stage == 0 || stage == 1), "dove_shard_frames: bad argument");
-  std::vector<std::pair<int, int>> fb;
-  frame_batches(n, stage == 0 ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch, &fb);
-  int b0 = 0, b1 = (int)fb.size();
-  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
-  int f = 0;
-  *first = 0; *count = 0;
-  for (int b = 0; b < (int)fb.size(); ++b) {
-    const int k = stage == 0 ? enc_batch_frames(c, fb[b].second - fb[b].first) : dec_batch_frames(c, fb[b].second - fb[b].first);
-    if (b == b0) *first = f;
-    if (b >= b0 && b < b1) *count += k;
-    f += k;
-  }
+  RankPlan rp;
+  rank_plan(c, stage == 0, n, &rp);
+  *first = rp.rank_first[c->rank];
+  *count = rp.rank_count[c->rank];
   return DOVE_OK;
 }
 
 extern "C" int dove_comm_useful_ranks(dove_ctx* c, int stage, int n) {
   if (!c || n < 1 || (stage != 0 && stage != 1)) return 0;
+  // ranks that get work when `nranks` ranks share the stage: up to two per frame-batch (batches are split into paired pieces when there
+  // are more ranks than batches); asked on a single-rank context: the most ranks that could
   std::vector<std::pair<int, int>> fb;
   frame_batches(n, stage == 0 ? c->cfg.vae_enc_batch : c->cfg.vae_dec_batch, &fb);
-  return (int)fb.size();
+  std::vector<std::vector<Piece>> plan;
+  return plan_pieces(fb, c->nranks > 1 ? c->nranks : 2 * (int)fb.size(), stage == 0, &plan);
 }
 
 extern "C" int dove_set_option(dove_ctx* c, int option, long long value) {
@@ -1225,24 +1383,22 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   const int T = 1 + (F - 1) / cf.vae_temporal_compression, h = H / 8, w = W / 8;
   const int ld = c->pc.at("encoder.conv_out").cout_store();
   CHK(alloc_t(c, T, h, w, ld, moments));
-  int b0 = 0, b1 = (int)fb.size();
-  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
-  int t0 = 0;
-  for (int b = 0; b < (int)fb.size(); ++b) {
-    const auto& se = fb[b];
-    const int tb = enc_batch_frames(c, se.second - se.first);                          // latent frames of this batch
-    if (b >= b0 && b < b1) {
-      c->halo_recv = c->nranks > 1 && b == b0 && b > 0;
-      c->halo_send = c->nranks > 1 && b == b1 - 1 && b + 1 < (int)fb.size();
-      Tensor xb = xcl; xb.p = xcl.p + (long long)se.first * H * W * xcl.C; xb.T = se.second - se.first;
-      Tensor o;
-      const int rc = encoder(c, xb, &o, stream);
-      c->halo_recv = c->halo_send = false;
-      CHK(rc);
-      HIPCHK(hipMemcpyAsync(moments->p + (long long)t0 * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-      free_t(c, o);
-    }
-    t0 += tb;
+  RankPlan rp;
+  rank_plan(c, true, F, &rp);
+  if (rp.total_out != T) { dove_set_error("dove_vae_encode: the rank plan yields %d latent frames, expected %d", rp.total_out, T); return DOVE_EINVAL; }
+  for (size_t i = 0; i < rp.mine.size(); ++i) {
+    const Piece& pc = rp.mine[i];
+    c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
+    c->halo_send = c->nranks > 1 && i + 1 == rp.mine.size() && c->rank < rp.active - 1;
+    set_piece(c, &pc);
+    Tensor xb = xcl; xb.p = xcl.p + (long long)pc.s * H * W * xcl.C; xb.T = pc.e - pc.s;
+    Tensor o;
+    const int rc = encoder(c, xb, &o, stream);
+    c->halo_recv = c->halo_send = false;
+    set_piece(c, nullptr);
+    CHK(rc);
+    HIPCHK(hipMemcpyAsync(moments->p + (long long)rp.out_first[i] * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    free_t(c, o);
   }
   free_t(c, xcl);
   clear_caches(c);
@@ -1326,39 +1482,161 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   frame_batches(T, cf.vae_dec_batch, &fb);
   clear_caches(c);
   const size_t esz = out_dtype == DOVE_F32 ? 4 : 2;
-  int b0 = 0, b1 = (int)fb.size();
-  if (c->nranks > 1) rank_batches(c, (int)fb.size(), &b0, &b1);
-  int f0 = 0;
-  for (int b = 0; b < (int)fb.size(); ++b) {
-    const auto& se = fb[b];
-    const int fb_frames = dec_batch_frames(c, se.second - se.first);
-    if (b >= b0 && b < b1) {
-      c->halo_recv = c->nranks > 1 && b == b0 && b > 0;
-      c->halo_send = c->nranks > 1 && b == b1 - 1 && b + 1 < (int)fb.size();
-      Tensor zb = zcl; zb.p = zcl.p + (long long)se.first * h * w * zcl.C; zb.T = se.second - se.first;
-      Tensor o;
-      const int rc = decoder(c, zb, &o, stream);
-      c->halo_recv = c->halo_send = false;
-      CHK(rc);
-      // [C][F][H][W] output: this batch's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
-      void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
-      DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
-      if (c->conv_out_bias) {
-        CHK(dove_conv_out_gather((const float*)o.p, o.C / 2, o.T, H, W, cf.vae_out_channels, c->conv_out_bias, range01 ? 0.5f : 1.0f,
-                                 range01 ? 0.5f : 0.0f, range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
-      } else {
-        CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
-                               range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
-      }
-      CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
-                 cf.vae_out_channels, (hipStream_t)stream));
-      c->arena.release(tmp);
-      free_t(c, o);
+  RankPlan rp;
+  rank_plan(c, false, T, &rp);
+  if (rp.total_out != F) { dove_set_error("dove_vae_decode: the rank plan yields %d frames, expected %d", rp.total_out, F); return DOVE_EINVAL; }
+  for (size_t i = 0; i < rp.mine.size(); ++i) {
+    const Piece& pc = rp.mine[i];
+    c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
+    c->halo_send = c->nranks > 1 && i + 1 == rp.mine.size() && c->rank < rp.active - 1;
+    set_piece(c, &pc);
+    Tensor zb = zcl; zb.p = zcl.p + (long long)pc.s * h * w * zcl.C; zb.T = pc.e - pc.s;
+    Tensor o;
+    const int rc = decoder(c, zb, &o, stream);
+    c->halo_recv = c->halo_send = false;
+    set_piece(c, nullptr);
+    CHK(rc);
+    const int f0 = rp.out_first[i];
+    // [C][F][H][W] output: this piece's frames are not contiguous per channel -> convert into a staging tensor, then strided copy
+    void* tmp = c->arena.alloc((size_t)cf.vae_out_channels * o.T * H * W * esz);
+    DOVE_CHECK_ARG(tmp, "workspace exhausted (decoder output staging)");
+    if (c->conv_out_bias) {
+      CHK(dove_conv_out_gather((const float*)o.p, o.C / 2, o.T, H, W, cf.vae_out_channels, c->conv_out_bias, range01 ? 0.5f : 1.0f,
+                               range01 ? 0.5f : 0.0f, range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
+    } else {
+      CHK(dove_ncthw_from_cl(o.p, o.C, cf.vae_out_channels, (long long)o.T * H * W, range01 ? 0.5f : 1.0f, range01 ? 0.5f : 0.0f,
+                             range01 ? 0.0f : -INFINITY, range01 ? 1.0f : INFINITY, tmp, out_dtype, stream));
     }
-    f0 += fb_frames;
+    CHK(copy2d((char*)video_out + (size_t)f0 * H * W * esz, (size_t)F * H * W * esz, tmp, (size_t)o.T * H * W * esz, (size_t)o.T * H * W * esz,
+               cf.vae_out_channels, (hipStream_t)stream));
+    c->arena.release(tmp);
+    free_t(c, o);
   }
   free_t(c, zcl);
   clear_caches(c);
+  return DOVE_OK;
+}
+
+// The same forward with the ranks of the context's communicator sharing ONE sample (dove_amd/dist.py dit_forward_ulysses, Ulysses-style):
+// the token-major residual stream [N, D] is sharded by ROWS for every row-local operator (LayerNormZero, the four linears with their gated
+// residuals, QK-LayerNorm + RoPE) and by HEADS (heads / nranks each) for attention, with one all-to-all of Q', K', V^T before the attention
+// kernel and one of its output after it per layer; the per-head score bound rides in the K blocks (dove_ulysses_place_bf16).  Every row and
+// every head sees the single-GPU arithmetic, so v_out - complete on every rank - is bit-identical to the one-GPU call.
+static int dit_forward_ulysses(dove_ctx* c, const void* hidden, int dtype, int T, int h, int w, const void* text, int L, int timestep,
+                               const dove_dit_aux* aux, void* v_out, int out_dtype, void* stream) {
+  const auto& cf = c->cfg;
+  const int p = cf.dit_patch, pt = cf.dit_patch_t, Cc = cf.dit_in_channels, D = cf.dit_heads * cf.dit_head_dim, Hh = cf.dit_heads;
+  const int R = c->nranks, me = c->rank;
+  DOVE_CHECK_ARG(!c->opt_linear_mx && !c->opt_attn_mx, "dove_dit_forward: the sharded DiT runs the bf16 path (configs[4] is one clip per GPU)");
+  DOVE_CHECK_ARG(Hh % R == 0, "dove_dit_forward: %d attention heads do not split over %d ranks", Hh, R);
+  DOVE_CHECK_ARG(R <= 16, "dove_dit_forward: at most 16 ranks");
+  hipStream_t s = (hipStream_t)stream;
+  const int hloc = Hh / R;
+  const long long nv = (long long)(T / pt) * (h / p) * (w / p), N = L + nv, npad = ru(N, 128);
+  std::vector<long long> bounds(R + 1), counts(R);
+  for (int i = 0; i <= R; ++i) bounds[i] = (long long)i * N / R;
+  for (int i = 0; i < R; ++i) counts[i] = bounds[i + 1] - bounds[i];
+  const long long r0 = bounds[me], r1 = bounds[me + 1], nloc = r1 - r0;
+  DOVE_CHECK_ARG(nloc > 0, "dove_dit_forward: more ranks than tokens");
+  const long long lt_loc = std::max<long long>(0, std::min<long long>(r1, L) - r0);      // local rows that are text rows (they come first)
+  const long long v0 = std::max<long long>(r0, L) - L, v1 = std::max<long long>(r1, L) - L;   // local video rows [v0, v1)
+  const float *cosp, *sinp;
+  if (aux && aux->rope_cos && aux->rope_sin) { cosp = aux->rope_cos; sinp = aux->rope_sin; }
+  else CHK(rope_tables(c, T / pt, h / p, w / p, &cosp, &sinp, stream));
+  CHK(modulation(c, timestep, aux ? aux->timestep_proj : nullptr, stream));
+  auto A = [&](size_t bytes) -> bf16_t* { return (bf16_t*)c->arena.alloc(bytes); };
+  auto Z = [&](size_t bytes) -> bf16_t* { bf16_t* q = (bf16_t*)c->arena.alloc(bytes); if (q) (void)hipMemsetAsync(q, 0, bytes, s); return q; };
+  bf16_t* hs = A((size_t)nloc * D * 2);
+  bf16_t* n1 = A((size_t)nloc * D * 2);
+  DOVE_CHECK_ARG(hs && n1, "workspace exhausted (DiT token buffers)");
+  ConvOpt o; bf16_t* dummy;
+  if (lt_loc) { o = ConvOpt(); o.out = hs; CHK(linear(c, (const bf16_t*)text + r0 * cf.dit_text_dim, lt_loc, c->pe_text, o, &dummy, stream)); }
+  if (v1 > v0) {
+    const int feat_pad = c->pe_proj.cin_pad;
+    bf16_t* tok = A((size_t)nv * feat_pad * 2);
+    DOVE_CHECK_ARG(tok, "workspace exhausted (DiT tokens)");
+    if (feat_pad > Cc * pt * p * p) HIPCHK(hipMemsetAsync(tok, 0, (size_t)nv * feat_pad * 2, s));
+    CHK(dove_patchify(hidden, dtype, T, Cc, h, w, pt, p, tok, feat_pad, stream));
+    o = ConvOpt(); o.out = hs + (size_t)lt_loc * D;
+    CHK(linear(c, tok + (size_t)v0 * feat_pad, v1 - v0, c->pe_proj, o, &dummy, stream));
+    c->arena.release(tok);
+  }
+  const float* cos_l = v1 > v0 ? cosp + v0 * 64 : cosp;        // a text-only shard still hands a valid table to the kernel
+  const float* sin_l = v1 > v0 ? sinp + v0 * 64 : sinp;
+  // Rank-local head-major operands with row stride nloc + 1: rows [0, nloc) are data, so "my rows of rank j's heads" is one contiguous
+  // all-to-all chunk; the extra row of a K head carries this rank's score-bound pair of that head to the rank that owns the head
+  const size_t qkl = (size_t)Hh * (nloc + 1) * 64 * 2;
+  bf16_t *Ql = Z(qkl), *Kl = Z(qkl), *Vl = Z(qkl);
+  const size_t ab = (size_t)hloc * npad * 64 * 2;
+  bf16_t *Qh = Z(ab), *Kh = Z(ab), *Vt = Z(ab);                 // pad rows / columns stay zero across the layers
+  const size_t rb = (size_t)(N + R) * hloc * 64 * 2;
+  bf16_t *rq = A(rb), *rk = A(rb), *rv = A(rb);
+  bf16_t* att = A((size_t)N * hloc * 64 * 2);
+  bf16_t* back = A((size_t)nloc * hloc * 64 * R * 2);
+  bf16_t* att_loc = A((size_t)nloc * D * 2);
+  float* norm2 = (float*)c->arena.alloc((size_t)Hh * 2 * sizeof(float));
+  float* norm2_mine = (float*)c->arena.alloc((size_t)hloc * 2 * sizeof(float));
+  DOVE_CHECK_ARG(Ql && Kl && Vl && Qh && Kh && Vt && rq && rk && rv && att && back && att_loc && norm2 && norm2_mine, "workspace exhausted (sharded attention buffers)");
+  std::vector<size_t> s_off(R), s_cnt(R), r_off(R), r_cnt(R), b_soff(R), b_scnt(R), b_roff(R), b_rcnt(R);
+  size_t ro = 0;
+  for (int j = 0; j < R; ++j) {
+    s_cnt[j] = (size_t)(nloc + 1) * hloc * 64 * 2; s_off[j] = (size_t)j * s_cnt[j];            // chunk j of Ql / Kl / Vl = head group j
+    r_cnt[j] = (size_t)(counts[j] + 1) * hloc * 64 * 2; r_off[j] = ro; ro += r_cnt[j];
+    b_scnt[j] = (size_t)counts[j] * hloc * 64 * 2; b_soff[j] = (size_t)bounds[j] * hloc * 64 * 2;   // rows of rank j in att [N][hloc*64]
+    b_rcnt[j] = (size_t)nloc * hloc * 64 * 2; b_roff[j] = (size_t)j * b_rcnt[j];
+  }
+  const float qscale = (1.0f / sqrtf((float)cf.dit_head_dim)) * 1.4426950408889634f;
+  for (auto& b : c->blocks) {
+    CHK(dove_layernorm_modulate_bf16(hs, n1, nloc, D, cf.dit_norm_eps, b.ln1_g, b.ln1_b, b.m1, lt_loc, stream));
+    bf16_t* qkv;
+    CHK(linear(c, n1, nloc, b.qkv, ConvOpt(), &qkv, stream));
+    CHK(dove_qkv_post_bf16(qkv, nloc, nloc + 1, Hh, 64, (int)lt_loc, b.nq_g, b.nq_b, b.nk_g, b.nk_b, cos_l, sin_l, qscale, 1e-6f, Ql, Kl, Vl, /*v_order=*/0, norm2, stream));
+    c->arena.release(qkv);
+    // the K heads' extra rows: two floats per head
+    HIPCHK(hipMemcpy2DAsync(Kl + (size_t)nloc * 64, (size_t)(nloc + 1) * 64 * 2, norm2, 2 * sizeof(float), 2 * sizeof(float), Hh, hipMemcpyDeviceToDevice, s));
+    CHK(all_to_all(c, Ql, s_off.data(), s_cnt.data(), rq, r_off.data(), r_cnt.data(), stream));
+    CHK(all_to_all(c, Kl, s_off.data(), s_cnt.data(), rk, r_off.data(), r_cnt.data(), stream));
+    CHK(all_to_all(c, Vl, s_off.data(), s_cnt.data(), rv, r_off.data(), r_cnt.data(), stream));
+    CHK(dove_ulysses_place_bf16(rq, rk, rv, counts.data(), R, hloc, N, npad, Qh, Kh, Vt, norm2_mine, stream));
+    CHK(dove_attention_fwd_bf16(Qh, Kh, Vt, att, N, npad, hloc, 64, (long long)hloc * 64, norm2_mine, stream));
+    // heads -> rows: rank j gets rows [bounds[j], bounds[j+1]) of my heads; I get my rows of every head group
+    CHK(all_to_all(c, att, b_soff.data(), b_scnt.data(), back, b_roff.data(), b_rcnt.data(), stream));
+    for (int j = 0; j < R; ++j)                                 // [head group j][my rows][hloc*64] -> [my rows][all heads]
+      CHK(copy2d(att_loc + (size_t)j * hloc * 64, (size_t)D * 2, back + (size_t)j * nloc * hloc * 64, (size_t)hloc * 64 * 2, (size_t)hloc * 64 * 2, (int)nloc, s));
+    o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g1; o.gate_split = lt_loc; o.out = hs;
+    CHK(linear(c, att_loc, nloc, b.out, o, &dummy, stream));
+    CHK(dove_layernorm_modulate_bf16(hs, n1, nloc, D, cf.dit_norm_eps, b.ln2_g, b.ln2_b, b.m2, lt_loc, stream));
+    bf16_t* f1;
+    o = ConvOpt(); o.act = 1;
+    CHK(linear(c, n1, nloc, b.ff1, o, &f1, stream));
+    o = ConvOpt(); o.resid = hs; o.ldr = D; o.gate = b.g2; o.gate_split = lt_loc; o.out = hs;
+    CHK(linear(c, f1, nloc, b.ff2, o, &dummy, stream));
+    c->arena.release(f1);
+  }
+  for (void* q : {(void*)Ql, (void*)Kl, (void*)Vl, (void*)Qh, (void*)Kh, (void*)Vt, (void*)rq, (void*)rk, (void*)rv, (void*)att, (void*)back, (void*)att_loc, (void*)norm2, (void*)norm2_mine})
+    c->arena.release(q);
+  // output head on my video rows, then every rank gathers all rows: the un-patchified velocity is complete everywhere
+  const int width = c->proj_out.cout_store();
+  bf16_t* oall = A((size_t)nv * width * 2);
+  DOVE_CHECK_ARG(oall, "workspace exhausted (DiT head)");
+  std::vector<size_t> g_off(R), g_cnt(R);
+  for (int j = 0; j < R; ++j) {
+    const long long a0 = std::max<long long>(bounds[j], L) - L, a1 = std::max<long long>(bounds[j + 1], L) - L;
+    g_off[j] = (size_t)a0 * width * 2; g_cnt[j] = (size_t)(a1 - a0) * width * 2;
+  }
+  bf16_t* po = nullptr;
+  if (v1 > v0) {
+    bf16_t* xv = hs + (size_t)lt_loc * D;
+    bf16_t* a1 = A((size_t)(v1 - v0) * D * 2);
+    DOVE_CHECK_ARG(a1, "workspace exhausted (DiT head)");
+    CHK(dove_layernorm_modulate_bf16(xv, a1, v1 - v0, D, cf.dit_norm_eps, c->nf_g, c->nf_b, nullptr, 0, stream));
+    CHK(dove_layernorm_modulate_bf16(a1, n1, v1 - v0, D, cf.dit_norm_eps, c->no_g, c->no_b, c->final_mod, 0, stream));
+    CHK(linear(c, n1, v1 - v0, c->proj_out, ConvOpt(), &po, stream));
+    c->arena.release(a1);
+  }
+  CHK(all_gather_v(c, po, oall, g_off.data(), g_cnt.data(), stream));
+  CHK(dove_unpatchify(oall, width, T, cf.dit_out_channels, h, w, pt, p, v_out, out_dtype, stream));
+  c->arena.release(po); c->arena.release(oall); c->arena.release(n1); c->arena.release(hs);
   return DOVE_OK;
 }
 
@@ -1373,6 +1651,7 @@ extern "C" int dove_dit_forward(dove_ctx* c, const void* hidden, int dtype, int 
   DOVE_CHECK_ARG(T % pt == 0 && h % p == 0 && w % p == 0 && L >= 1, "dove_dit_forward: T / h / w must be multiples of the patch sizes");
   StageGuard guard(c);
   CHK(ensure_ws(c, 1 + 4 * (T - 1), 8 * h, 8 * w));
+  if (c->nranks > 1) return dit_forward_ulysses(c, hidden, dtype, T, h, w, text, L, timestep, aux, v_out, out_dtype, stream);
   const long long nv = (long long)(T / pt) * (h / p) * (w / p), N = L + nv, npad = ru(N, 128);
   const float *cosp, *sinp;
   if (aux && aux->rope_cos && aux->rope_sin) { cosp = aux->rope_cos; sinp = aux->rope_sin; }
@@ -1466,7 +1745,6 @@ extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F,
   DOVE_CHECK_ARG(video_in && noise && text && video_out, "dove_sr_clip: null pointer");
   DOVE_CHECK_ARG(!pre || pre->eps, "dove_sr_clip: pre_noise without eps");
   StageGuard guard(c);
-  DOVE_CHECK_ARG(c->nranks == 1, "dove_sr_clip: a multi-rank context runs the VAE stages only (dove_vae_encode / dove_vae_decode + the caller's gather)");
   DOVE_CHECK_ARG(F >= 1 && H % 16 == 0 && W % 16 == 0, "dove_sr_clip: H and W must be multiples of 16 (8x VAE, 2x patch)");
   CHK(ensure_ws(c, F, H, W));
   const auto& cf = c->cfg;
@@ -1476,6 +1754,16 @@ extern "C" int dove_sr_clip(dove_ctx* c, const void* video_in, int dtype, int F,
   CHK(vae_encode_cl(c, video_in, dtype, F, H, W, &m, stream));
   const int T = m.T;
   const long long fsz = (long long)h * w;                       // elements of one latent frame of one channel
+  if (c->nranks > 1) {
+    // ONE clip on all ranks (BASELINE configs[2]): every rank encoded its frames; the posterior moments are gathered so that every rank
+    // samples the SAME latent (the caller passes the same noise on every rank), the DiT runs sequence / head parallel and returns the whole
+    // velocity everywhere, and dove_vae_decode below writes only this rank's frames of video_out (dove_shard_frames(ctx, 1, T, ...))
+    RankPlan rp;
+    rank_plan(c, true, F, &rp);
+    std::vector<size_t> off(c->nranks), cnt(c->nranks);
+    for (int j = 0; j < c->nranks; ++j) { off[j] = (size_t)rp.rank_first[j] * fsz * m.C * 2; cnt[j] = (size_t)rp.rank_count[j] * fsz * m.C * 2; }
+    CHK(all_gather_v(c, (char*)m.p + off[c->rank], m.p, off.data(), cnt.data(), stream));
+  }
   // sample = mean + std * noise (bf16, [L][T][h][w]), then * scaling_factor and the first-frame pad, as [T'][L][h][w] for the DiT
   bf16_t* samp = (bf16_t*)c->arena.alloc((size_t)Lc * T * fsz * 2);
   DOVE_CHECK_ARG(samp, "workspace exhausted");

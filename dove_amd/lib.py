@@ -61,6 +61,7 @@ OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP
 
 _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)   # dove_xfer_fn
+GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)                                  # dove_group_fn
 
 # name -> argtypes; the symbol list doubles as the export check in tests/test_abi.py
 SIGNATURES = {
@@ -111,6 +112,7 @@ SIGNATURES = {
     "dove_comm_unique_id": [_VP],
     "dove_comm_init": [_VP, _VP, _I, _I],
     "dove_comm_init_custom": [_VP, _I, _I, XFER_FN, XFER_FN, _VP],
+    "dove_comm_set_group": [_VP, GROUP_FN, GROUP_FN],
     "dove_shard_frames": [_VP, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }

@@ -288,27 +288,40 @@ typedef struct dove_model_config {
  * NULL = computed inside (host libm + upload, cached per shape / timestep) */
 typedef struct dove_dit_aux { const float* rope_cos; const float* rope_sin; const float* timestep_proj; } dove_dit_aux;
 int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
-/* ---- one clip on several GPUs: halo-exact VAE ----
- * One context per rank (process or thread, one GPU each).  With a communicator set, dove_vae_encode / dove_vae_decode run only
- * THIS rank's contiguous group of frame-batches (diffusers' num_sample_frames_batch_size / num_latent_frames_batch_size batching;
- * at most as many ranks as batches do work): every CogVideoXCausalConv3d of the rank's first batch receives its conv_cache (the
- * last kt-1 input frames the previous batch would have left) from rank-1, and sends its own to rank+1 after the rank's last
- * batch - point-to-point, in layer order, on the caller's stream.  Results are bit-identical to the single-GPU call.  Only the
- * frames dove_shard_frames reports are written to the output buffer; gathering them is the caller's (an all-gather of
- * [channels][own frames][H][W] pieces).  RANK LIMIT: frame-batches are never split at this level, so ranks beyond the number of
- * frame-batches (dove_comm_useful_ranks: 4 for a 33-frame clip) get no work; the paired-piece split that lets 8 ranks share 4
- * batches (BASELINE's "frame-chunk = 4": GroupNorm sums combined across a rank pair) lives in the Python host, dove_amd.dist.  dove_dit_forward is not sharded at this level and dove_sr_clip refuses a multi-rank
- * context (the Python host shards the DiT by sequence / heads, dove_amd.dist).
- * dove_comm_init: RCCL transport (librccl opened at run time; the 128-byte id from dove_comm_unique_id on rank 0, distributed by
- * the host).  dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`, ordered on `stream`. */
+/* ---- one clip on several GPUs (BASELINE configs[2]) ----
+ * One context per rank (process or thread, one GPU each).  With a communicator set,
+ *  - dove_vae_encode / dove_vae_decode run only THIS rank's share of the frame-batches (diffusers' num_sample_frames_batch_size /
+ *    num_latent_frames_batch_size batching): every CogVideoXCausalConv3d of the rank's first work item receives its conv_cache (the last
+ *    kt-1 input frames the previous item would have left) from rank-1, and sends its own to rank+1 after the rank's last - point-to-point, in
+ *    layer order, on the caller's stream.  With at most as many ranks as frame-batches the items are whole batches; with MORE ranks (ABI 12)
+ *    batches are split into PAIRED PIECES on consecutive ranks - 8 ranks on a 33-frame clip decode 5,4,4,4,4,4,4,4 frames, BASELINE's
+ *    "frame-chunk = 4" - and every GroupNorm of a piece swaps 65 doubles (per-group sum, sum of squares, element count) with its partner, so the
+ *    statistics are the whole batch's.  Only the frames dove_shard_frames reports are written to the output buffer;
+ *  - dove_dit_forward (ABI 12) shards ONE sample over the ranks: rows of the token-major residual stream for every row-local operator,
+ *    heads for attention, one all-to-all of Q' / K' / V^T and one of the attention output per layer (the score bound rides in the K blocks);
+ *    v_out is complete on every rank.  dit_heads must be a multiple of nranks;
+ *  - dove_sr_clip (ABI 12) chains them: encode, gather of the posterior moments, the sharded DiT, decode - every rank passes the SAME clip,
+ *    noise and text and gets ITS frames of video_out (dove_shard_frames(ctx, 1, T, ...)); gathering them is the caller's.
+ * Every result is bit-identical to the single-GPU call (tests/test_graph_gpu.py plays 2 - 8 ranks as threads on one GPU).
+ * dove_comm_init: RCCL transport (librccl opened at run time; the 128-byte id from dove_comm_unique_id on rank 0, distributed by the host;
+ * every exchange is one ncclGroup).  dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`,
+ * ordered on `stream`, matched in order per (source, destination) pair. */
 typedef int (*dove_xfer_fn)(void* user, int peer, void* dev_ptr, size_t bytes, void* stream);
+/* Bracket of ONE exchange (ABI 12).  The paired-piece VAE swaps 65 doubles with a partner per GroupNorm and the sharded DiT runs all-to-alls:
+ * symmetric patterns in which every rank sends and receives.  A transport whose send rendezvous with the peer's receive (RCCL) must see the
+ * calls of such an exchange as one group (dove_comm_init does this with ncclGroupStart / ncclGroupEnd); a custom transport either BUFFERS its
+ * sends (then no bracket is needed: the library issues all sends of an exchange before its receives, and in a pair swap the lower rank
+ * sends first) or provides the two callbacks here. */
+typedef int (*dove_group_fn)(void* user, void* stream);
+int dove_comm_set_group(dove_ctx* ctx, dove_group_fn begin, dove_group_fn end);
 int dove_comm_unique_id(void* out128);
 int dove_comm_init(dove_ctx* ctx, const void* nccl_unique_id, int rank, int nranks);
 int dove_comm_init_custom(dove_ctx* ctx, int rank, int nranks, dove_xfer_fn send, dove_xfer_fn recv, void* user);
 void dove_comm_destroy(dove_ctx* ctx);
 /* stage 0 = dove_vae_encode (n = pixel frames F -> latent frames), stage 1 = dove_vae_decode (n = latent frames T -> pixel frames) */
 int dove_shard_frames(dove_ctx* ctx, int stage, int n, int* first, int* count);
-/* number of ranks that get work for this stage and clip length = its number of frame-batches */
+/* number of ranks that get work for this stage and clip length under the context's communicator (whole batches, or paired pieces when there
+ * are more ranks than batches); on a single-rank context: the most ranks that could (two per splittable frame-batch) */
 int dove_comm_useful_ranks(dove_ctx* ctx, int stage, int n);
 void dove_destroy(dove_ctx* ctx);
 /* ---- options of the graph level: the reference's switches that change what a stage computes ----

@@ -308,10 +308,132 @@ def test_vae_sharded_halo_exchange_c_level(both, R):
     assert covered_d == d_ref.shape[1] and torch.equal(d, d_ref), "sharded decode differs"
     assert all(not q for q in box.values()), "unconsumed halo messages"
     assert n_enc_msgs > 0 and len(log) > n_enc_msgs and all(dst == src + 1 for src, dst, _ in log)
-    with pytest.raises(RuntimeError):                           # the fused call is single-rank only
-        ranks[0].sr_clip(video, torch.zeros(16, 9, H // 8, W // 8, device="cuda"), torch.zeros(226, 4096, dtype=BF, device="cuda"), 399, 0.6, 0.8)
     for c in ranks:
         c.comm_destroy()
+
+
+class _Mailbox:
+    """In-process transport for R contexts that run as R THREADS on one GPU: send = copy into a queued device buffer (buffered: never
+    blocks), recv = wait for the peer's message, copy out.  All contexts launch on the same stream, so enqueue order = data order."""
+
+    def __init__(self):
+        import ctypes as C
+        import threading
+        self.cv = threading.Condition()
+        self.q = {}
+        self.log = []
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def fns(self, rank):
+        def send(peer, p, n, st):
+            buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+            if self.hip.hipMemcpyAsync(buf.data_ptr(), p, n, 3, st) != 0:
+                return -3
+            with self.cv:
+                self.q.setdefault((rank, peer), []).append(buf)
+                self.log.append((rank, peer, n))
+                self.cv.notify_all()
+            return 0
+
+        def recv(peer, p, n, st):
+            with self.cv:
+                if not self.cv.wait_for(lambda: self.q.get((peer, rank)), timeout=120):
+                    return -1                                   # the peer never sent: the two ranks' exchange orders diverged (or it died)
+                buf = self.q[(peer, rank)].pop(0)
+            if buf.numel() != n:
+                return -2
+            return 0 if self.hip.hipMemcpyAsync(p, buf.data_ptr(), n, 3, st) == 0 else -3
+        return send, recv
+
+
+def _run_ranks(ctxs, fn):
+    """fn(rank, ctx) on one thread per rank; returns the results in rank order, re-raising the first failure."""
+    import threading
+    res, err = [None] * len(ctxs), []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            res[r] = fn(r, ctxs[r])
+        except BaseException as e:                              # noqa: BLE001
+            err.append((r, e))
+    ths = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(len(ctxs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not any(t.is_alive() for t in ths), "a rank thread hung"
+    if err:
+        raise AssertionError(f"rank {err[0][0]} failed: {err[0][1]}") from err[0][1]
+    return res
+
+
+@pytest.mark.parametrize("R", [2, 4, 8])
+def test_one_clip_sharded_c_level(both, R):
+    """BASELINE configs[2] from the four graph calls alone (ABI 12): R contexts = R ranks (threads on one GPU, mailbox transport) share ONE
+    clip.  R = 8 on 33 frames = PAIRED PIECES (5,4,4,4,4,4,4,4 decoded frames; GroupNorm sums swapped with the partner, Upsample3D's piece
+    role); dove_dit_forward shards rows / heads with its all-to-alls (score bound in the K blocks); dove_sr_clip chains encode -> gather of
+    the moments -> sharded DiT -> decode.  Every stage and the whole clip must equal the single-context result BIT FOR BIT."""
+    pipe, ctx0, (v, t, s, wv, wt) = both
+    g = torch.Generator().manual_seed(200 + R)
+    F, H, W = 33, 128, 192                                      # every VAE level >= 16 rows: the LDS-halo conv with fused statistics runs at each
+    video = (torch.rand(3, F, H, W, generator=g) * 2 - 1).to(BF).cuda()
+    T = 1 + (F - 1) // 4
+    noise = torch.randn(16, T, H // 8, W // 8, generator=g).cuda()
+    text = (torch.randn(226, 4096, generator=g) * 0.15).to(BF).cuda()
+    z = torch.randn(16, T, H // 8, W // 8, generator=g).to(BF).cuda()
+    hidden = torch.randn(T + T % 2, 16, H // 8, W // 8, generator=g).to(BF).cuda()
+    rope = rope_for(pipe, T + T % 2, H // 8, W // 8)
+    tproj = pipe.transformer.timestep_projection(399)
+    sa, s1 = pipe.scheduler._coeffs(torch.tensor([399]), BF)
+    m_ref = ctx0.vae_encode(video)
+    d_ref = ctx0.vae_decode(z, prescale=1 / 0.7, range01=True)
+    v_ref = ctx0.dit_forward(hidden, text, 399, rope=rope, timestep_proj=tproj)
+    clip_ref = ctx0.sr_clip(video, noise, text, 399, sa, s1, rope=rope, timestep_proj=tproj)
+    torch.cuda.synchronize()
+    box = _Mailbox()
+    ctxs = []
+    for r in range(R):
+        c = GraphContext(v, t, wv, wt, "cuda")
+        c.comm_init_custom(r, R, *box.fns(r))
+        ctxs.append(c)
+    try:
+        # ---- VAE stages: every rank writes only its frames ----
+        outs = _run_ranks(ctxs, lambda r, c: (c.shard_frames(0, F), c.vae_encode(video, out=torch.full_like(m_ref, float("nan")))))
+        torch.cuda.synchronize()
+        m = torch.full_like(m_ref, float("nan"))
+        for (first, count), o in outs:
+            assert bool(torch.isnan(o[:, :first].float()).all()) and bool(torch.isnan(o[:, first + count:].float()).all())
+            m[:, first:first + count] = o[:, first:first + count]
+        assert sum(cnt for (_, cnt), _ in outs) == m_ref.shape[1] and torch.equal(m, m_ref), "sharded encode differs"
+        outs = _run_ranks(ctxs, lambda r, c: (c.shard_frames(1, T), c.vae_decode(z, prescale=1 / 0.7, range01=True, out=torch.full_like(d_ref, float("nan")))))
+        torch.cuda.synchronize()
+        d = torch.full_like(d_ref, float("nan"))
+        for (first, count), o in outs:
+            d[:, first:first + count] = o[:, first:first + count]
+        counts = [cnt for (_, cnt), _ in outs]
+        if R == 8:
+            assert counts == [5, 4, 4, 4, 4, 4, 4, 4], counts      # paired pieces: BASELINE's "frame-chunk = 4"
+        assert sum(counts) == d_ref.shape[1] and torch.equal(d, d_ref), "sharded decode differs"
+        # ---- DiT: rows / heads sharded, the velocity complete on every rank ----
+        vs = _run_ranks(ctxs, lambda r, c: c.dit_forward(hidden, text, 399, rope=rope, timestep_proj=tproj))
+        torch.cuda.synchronize()
+        for r, vv in enumerate(vs):
+            assert torch.equal(vv, v_ref), f"sharded DiT differs on rank {r}: {float((vv.float() - v_ref.float()).abs().max())}"
+        # ---- the whole clip ----
+        clips = _run_ranks(ctxs, lambda r, c: (c.shard_frames(1, T), c.sr_clip(video, noise, text, 399, sa, s1, rope=rope, timestep_proj=tproj)))
+        torch.cuda.synchronize()
+        clip = torch.full_like(clip_ref, float("nan"))
+        for (first, count), o in clips:
+            clip[:, first:first + count] = o[:, first:first + count]
+        assert torch.equal(clip, clip_ref), f"sharded sr_clip differs: {float((clip.float() - clip_ref.float()).abs().max())}"
+        assert all(not q for q in box.q.values()), "unconsumed messages"
+        pair = [(a, b) for a, b, n in box.log if n == 65 * 8]
+        assert (len(pair) > 0) == (R > 4), "GroupNorm pair sums travel exactly when frame-batches are split"
+    finally:
+        for c in ctxs:
+            c.comm_destroy()
 
 
 def test_comm_init_rccl_single_rank(both):
