@@ -82,6 +82,14 @@ __global__ void pack_in_taps_kernel(const void* src, int dt, int cout, int C, in
     dst[((long long)t * cout_pad + co) * cin_pad + col] = f2bf(load_any(src, dt, (((long long)co * C + c) * kt + t) * 9 + tap));
   }
 }
+// temporal sums of a packed kt = 3 weight [3][taps][n]: dst [2][taps][n] = w0 + w1, (w0 + w1) + w2 in fp32, rounded once (dove_amd/ops.py pack_conv)
+__global__ void pack_first_kernel(const bf16_t* __restrict__ w, long long n, bf16_t* __restrict__ dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float s01 = bf2f(w[i]) + bf2f(w[n + i]);
+    dst[i] = f2bf(s01);
+    dst[n + i] = f2bf(s01 + bf2f(w[2 * n + i]));
+  }
+}
 __global__ void to_f32_kernel(const void* src, int dt, long long n, float* dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = load_any(src, dt, i);
 }
@@ -131,7 +139,8 @@ inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
 }
 
 struct Raw { const void* p; std::vector<long long> shape; int dt; long long numel() const { long long n = 1; for (auto d : shape) n *= d; return n; } };
-struct Packed { bf16_t* w = nullptr; float* bias = nullptr; int kt = 1, kh = 1, kw = 1, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
+struct Packed { bf16_t* w = nullptr; float* bias = nullptr; bf16_t* w_first = nullptr;   // w_first: dove_conv_desc.w_first (kt == 3)
+                int kt = 1, kh = 1, kw = 1, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
                 int cout_store() const { return (int)ru(cout, 4); } };
 struct Tensor { bf16_t* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long long elems() const { return (long long)T * H * W * C; } size_t bytes() const { return (size_t)elems() * 2; } };
 struct Stats { float* stats = nullptr; };
@@ -305,6 +314,12 @@ int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<
     row0 += (int)r->shape[0];
   }
   q.w = (bf16_t*)wp;
+  if (q.kt == 3) {                                              // temporal sums for the cache-less first frames (dove_conv_desc.w_first)
+    const long long n = (long long)q.kh * q.kw * q.cout_pad * q.cin_pad;
+    void* wf; CHK(dev_alloc(c, (size_t)2 * n * 2, &wf));
+    hipLaunchKernelGGL(pack_first_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wf);
+    q.w_first = (bf16_t*)wf;
+  }
   if (!bnames.empty()) {
     void* bp; CHK(dev_alloc(c, (size_t)q.cout_pad * 4, &bp));
     HIPCHK(hipMemsetAsync(bp, 0, (size_t)q.cout_pad * 4, 0));
@@ -373,6 +388,7 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
   d.t_in = t_in; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
   d.nb = nb; d.cache_stride = o.cache ? o.cache_stride : 0;
+  d.w_first = o.cache ? nullptr : pc.w_first;
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
   d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
   d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;

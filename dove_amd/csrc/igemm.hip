@@ -351,6 +351,8 @@ struct H4State {
   int t;                                                      // output frame of nxt's tile WITHIN its instance (dove_conv_desc.nb)
   long long f0;                                               // first input frame of that instance
   const bf16_t* cache_b;                                      // that instance's conv cache (nullptr: none)
+  int ndt;                                                    // temporal groups of nxt's tile: a.kt, or 1 / 2 for an instance's first two frames
+  const bf16_t* wf_base;                                      //   (IgemmArgs.w_first: the replicated-frame taps pre-summed), cout tile applied
   const bf16_t* wt_base;                                      // weights of nxt's cout tile
   const bf16_t* h_base;                                       // nxt's halo source: frame + channel chunk
   const bf16_t* wg_nxt;                                       // nxt's weights: tap 0 of (frame tap, chunk)
@@ -370,6 +372,12 @@ __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k
   q.ow0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_w) * halo8::TW);
   q.oh0 = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_w) * halo8::TH);
   return q;
+}
+// temporal groups of the tile whose output frame (global index over the instances) is t: see IgemmArgs.w_first
+__device__ __forceinline__ int h4_tile_ndt(const IgemmArgs& a, int t) {
+  if (a.w_first == nullptr || a.kt != 3 || a.cache != nullptr) return a.kt;
+  const int tl = a.seg_out == a.T_out ? t : t % a.seg_out;
+  return tl == 0 ? 1 : (tl == 1 ? 2 : 3);
 }
 template <bool kUp>
 __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, const H4Const& k, int id) {
@@ -404,6 +412,8 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
   s.f0 = (long long)b * a.seg_in;
   s.cache_b = a.cache ? h4_pin64(a.cache + (long long)b * a.cache_bs) : nullptr;
   s.wt_base = a.w + (long long)q.n0 * a.Cin;
+  s.ndt = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, q.t));
+  s.wf_base = a.w_first ? a.w_first + (long long)q.n0 * a.Cin : nullptr;
   s.n_dt = 0; s.n_kc = 0;
 }
 __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const H4Const& k) {   // descriptors of group nxt
@@ -413,13 +423,18 @@ __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const
   // load from the struct and keep all of it in scratch memory
   const int t = s.t;
   const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-  const int fv = t + s.n_dt - (a.kt - 1);
+  // an instance's first two frames without a conv cache (ndt < kt): group j of frame 0 is (W0+W1+W2) on frame 0; of frame 1: (W0+W1) on
+  // frame 0, then W2 on frame 1 - `dtw` is the tap block of the weights, `fv` the source frame
+  const bool first = s.ndt < a.kt;
+  const int dtw = first ? (s.ndt == 2 && s.n_dt == 1 ? 2 : 0) : s.n_dt;
+  const bf16_t* wsel = first && !(s.ndt == 2 && s.n_dt == 1) ? h4_pin64(s.wf_base + (s.ndt == 1 ? 9 : 0) * k.wtap_stride) : s.wt_base;
+  const int fv = first ? s.n_dt : t + s.n_dt - (a.kt - 1);
   const bool from_cache = a.kt > 1 && fv < 0 && s.cache_b != nullptr;
   const int fidx = a.kt > 1 ? (fv >= 0 ? fv : (from_cache ? a.kt - 1 + fv : 0)) : tin;
   const bf16_t* f = h4_pin64(from_cache ? s.cache_b + (long long)fidx * k.frame_elems : a.x + (s.f0 + fidx) * k.frame_elems);
   s.h_base = f + s.n_kc * BK;
   s.h_nrec = s.n_on ? k.frame_bytes - s.n_kc * ROWB : 0;      // off stream: zero-length descriptor -> harmless zero fill
-  s.wg_nxt = s.wt_base + (long long)(s.n_dt * 9) * k.wtap_stride + s.n_kc * BK;
+  s.wg_nxt = wsel + (long long)(dtw * 9) * k.wtap_stride + s.n_kc * BK;
   s.nrec_b_nxt = s.n_on ? k.wtap_bytes - s.n_kc * ROWB : 0;
 }
 template <bool kUp>
@@ -427,7 +442,7 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
   s.nrec_b_cur = s.nrec_b_nxt;
   if (++s.n_kc == k.kcn) {
     s.n_kc = 0;
-    if (++s.n_dt == a.kt) h4_open_tile<kUp>(s, a, k, s.n_tile + k.G);
+    if (++s.n_dt == s.ndt) h4_open_tile<kUp>(s, a, k, s.n_tile + k.G);
   }
   h4_set_nxt(s, a, k);
 }
@@ -650,7 +665,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 
     // a tile has an even number of groups (Cin % 64 == 0): two per trip, one of each halo-buffer parity - straight-line,
     // so there is no control-flow merge at which the register allocator would have to reconcile two step bodies
-    for (int g = 0; g < ngroups; g += 2) {
+    const int ng_tile = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, c.t)) * kc.kcn;   // (2 or 1 temporal groups for an instance's first frames)
+    for (int g = 0; g < ng_tile; g += 2) {
       group(I0{});
       __builtin_amdgcn_sched_barrier(0);
       h4_advance<kUp>(st, a, kc);
@@ -1377,6 +1393,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   a.kt = d->kt; a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w;
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
+  a.w_first = nullptr;
   a.out_f32 = d->out_f32;
   a.nt_out = 0;
   a.debug = 0;
@@ -1456,6 +1473,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
     case K_HALO4X:
     case K_HALO4X_UP: {
       a.gn_partial = d->gn_partial;
+      a.w_first = (kern == K_HALO4X && d->kt == 3 && !d->cache) ? (const bf16_t*)d->w_first : nullptr;
       a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;

@@ -51,6 +51,11 @@ struct IgemmArgs {
   // (nb x per-instance), seg_out / seg_in the per-instance frame counts; temporal taps, the conv cache and tmode are per instance
   int seg_out, seg_in;
   long long cache_bs;  // elements between two instances' cache frames
+  // conv3x3_halo4x, kt == 3, no conv cache (the first frame-batch of a clip / tile / chunk): the causal taps before an instance's first
+  // frame all read the REPLICATED frame 0, so output frame 0 is (W0 + W1 + W2) x0 and output frame 1 is (W0 + W1) x0 + W2 x1 - one and two
+  // temporal groups instead of three.  w_first = [2][9][Cout_pad][Cin]: the temporal sums W0 + W1 and W0 + W1 + W2, formed in fp32 and
+  // rounded to bf16 ONCE at pack time (dove_conv_desc.w_first); nullptr = three groups for every frame
+  const bf16_t* w_first;
 };
 
 // frame of the INPUT a temporal tap reads: output frame t (global index over all instances), tap dt of kt (causal: taps before an

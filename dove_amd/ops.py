@@ -27,6 +27,9 @@ class PackedConv:
     cin_pad: int
     cout: int
     cout_pad: int
+    # kt == 3: [2][kh*kw][cout_pad][cin_pad] temporal sums w0 + w1 and w0 + w1 + w2 of the bf16 weights (fp32 sums, one rounding): what a causal
+    # conv without a cache needs for its first two output frames, whose early taps all read the replicated frame 0 (dove_conv_desc.w_first)
+    w_first: torch.Tensor | None = None
 
     @property
     def cout_store(self) -> int:
@@ -49,7 +52,13 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
     if bias is not None:
         bp = torch.zeros(cout_pad, dtype=torch.float32, device=device)
         bp[:cout] = bias.detach().to(device=device, dtype=torch.float32)
-    return PackedConv(wp.contiguous(), bp, kt, kh, kw, cin, cin_pad, cout, cout_pad)
+    wp = wp.contiguous()
+    w_first = None
+    if kt == 3:
+        t = wp.float().view(3, kh * kw, cout_pad, cin_pad)
+        s01 = t[0] + t[1]
+        w_first = torch.stack([s01, s01 + t[2]]).to(torch.bfloat16).contiguous()
+    return PackedConv(wp, bp, kt, kh, kw, cin, cin_pad, cout, cout_pad, w_first)
 
 
 _profiler = None
@@ -130,6 +139,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
             assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
     d = L.ConvDesc()
     d.nb, d.cache_stride = nb, cache_stride
+    if cache is None and pc.w_first is not None:
+        d.w_first = pc.w_first.data_ptr()
     d.x, d.cache, d.w = x.data_ptr(), (cache.data_ptr() if cache is not None else None), pc.w.data_ptr()
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None

@@ -81,6 +81,14 @@ typedef struct dove_conv_desc {
   /* elements between two instances' cache frames; 0 = (kt-1) * h_in * w_in * cin (a dense [nb][kt-1][h][w][cin] array).  A cache that is
    * a view of the previous frame-batch's input [nb][t_prev][h][w][cin] passes t_prev * h_in * w_in * cin. */
   long long cache_stride;
+  /* optional (ABI 12), kt == 3 only: [2][kh*kw][cout_pad][cin] = the temporal weight sums w[0] + w[1] and w[0] + w[1] + w[2] (tap blocks of
+   * `w`), formed in fp32 and rounded to bf16 ONCE at pack time.  Without a conv cache (cache == NULL: the first frame-batch of a clip, tile
+   * or chunk) CogVideoXCausalConv3d pads the front with the REPLICATED first frame, so output frame 0 is (w0 + w1 + w2) x0 and output frame 1
+   * is (w0 + w1) x0 + w2 x1: one and two temporal taps instead of three (3 % of the causal-conv MACs of a 33-frame clip).  Used by
+   * conv3x3_halo4x_kernel when cache == NULL; ignored otherwise (NULL: three taps for every frame).  The sums differ from the three separate
+   * products by one bf16 rounding of the summed weight - inside the operator tolerance, but a caller that needs the un-summed arithmetic
+   * leaves the field NULL. */
+  const void* w_first;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 /* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm8p_kernel,
