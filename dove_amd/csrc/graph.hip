@@ -90,6 +90,21 @@ __global__ void pack_first_kernel(const bf16_t* __restrict__ w, long long n, bf1
     dst[n + i] = f2bf(s01 + bf2f(w[2 * n + i]));
   }
 }
+// sub-pixel form of an upsample-fused 3x3 conv: w [3][3][n] packed bf16 -> dst [4 phases][2x2][n]; fp32 sums in (dh, dw) order, one rounding
+__global__ void pack_sub_kernel(const bf16_t* __restrict__ w, long long n, bf16_t* __restrict__ dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dh = 0; dh < 3; ++dh)
+          for (int dw = 0; dw < 3; ++dw) {
+            const int a = (py + dh + 1) / 2 - py, b = (px + dw + 1) / 2 - px;
+            acc[2 * a + b] += bf2f(w[(long long)(dh * 3 + dw) * n + i]);
+          }
+        for (int tp = 0; tp < 4; ++tp) dst[(long long)((2 * py + px) * 4 + tp) * n + i] = f2bf(acc[tp]);
+      }
+  }
+}
 __global__ void to_f32_kernel(const void* src, int dt, long long n, float* dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = load_any(src, dt, i);
 }
@@ -139,7 +154,7 @@ inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
 }
 
 struct Raw { const void* p; std::vector<long long> shape; int dt; long long numel() const { long long n = 1; for (auto d : shape) n *= d; return n; } };
-struct Packed { bf16_t* w = nullptr; float* bias = nullptr; bf16_t* w_first = nullptr;   // w_first: dove_conv_desc.w_first (kt == 3)
+struct Packed { bf16_t* w = nullptr; float* bias = nullptr; bf16_t* w_first = nullptr, *w_sub = nullptr;   // dove_conv_desc.w_first (kt == 3) / .w_sub (3x3, kt == 1)
                 int kt = 1, kh = 1, kw = 1, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
                 int cout_store() const { return (int)ru(cout, 4); } };
 struct Tensor { bf16_t* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long long elems() const { return (long long)T * H * W * C; } size_t bytes() const { return (size_t)elems() * 2; } };
@@ -320,6 +335,12 @@ int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<
     hipLaunchKernelGGL(pack_first_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wf);
     q.w_first = (bf16_t*)wf;
   }
+  if (q.kt == 1 && q.kh == 3 && q.kw == 3) {                     // sub-pixel form for the upsample-fused use of this conv (dove_conv_desc.w_sub)
+    const long long n = (long long)q.cout_pad * q.cin_pad;
+    void* wsb; CHK(dev_alloc(c, (size_t)16 * n * 2, &wsb));
+    hipLaunchKernelGGL(pack_sub_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wsb);
+    q.w_sub = (bf16_t*)wsb;
+  }
   if (!bnames.empty()) {
     void* bp; CHK(dev_alloc(c, (size_t)q.cout_pad * 4, &bp));
     HIPCHK(hipMemsetAsync(bp, 0, (size_t)q.cout_pad * 4, 0));
@@ -389,6 +410,7 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   d.t_in = t_in; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
   d.nb = nb; d.cache_stride = o.cache ? o.cache_stride : 0;
   d.w_first = o.cache ? nullptr : pc.w_first;
+  d.w_sub = o.up == 1 ? pc.w_sub : nullptr;
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
   d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
   d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;

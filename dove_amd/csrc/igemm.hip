@@ -327,7 +327,9 @@ struct Halo4xCfg {
   static constexpr int HPS = 2;                                 // halo rounds staged per step (steps 0..5 of a group)
   static constexpr int DS0 = 4;                                 // first MFMA gap that carries a k-half-1 fragment read
   static constexpr int LDS_BYTES = 2 * halo8::A_BYTES + BR * halo8::B_BYTES;   // 147456
+  static constexpr int NT = 9;                                  // steps (spatial taps) per group
   static constexpr int nh(int tap, int nr) { return (HPS * tap + HPS <= nr) ? HPS : ((HPS * tap < nr) ? nr - HPS * tap : 0); }
+  static constexpr int round0(int tap) { return HPS * tap; }   // first halo round staged in step `tap`
   static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
   static constexpr int inflight(int tap, int nr) {              // loads issued in the BAHEAD-2 steps before step `tap`
     int n = 0;
@@ -335,11 +337,24 @@ struct Halo4xCfg {
     return n;
   }
 };
+// SUB-PIXEL form of the upsample-fused conv (kSub): a nearest x2 upsample followed by a 3x3 conv is, per output phase (oy & 1, ox & 1), a
+// 2x2 conv on the LOW-RES input with the 3x3 weights summed over the taps that hit the same low-res pixel (dove_conv_desc.w_sub: sums in
+// fp32, rounded once at pack time): 4 / 9 of the MACs.  The phase is tied to the cout tile (tiles_n = 4 x Cout / 128), so a workgroup tile is
+// 16 x 32 LOW-RES pixels of ONE phase x 128 channels: the plain halo geometry and weight sharing of the non-upsampling kernel, groups of
+// FOUR steps whose halo offsets (py + a, px + b) are per-tile VGPR bases.  The 12 halo rounds of the next group are staged in the first two
+// steps (they must have landed at the barrier of the fourth, whose tail reads the next group's first fragments); a 4-slot weight ring.
+struct Halo4xSubCfg {
+  static constexpr int NT = 4, BR = 4, BAHEAD = 3, HPS = 6, DS0 = 4;
+  static constexpr int nh(int tap, int nr) { return tap < 2 ? nr / 2 : 0; }
+  static constexpr int round0(int tap) { return HPS * tap; }
+  static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
+  static constexpr int inflight(int tap, int nr) { return issued((tap + NT - 1) % NT, nr); }
+};
 
 // Staging-side state of the persistent halo4x walk.  Plain structs + force-inlined functions (not by-reference lambda
 // closures nested three deep: those left the counters in scratch memory, where the compiler treats them as per-lane
 // values and builds every buffer descriptor through a waterfall loop).
-struct H4Tile { int n0, t, oh0, ow0; };
+struct H4Tile { int n0, t, oh0, ow0, ph; };                 // ph: output phase 2 py + px of the sub-pixel form (0 otherwise)
 struct H4Const {
   int ntiles, G, kcn, frame_bytes, wtap_bytes, tid;
   long long frame_elems, wtap_stride;
@@ -367,7 +382,10 @@ __device__ __forceinline__ const bf16_t* h4_pin64(const bf16_t* p) {
 __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k, int id) {
   unsigned rest = xcd_remap((unsigned)(id < k.ntiles ? id : k.ntiles - 1), (unsigned)k.ntiles);
   H4Tile q;
-  q.n0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_n) * halo8::BN); rest /= a.tiles_n;
+  const int nidx = (int)(rest % a.tiles_n); rest /= a.tiles_n;
+  const int ctn = a.sub ? a.tiles_n >> 2 : a.tiles_n;          // cout tiles (sub-pixel form: per phase)
+  q.ph = __builtin_amdgcn_readfirstlane(a.sub ? nidx / ctn : 0);
+  q.n0 = __builtin_amdgcn_readfirstlane((nidx - q.ph * ctn) * halo8::BN);
   q.t = __builtin_amdgcn_readfirstlane((int)(rest % a.T_out)); rest /= a.T_out;
   q.ow0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_w) * halo8::TW);
   q.oh0 = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_w) * halo8::TH);
@@ -411,7 +429,7 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
   s.t = q.t - b * a.seg_out;
   s.f0 = (long long)b * a.seg_in;
   s.cache_b = a.cache ? h4_pin64(a.cache + (long long)b * a.cache_bs) : nullptr;
-  s.wt_base = a.w + (long long)q.n0 * a.Cin;
+  s.wt_base = a.w + (long long)q.n0 * a.Cin + (long long)(q.ph * 4) * k.wtap_stride;   // sub-pixel form: [phase][2x2 tap][Cout_pad][Cin]
   s.ndt = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, q.t));
   s.wf_base = a.w_first ? a.w_first + (long long)q.n0 * a.Cin : nullptr;
   s.n_dt = 0; s.n_kc = 0;
@@ -450,13 +468,14 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // (Round 3 tried two other placements of a step's 2-4 LDS-DMA instructions - spread by sched_group_barrier: -4 %, the compiler also
 // re-clusters the fragment reads; four sched_barrier-fenced quarters of {<= 1 DMA, 4 reads, 8 MFMAs}: +-0.3 % - profiles/r03_halo4x_dma.log.
 // Unlike gemm4x's eight DMAs per step, two to four do not back up the CU's address path; the pinned order below stays.)
-template <bool kUp, bool kTiming, bool kPipe = true>
+template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
-  using CFG = Halo4xCfg;
+  using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
+  static_assert(!(kUp && kSub), "the sub-pixel form runs on the plain halo geometry of the low-res grid");
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
   constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
-  constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, HPS = CFG::HPS;
+  constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, NT = CFG::NT;
   constexpr int B0 = 2 * A_BYTES;                               // LDS: halo buffer 0 | halo buffer 1 | weight ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -562,18 +581,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   asm volatile("" ::: "memory");
 
   // fragment loaders: every address is a base VGPR + an immediate
+  // (kSub: the four taps of a group sit at halo offset (py + a, px + b) - per-tile bases abaseT[tap]; abaseN0 = tap 0 of the NEXT group's tile)
+  int abaseT[4] = {0, 0, 0, 0}, abaseN0 = 0;
+  auto sub_bases = [&](int ph, int (&bt)[4]) {
+    const int py = ph >> 1, px = ph & 1;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) bt[tp] = abase0 + ((py + (tp >> 1)) * HWID + px + (tp & 1)) * APITCH;
+  };
   auto load_a = [&](auto tapc, auto kkc, auto bufc, bf16x8 (&xf)[4]) {
     constexpr int tap = decltype(tapc)::value, kk = decltype(kkc)::value, gb = decltype(bufc)::value * A_BYTES;
     constexpr int dh = tap / 3, dw = tap % 3;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      if (kUp) {
+      if (kSub) {
+        xf[p] = *(const bf16x8*)(smem + abaseT[tap & 3] + gb + p * HWID * APITCH + kk * 32);
+      } else if (kUp) {
         const int rowimm = ((p + dh + 1) >> 1) * UHW * APITCH;
         xf[p] = *(const bf16x8*)(smem + abaseU[dw] + gb + rowimm + kk * 32);
       } else {
         xf[p] = *(const bf16x8*)(smem + abase0 + gb + ((p + dh) * HWID + dw) * APITCH + kk * 32);
       }
     }
+  };
+  auto load_a_next0 = [&](auto bufc, bf16x8 (&xf)[4]) {           // kSub: k-half 0 of tap 0 of group nxt (possibly another tile, another phase)
+    constexpr int gb = decltype(bufc)::value * A_BYTES;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) xf[p] = *(const bf16x8*)(smem + abaseN0 + gb + p * HWID * APITCH);
   };
   auto load_b = [&](auto kkc, auto slotc, bf16x8 (&wf)[4]) {
     constexpr int kk = decltype(kkc)::value, slot = decltype(slotc)::value;
@@ -590,6 +623,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   };
 
   bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
+  if (kSub) sub_bases(h4_decode(a, kc, (int)blockIdx.x).ph, abaseT);
   load_a(I0{}, I0{}, I0{}, xa);
   load_b(I0{}, I0{}, wa);
 
@@ -598,24 +632,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     constexpr int tap = decltype(tapc)::value, par = decltype(parc)::value;
     constexpr int NH = CFG::nh(tap, NR);                       // halo rounds staged in this step
     constexpr int PEND = CFG::inflight(tap, NR);               // (issue counts are tap-periodic: loads are unconditional)
-    constexpr int stap = tap + BAHEAD;                         // the weight tap staged now (>= 9: of group nxt)
+    constexpr int stap = tap + BAHEAD;                         // the weight tap staged now (>= NT: of group nxt)
+    constexpr int R0 = CFG::round0(tap);
     using Par = std::integral_constant<int, par>;
     using NPar = std::integral_constant<int, 1 - par>;
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PEND) : "memory");   // drain all but the last BAHEAD-2 steps' loads,
     __builtin_amdgcn_s_barrier();                                  // then the step barrier (LDS hand-off point)
     __builtin_amdgcn_sched_barrier(0);
     // ---- from here to the end of the step: ONE basic block ----
-    if (stap == 9) b_wp = wg_nxt;
-    stage_b(std::integral_constant<int, (stap + 3 * par) % 6>{}, stap < 9 ? nrec_b_cur : nrec_b_nxt);
-    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? HPS * tap : 0)>{}, NPar{});
-    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? HPS * tap + 1 : 0)>{}, NPar{});
+    if (stap == NT) b_wp = wg_nxt;
+    stage_b(std::integral_constant<int, (stap + NT * par) % BR>{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
+    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
+    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? R0 + 2 : 0)>{}, NPar{});
+    if (NH >= 4) stage_halo_round(std::integral_constant<int, (NH >= 4 ? R0 + 3 : 0)>{}, NPar{});
+    if (NH >= 5) stage_halo_round(std::integral_constant<int, (NH >= 5 ? R0 + 4 : 0)>{}, NPar{});
+    if (NH >= 6) stage_halo_round(std::integral_constant<int, (NH >= 6 ? R0 + 5 : 0)>{}, NPar{});
     load_a(tapc, I1{}, Par{}, xb);
-    load_b(I1{}, std::integral_constant<int, (tap + 3 * par) % 6>{}, wb);
+    load_b(I1{}, std::integral_constant<int, (tap + NT * par) % BR>{}, wb);
     mma(wa, xa);
-    // next step's k-half 0 (tap 8: tap 0 of group nxt - after a tile's last group that is the NEXT tile's first)
-    if (tap < 8) load_a(std::integral_constant<int, (tap + 1) % 9>{}, I0{}, Par{}, xa);
+    // next step's k-half 0 (last tap: tap 0 of group nxt - after a tile's last group that is the NEXT tile's first)
+    if (tap < NT - 1) load_a(std::integral_constant<int, (tap + 1) % NT>{}, I0{}, Par{}, xa);
+    else if (kSub) load_a_next0(NPar{}, xa);
     else load_a(I0{}, I0{}, NPar{}, xa);
-    load_b(I0{}, std::integral_constant<int, (tap + 1 + 3 * par) % 6>{}, wa);
+    load_b(I0{}, std::integral_constant<int, (tap + 1 + NT * par) % BR>{}, wa);
     mma(wb, xb);
     // pinned interleave: the staging work and one fragment read per MFMA gap
 #pragma unroll
@@ -637,9 +677,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   auto group = [&](auto parc) {
     step(std::integral_constant<int, 0>{}, parc); step(std::integral_constant<int, 1>{}, parc);
     step(std::integral_constant<int, 2>{}, parc); step(std::integral_constant<int, 3>{}, parc);
-    step(std::integral_constant<int, 4>{}, parc); step(std::integral_constant<int, 5>{}, parc);
-    step(std::integral_constant<int, 6>{}, parc); step(std::integral_constant<int, 7>{}, parc);
-    step(std::integral_constant<int, 8>{}, parc);
+    if (!kSub) {
+      step(std::integral_constant<int, (kSub ? 0 : 4)>{}, parc); step(std::integral_constant<int, (kSub ? 0 : 5)>{}, parc);
+      step(std::integral_constant<int, (kSub ? 0 : 6)>{}, parc); step(std::integral_constant<int, (kSub ? 0 : 7)>{}, parc);
+      step(std::integral_constant<int, (kSub ? 0 : 8)>{}, parc);
+    }
   };
 
   // epilogue-side lane role: 8 lanes x 8 channels cover 64 channels (128 B) of one pixel
@@ -666,12 +708,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     // a tile has an even number of groups (Cin % 64 == 0): two per trip, one of each halo-buffer parity - straight-line,
     // so there is no control-flow merge at which the register allocator would have to reconcile two step bodies
     const int ng_tile = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, c.t)) * kc.kcn;   // (2 or 1 temporal groups for an instance's first frames)
+    int next_base0 = 0;
+    if (kSub) {                                                 // halo offsets of this tile's phase; tap 0 of the next tile's
+      sub_bases(c.ph, abaseT);
+      int nb4[4];
+      sub_bases(h4_decode(a, kc, tile + G).ph, nb4);
+      next_base0 = nb4[0];
+    }
     for (int g = 0; g < ng_tile; g += 2) {
+      if (kSub) abaseN0 = abaseT[0];                            // group(I0)'s last step prefetches this tile's next group
       group(I0{});
       __builtin_amdgcn_sched_barrier(0);
       h4_advance<kUp>(st, a, kc);
       publish(st);
       __builtin_amdgcn_sched_barrier(0);
+      if (kSub) abaseN0 = (g + 2 >= ng_tile) ? next_base0 : abaseT[0];   // ... the tile's last group the NEXT tile's first
       group(I1{});
       __builtin_amdgcn_sched_barrier(0);
       h4_advance<kUp>(st, a, kc);
@@ -697,8 +748,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int px = it * 8 + e_px;
-        const bool okw = c.ow0 + px < a.W_out;
-        o_off[it] = okw ? (unsigned)((px * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
+        // kSub: the tile is 16 x 32 LOW-RES pixels of one phase: output pixel (2 y + py, 2 x + px) - every other pixel of a 64-pixel row segment
+        const bool okw = kSub ? c.ow0 + px < a.W_in : c.ow0 + px < a.W_out;
+        o_off[it] = okw ? (unsigned)(((kSub ? 2 * px : px) * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
         r_off[it] = okw ? (unsigned)((px * (int)a.ldr + e_ch * 8) * 2) : 0x80000000u;
       }
       auto emit = [&](auto has_resid, auto has_gn) {
@@ -727,10 +779,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int oh = c.oh0 + 4 * wave + p;
-          const long long pix0 = ((long long)c.t * a.H_out + oh) * a.W_out + c.ow0;
-          const bool okh = oh < a.H_out;
+          const long long pix0 = kSub ? ((long long)c.t * a.H_out + 2 * oh + (c.ph >> 1)) * a.W_out + 2 * c.ow0 + (c.ph & 1)
+                                      : ((long long)c.t * a.H_out + oh) * a.W_out + c.ow0;
+          const bool okh = kSub ? oh < a.H_in : oh < a.H_out;
           const auto srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + pix0 * a.ldo + c.n0), (short)0,
-                                                               okh ? (int)(TW * a.ldo * 2) : 0, 0x00020000);
+                                                               okh ? (int)((kSub ? 2 * TW : TW) * a.ldo * 2) : 0, 0x00020000);
           const auto srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.resid + pix0 * a.ldr + c.n0 : a.out), (short)0,
                                                                (kRes && okh) ? (int)(TW * a.ldr * 2) : 0, 0x00020000);
 #pragma unroll
@@ -785,7 +838,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         if (kGn) {
           // lane totals -> totals over the wave's 128 pixels (lanes that differ in e_px), then one (sum, sumsq) per group
           const int cpg_log = a.cpg_log;                       // 2, 3 or 4 channels-per-group bits (Cout 128 / 256 / 512)
-          const long long row = ((((long long)c.t * a.tiles_h + (c.oh0 >> 4)) * a.tiles_w + (c.ow0 >> 5)) << 2) + wave;
+          const long long tix = ((long long)c.t * a.tiles_h + (c.oh0 >> 4)) * a.tiles_w + (c.ow0 >> 5);
+          const long long row = ((kSub ? tix * 4 + c.ph : tix) << 2) + wave;      // kSub: a row per phase (the four phases write the same channels)
           float* dst = a.gn_partial + row * 64;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -1235,9 +1289,9 @@ __global__ __launch_bounds__(256) void smallk_kernel(const bf16_t* __restrict__ 
   }
 }
 
-enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM8P, K_SMALLK };
+enum ConvKernel { K_IGEMM = 0, K_IGEMM_FAST, K_HALO4X, K_HALO4X_UP, K_GEMM8P, K_SMALLK, K_HALO4X_SUB };
 static const char* const kKernelNames[] = {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "conv3x3_halo4x_kernel", "gemm8p_kernel",
-                                           "smallk_kernel"};
+                                           "smallk_kernel", "conv3x3_halo4x_kernel"};
 
 static inline int desc_nb(const dove_conv_desc* d) { return d->nb > 1 ? d->nb : 1; }
 
@@ -1262,6 +1316,8 @@ static ConvKernel select_kernel(const dove_conv_desc* d) {
     const bool ups = d->up == 1 && d->kt == 1 && d->h_out == 2 * d->h_in && d->w_out == 2 * d->w_in && d->h_out >= 16 && d->w_out >= 32;
     const bool h4 = d->cout_store % 128 == 0 && d->cin % 64 == 0 && d->ldo < (1 << 20) && (!d->resid || d->ldr < (1 << 20));
     if (same && h4) return K_HALO4X;
+    // sub-pixel form (4 / 9 of the MACs) when the caller packed the phase-summed weights and the LOW-RES grid fills the 16 x 32 tile
+    if (ups && h4 && d->w_sub && d->h_in >= 16 && d->w_in >= 32) return K_HALO4X_SUB;
     if (ups && h4) return K_HALO4X_UP;
   }
   const int BN = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
@@ -1305,9 +1361,13 @@ static int cu_count() {
 extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
   if (!desc_size_ok(d, "conv_gn_partial_rows")) return 0;
   const ConvKernel k = select_kernel(d);
-  if (k != K_HALO4X && k != K_HALO4X_UP) return 0;
+  if (k != K_HALO4X && k != K_HALO4X_UP && k != K_HALO4X_SUB) return 0;
   if (d->cout_store != 128 && d->cout_store != 256 && d->cout_store != 512) return 0;   // 4 / 8 / 16 channels per group
   if (d->cout_store != d->cout_pad) return 0;
+  if (k == K_HALO4X_SUB) {                                      // tiles of the LOW-RES grid x 4 phases x 4 waves
+    const long long th = (d->h_in + halo8::TH - 1) / halo8::TH, tw = (d->w_in + halo8::TW - 1) / halo8::TW;
+    return (long long)desc_nb(d) * d->t_out * th * tw * 16;
+  }
   const long long th = (d->h_out + halo8::TH - 1) / halo8::TH, tw = (d->w_out + halo8::TW - 1) / halo8::TW;
   return (long long)desc_nb(d) * d->t_out * th * tw * 4;      // instance-major: instance b owns rows [b * rows / nb, (b + 1) * rows / nb)
 }
@@ -1394,6 +1454,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
   a.w_first = nullptr;
+  a.sub = 0;
   a.out_f32 = d->out_f32;
   a.nt_out = 0;
   a.debug = 0;
@@ -1468,6 +1529,24 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       dim3 grid((unsigned)((M + 4 * smallk::ROWS - 1) / (4 * smallk::ROWS)), (unsigned)((d->cout_store + 255) / 256));
       hipLaunchKernelGGL(smallk_kernel, grid, dim3(256), 0, s, a.x, a.w, a.bias, a.out, M, d->cout_store, d->ldo);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(smallk)");
+      return DOVE_OK;
+    }
+    case K_HALO4X_SUB: {
+      a.gn_partial = d->gn_partial;
+      a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
+      a.sub = 1;
+      a.w = (const bf16_t*)d->w_sub;                            // [4 phases][2x2 taps][cout_pad][cin]
+      a.tiles_w = (d->w_in + halo8::TW - 1) / halo8::TW;        // tiles of the LOW-RES grid, one per phase and cout tile
+      a.tiles_h = (d->h_in + halo8::TH - 1) / halo8::TH;
+      a.tiles_n = 4 * (d->cout_pad / 128);
+      const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+      DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
+      static PerDeviceOnce attrs;
+      if (attrs.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+      const int cus = cu_count();
+      const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
+      hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x sub-pixel)");
       return DOVE_OK;
     }
     case K_HALO4X:

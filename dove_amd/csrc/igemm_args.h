@@ -56,6 +56,7 @@ struct IgemmArgs {
   // temporal groups instead of three.  w_first = [2][9][Cout_pad][Cin]: the temporal sums W0 + W1 and W0 + W1 + W2, formed in fp32 and
   // rounded to bf16 ONCE at pack time (dove_conv_desc.w_first); nullptr = three groups for every frame
   const bf16_t* w_first;
+  int sub;             // conv3x3_halo4x<kSub>: sub-pixel form of the upsample-fused conv - `w` = dove_conv_desc.w_sub, tiling over the LOW-RES grid
 };
 
 // frame of the INPUT a temporal tap reads: output frame t (global index over all instances), tap dt of kt (causal: taps before an

@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
         ("up", C.c_int), ("tmode", C.c_int), ("act", C.c_int),
         ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
         ("gn_partial", C.c_void_p), ("out_f32", C.c_int),
-        ("nb", C.c_int), ("cache_stride", C.c_longlong), ("w_first", C.c_void_p),
+        ("nb", C.c_int), ("cache_stride", C.c_longlong), ("w_first", C.c_void_p), ("w_sub", C.c_void_p),
     ]
 
     def __init__(self, *a, **k):

@@ -30,6 +30,9 @@ class PackedConv:
     # kt == 3: [2][kh*kw][cout_pad][cin_pad] temporal sums w0 + w1 and w0 + w1 + w2 of the bf16 weights (fp32 sums, one rounding): what a causal
     # conv without a cache needs for its first two output frames, whose early taps all read the replicated frame 0 (dove_conv_desc.w_first)
     w_first: torch.Tensor | None = None
+    # 3x3, kt == 1: [4 phases][2x2 taps][cout_pad][cin_pad] - the sub-pixel form of an upsample-fused conv (dove_conv_desc.w_sub): per output
+    # phase the 3x3 weights summed over the taps that read the same low-res pixel (fp32 sums of the bf16 weights, one rounding)
+    w_sub: torch.Tensor | None = None
 
     @property
     def cout_store(self) -> int:
@@ -58,7 +61,18 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
         t = wp.float().view(3, kh * kw, cout_pad, cin_pad)
         s01 = t[0] + t[1]
         w_first = torch.stack([s01, s01 + t[2]]).to(torch.bfloat16).contiguous()
-    return PackedConv(wp, bp, kt, kh, kw, cin, cin_pad, cout, cout_pad, w_first)
+    w_sub = None
+    if kt == 1 and kh == 3 and kw == 3:
+        t = wp.float().view(3, 3, cout_pad, cin_pad)
+        w_sub = torch.zeros(4, 4, cout_pad, cin_pad, dtype=torch.float32, device=device)
+        for py in range(2):
+            for px in range(2):
+                for dh in range(3):                       # fixed summation order (csrc/graph.hip pack_sub_kernel: the same)
+                    for dw in range(3):
+                        a, b = (py + dh + 1) // 2 - py, (px + dw + 1) // 2 - px
+                        w_sub[2 * py + px, 2 * a + b] += t[dh, dw]
+        w_sub = w_sub.to(torch.bfloat16).contiguous()
+    return PackedConv(wp, bp, kt, kh, kw, cin, cin_pad, cout, cout_pad, w_first, w_sub)
 
 
 _profiler = None
@@ -89,6 +103,7 @@ def conv_kernel_name(x_shape, pc: PackedConv, *, stride=1, pad=(None, None), up=
     d.ldo = pc.cout_store
     d.ldr = pc.cout_store if resid else 0
     d.resid = 1 if (resid or gated) else None                  # only tested for NULL-ness by the selection rule
+    d.w_sub = 1 if (up == 1 and pc.kt == 1 and pc.kh == 3 and pc.kw == 3) else None
     d.gate = 1 if gated else None
     return L.load().dove_conv_kernel_name(C.byref(d)).decode()
 
@@ -141,6 +156,8 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     d.nb, d.cache_stride = nb, cache_stride
     if cache is None and pc.w_first is not None:
         d.w_first = pc.w_first.data_ptr()
+    if up == 1 and pc.w_sub is not None:
+        d.w_sub = pc.w_sub.data_ptr()
     d.x, d.cache, d.w = x.data_ptr(), (cache.data_ptr() if cache is not None else None), pc.w.data_ptr()
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None

@@ -89,6 +89,13 @@ typedef struct dove_conv_desc {
    * products by one bf16 rounding of the summed weight - inside the operator tolerance, but a caller that needs the un-summed arithmetic
    * leaves the field NULL. */
   const void* w_first;
+  /* optional (ABI 12), up == 1 with a 3x3 (kt == 1) kernel: [4 phases][2x2 taps][cout_pad][cin] = the SUB-PIXEL form of the upsample-fused conv.
+   * A nearest x2 upsample followed by a 3x3 conv is, for output phase (py, px) = (oy & 1, ox & 1), a 2x2 conv on the low-res input:
+   *   out[2y + py][2x + px] = sum_{a,b in {0,1}} w_sub[2 py + px][2 a + b] . in[y + py - 1 + a][x + px - 1 + b]   (zero outside the frame),
+   *   w_sub[2 py + px][2 a + b] = sum of w[dh][dw] over the dh with (py + dh + 1) / 2 == py + a and the dw with (px + dw + 1) / 2 == px + b
+   * (integer division), formed in fp32 and rounded to bf16 ONCE at pack time - 4 / 9 of the MACs of Upsample3D's conv.  Used when the low-res grid
+   * is at least 16 x 32; NULL = the direct form (upsample folded into the addressing, all 9 taps). */
+  const void* w_sub;
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 /* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm8p_kernel,

@@ -81,6 +81,12 @@ CONV_CASES = [
     ("c2d_halo4x_k64_many", 64, 128, (3, 3), 20, 64, 128, {}),
     ("c2d_halo4x_kt1_resid", 128, 256, (3, 3), 2, 24, 40, {"resid": True}),
     # Cin_pad == 32 convs with H, W >= 16 (direct encoder.conv_in 3 -> 128 of the tiled VAE, decoder.conv_in 16 -> 512): igemm_fast
+    # SUB-PIXEL form of the upsample-fused conv (dove_conv_desc.w_sub; low-res grid >= 16 x 32): ragged low-res edges in both directions,
+    # several tiles, two cout tiles per phase, Upsample3D's two time-doubling maps
+    ("c2d_up_sub", 128, 128, (3, 3), 2, 17, 37, {"up": 1, "pad": (1, 1)}),
+    ("c2d_up_sub_256", 256, 256, (3, 3), 2, 20, 70, {"up": 1, "pad": (1, 1)}),
+    ("c2d_up_sub_t1", 128, 128, (3, 3), 2, 16, 32, {"up": 1, "pad": (1, 1), "tmode": 1, "t_out": 4}),
+    ("c2d_up_sub_t2", 64, 256, (3, 3), 3, 18, 40, {"up": 1, "pad": (1, 1), "tmode": 2, "t_out": 5}),
     ("c3d_conv_in_enc", 3, 128, (3, 3, 3), 3, 40, 48, {"cache": True}),
     ("c3d_conv_in_dec", 16, 512, (3, 3, 3), 2, 18, 34, {}),
 ]
@@ -521,6 +527,32 @@ def test_attention_bound_anti_aligned_at_cutoff():
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=bad)
     torch.cuda.synchronize()
     close("attention_nan_bound", got, ref, rtol=3e-2, afrac=8e-3)
+
+
+def test_conv_subpixel_is_the_kernel_and_matches_direct_form():
+    """The production upsample shapes dispatch to the sub-pixel variant when the phase-summed weights are handed over; its result equals the
+    direct form (upsample folded into the addressing, 9 taps) up to the one bf16 rounding of the summed weights; the fused GroupNorm
+    statistics (a partial row per tile, phase and wave) equal a statistics pass over the output; nb instances == nb calls, bit for bit."""
+    pc_c, pc_g = pack(256, 256, (3, 3))
+    assert pc_g.w_sub is not None and pc_g.w_sub.shape == (4, 4, 256, 256)
+    x = rnd(2, 36, 54, 256, seed=5).cuda()
+    kw = dict(up=1, pad=(1, 1), tmode=1, t_out=4)
+    y = ops.conv(x, pc_g, gn_eps=1e-6, **kw)
+    assert y.gn_rows.shape[0] == 4 * 3 * 2 * 16, y.gn_rows.shape     # frames x (3 x 2 low-res tiles) x 4 phases x 4 waves
+    ref_stats = ops.groupnorm_stats(y, 1e-6)
+    assert torch.allclose(y.gn_stats[0].cpu(), ref_stats.cpu(), rtol=2e-4, atol=2e-5)
+    w_sub, pc_g.w_sub = pc_g.w_sub, None                          # the direct form: the same conv without the summed weights
+    direct = ops.conv(x, pc_g, **kw)
+    pc_g.w_sub = w_sub
+    torch.cuda.synchronize()
+    close("subpixel_vs_direct", y, direct, rtol=1.6e-2, afrac=4e-3)
+    assert not torch.equal(y, direct)                              # (it IS another kernel and another rounding of the weights)
+    xb = torch.cat([x, rnd(2, 36, 54, 256, seed=6).cuda()])
+    yb = ops.conv(xb, pc_g, nb=2, gn_eps=1e-6, **kw)
+    y2 = ops.conv(xb[2:].contiguous(), pc_g, gn_eps=1e-6, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(yb[:4], y) and torch.equal(yb[4:], y2)
+    assert torch.equal(yb.gn_stats[0][0], y.gn_stats[0]) and torch.equal(yb.gn_stats[0][1], y2.gn_stats[0])
 
 
 @pytest.mark.parametrize("cin,cout,k,T,H,W,up,resid", [
