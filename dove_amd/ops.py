@@ -79,8 +79,8 @@ _profiler = None
 
 
 def set_profiler(records: list | None):
-    """bench.py hook: when a list is installed, every igemm launch appends (key, algorithmic_flops, ev_start, ev_end)
-    with HIP events recorded on the launch stream."""
+    """bench.py hook: when a list is installed, every igemm launch appends (key, algorithmic_flops, ev_start, ev_end, kernel_name,
+    issued_flops) with HIP events recorded on the launch stream (issued < algorithmic where a weight-summed form skips duplicate taps)."""
     global _profiler
     _profiler = records
 
@@ -191,7 +191,16 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
     if _profiler is not None:
         e1.record()
         flops = 2.0 * nb * t_out * hw_out[0] * hw_out[1] * pc.cout * pc.cin * pc.kt * pc.kh * pc.kw
-        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1, L.load().dove_conv_kernel_name(C.byref(d)).decode()))
+        name = L.load().dove_conv_kernel_name(C.byref(d)).decode()
+        # MFMA work actually issued: the ALGORITHMIC count above is the reference's formulation; the weight-summed forms skip taps whose
+        # input is a duplicate (w_first: 2 + 1 of the first two frames' 3 + 3 temporal taps per instance; w_sub: 5 of 9 spatial taps)
+        real = flops
+        if name == "conv3x3_halo4x_kernel":
+            if d.w_first and pc.kt == 3 and up == 0:
+                real = flops * (1.0 - (2.0 + (1.0 if t_out > 1 else 0.0)) / (3.0 * t_out))
+            elif d.w_sub and up == 1 and H >= 16 and W >= 32:
+                real = flops * 4.0 / 9.0
+        _profiler.append(((pc.cin, pc.cout, pc.kt * pc.kh * pc.kw), flops, e0, e1, name, real))
     if partial is None:
         if getattr(out, "gn_stats", None) is not None:      # a re-used `out` tensor must not keep statistics of old contents
             out.gn_stats = None
