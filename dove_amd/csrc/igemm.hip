@@ -1355,6 +1355,12 @@ static int cu_count() {
     (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     if (dev >= 0 && dev < DOVE_MAX_DEVICES) cus[dev].store(n, std::memory_order_relaxed);
   }
+#ifdef DOVE_TIMING_BUILD
+  {
+    const char* e = getenv("DOVE_CU_LIMIT");                  // tools/cumask_probe.py: persistent grids sized for a CU-masked stream
+    if (e && atoi(e) > 0 && atoi(e) < n) return atoi(e);
+  }
+#endif
   return n;
 }
 
