@@ -45,10 +45,12 @@ def main():
     _t = timeit
     timeit = lambda fn, iters=args.iters, warm=2: _t(fn, iters=min(iters, args.iters), warm=min(warm, 2))   # noqa: E731
 
-    def conv_case(name, cin, cout, k, T, H, W, **kw):
+    def conv_case(name, cin, cout, k, T, H, W, direct=False, **kw):
         if not want(name):
             return
         pc = pack(cout, cin, k)
+        if direct:                 # the forms without the pack-time weight sums (dove_conv_desc.w_first / w_sub = NULL)
+            pc.w_first = pc.w_sub = None
         x = torch.randn(T, H, W, pc.cin_pad, device=dev).to(BF)
         y = ops.conv(x, pc, **kw)
         dt = timeit(lambda: ops.conv(x, pc, out=y, **kw))
@@ -63,6 +65,7 @@ def main():
     conv_case("conv3d 3->128 9x720x1280", 3, 128, (3, 3, 3), 9, 720, 1280)
     conv_case("conv3d 128->3 9x720x1280", 128, 3, (3, 3, 3), 9, 720, 1280)
     conv_case("conv2d up 256->256 ->8x720x1280", 256, 256, (3, 3), 8, 360, 640, up=1, pad=(1, 1))
+    conv_case("conv2d updirect 256->256 ->8x720x1280", 256, 256, (3, 3), 8, 360, 640, direct=True, up=1, pad=(1, 1))
     conv_case("conv2d down 128 s2 9x720x1280", 128, 128, (3, 3), 9, 720, 1280, stride=2, pad=(0, 0))
 
     N = 18226
