@@ -1217,8 +1217,10 @@ static const bf16_t* zero_page() {
 // ------------------------------------------------------------------------------------------------
 // Dispatch.  ONE selection rule (used by the launch, by dove_conv_gn_partial_rows and by dove_conv_kernel_name); no
 // environment switches.  Which shapes of the 33x720x1280 clip reach which kernel:
-//   conv3x3_halo4x  3x3(x3) stride-1 convs with Cin % 64 == 0, Cout % 128 == 0, H, W >= 16 (every VAE resnet conv) and the
-//                   upsample-fused 3x3 convs (Upsample3D)                                       268 + 12 launches, 55 % of the step
+//   conv3x3_halo4x  3x3(x3) stride-1 convs with Cin % 64 == 0, Cout % 128 == 0, H, W >= 16 (every VAE resnet conv; without a conv cache and
+//                   with dove_conv_desc.w_first the first two frames run 1 / 2 temporal groups) and the upsample-fused 3x3 convs of
+//                   Upsample3D - in SUB-PIXEL form (<kSub>, dove_conv_desc.w_sub, low-res grid >= 16 x 32: 4 / 9 of the MACs), else with
+//                   the upsample folded into the addressing (<kUp>)                             268 + 12 launches, 55 % of the step
 //   gemm8p          plain GEMMs with M >= 4096, Cout % 256 == 0, Cin % 128 == 0, Cin >= 256 (DiT qkv / out / ff)    168 launches
 //   smallk          pointwise convs with Cin_pad == 32: SpatialNorm conv_y||conv_b on the latent grid                    158 launches
 //   igemm_fast      everything else without upsampling: stride-2 downsample convs, the (3,1,1) forms of encoder.conv_in / decoder.conv_out,
