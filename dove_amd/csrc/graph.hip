@@ -1300,8 +1300,11 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
   int rc = 0;
   for (size_t k = 0; k < classes.size() && !rc; ++k) {
     const Cls& cl = classes[k];
-    for (size_t m0 = 0; m0 < cl.members.size() && !rc; m0 += 64) {             // (TileOrigins holds 64 tiles; 20 at 720x1280)
-      const int nb = (int)std::min<size_t>(64, cl.members.size() - m0);
+    // at most 16 tiles per batch: activations scale with the batch (the 30 interior tiles of a 1088x1920 clip would hold > 100 GB live), and
+    // 16 is past the point where the launches fill the chip; per tile the result does not depend on the batching
+    constexpr size_t kTileBatchMax = 16;
+    for (size_t m0 = 0; m0 < cl.members.size() && !rc; m0 += kTileBatchMax) {
+      const int nb = (int)std::min<size_t>(kTileBatchMax, cl.members.size() - m0);
       TileOrigins org; org.n = nb;
       for (int n = 0; n < nb; ++n) { org.oy[n] = (short)ii[cl.members[m0 + n].first]; org.ox[n] = (short)jj[cl.members[m0 + n].second]; }
       clear_caches(c);

@@ -107,6 +107,7 @@ class AutoencoderKLCogVideoX:
         self.tile_batching = True
         self.tile_streams = 2
         self._tile_stream = None
+        self.tile_batch_max = 16
         self._pack(state_dict)
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -310,6 +311,13 @@ class AutoencoderKLCogVideoX:
             for a, i in enumerate(ii):
                 for b, j in enumerate(jj):
                     classes.setdefault((min(tile_h, H - i), min(tile_w, W - j)), []).append((a, b))
+            # at most tile_batch_max tiles per batch: activations scale with the batch (30 interior tiles of a 1088x1920 clip would hold
+            # 118 GB live; 16 is past the point where the launches fill the chip).  Per tile the result does not depend on the batching
+            split = {}
+            for (shape, members) in classes.items():
+                for k in range(0, len(members), self.tile_batch_max):
+                    split[shape + (k,)] = members[k:k + self.tile_batch_max]
+            classes = split
             order = sorted(classes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
             # tile_streams = 2: the largest class stays on the caller's stream, the edge classes (a fifth of the work at 720x1280) run
             # on a second HIP stream - their launches fill the CUs the big class leaves idle in its partly filled last rounds and at
@@ -320,7 +328,7 @@ class AutoencoderKLCogVideoX:
                     self._tile_stream = torch.cuda.Stream(device=self.device)
                 side, main = self._tile_stream, torch.cuda.current_stream()
                 side.wait_stream(main)                          # x_cl was produced on the caller's stream
-            for k, ((th, tw), members) in enumerate(order):
+            for k, ((th, tw, _), members) in enumerate(order):
                 nb = len(members)
                 cache, parts = {}, []
                 self._nb = nb
