@@ -78,20 +78,63 @@ def _kernel_body(lines, mangled_prefix):
     return lines[start:end + 1]
 
 
-def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(tmp_path):
+@pytest.fixture(scope="module")
+def igemm_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "g.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-result",
+                           os.path.join(ROOT, "dove_amd", "csrc", "igemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _bare_vmcnt_waits(walk):
+    in_asm, bare = False, []
+    for l in walk:
+        if "#ASMSTART" in l:
+            in_asm = True
+        elif "#ASMEND" in l:
+            in_asm = False
+        elif "s_waitcnt" in l and "vmcnt" in l and not in_asm:
+            bare.append(l.strip())
+    return bare
+
+
+@pytest.mark.parametrize("variant,taps", [("ILb0ELb0ELb1ELb0E", 9), ("ILb1ELb0ELb1ELb0E", 9), ("ILb0ELb0ELb1ELb1E", 4)],
+                         ids=["direct", "upsample-in-addressing", "sub-pixel"])
+def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, taps):
+    """conv3x3_halo4x runs ONE wave per SIMD on the whole 512-register file: its 4 x 4 accumulator tile is the 256 AGPRs, everything else
+    must fit the 256 VGPRs WITHOUT scratch (a spill inside the tap walk costs more than any schedule gains).  Its operand ring is kept
+    in flight by hand-counted `s_waitcnt vmcnt(n)` in asm; a wait the compiler adds on its own between the first and the last MFMA
+    means it lost track of the queue and drains the ring there (what happened to gemm8p in round 3).  The unrolled body is two groups of
+    `taps` spatial-tap steps x 32 MFMAs (9 taps; 4 in the sub-pixel form of the upsample-fused conv, dove_conv_desc.w_sub)."""
+    text = igemm_asm
+    name = f"_Z21conv3x3_halo4x_kernel{variant}Ev9IgemmArgs"
+
+    def prop(key):
+        m = re.search(rf"\.set {name}\.{key}, (\d+)", text)
+        assert m, f"{name}: no {key} record"
+        return int(m.group(1))
+
+    assert prop("private_seg_size") == 0, f"{name}: scratch in use"
+    assert prop("num_agpr") == 256 and prop("num_vgpr") <= 256, f"{name}: register budget {prop('num_vgpr')} + {prop('num_agpr')}"
+    body = _kernel_body(text.split("\n"), name)
+    assert not any("scratch_" in l for l in body), f"{name}: scratch instructions"
+    mf = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(mf) == 2 * taps * 32, f"{name}: expected 2 groups x {taps} taps x 32 MFMAs, found {len(mf)}"
+    bare = _bare_vmcnt_waits(body[mf[0]:mf[-1]])
+    assert not bare, f"{name}: compiler-inserted vmcnt waits inside the tap walk: {bare}"
+
+
+def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(igemm_asm):
     """gemm8p stages its operands one K-64 step ahead by LDS-DMA and waits for them with hand-placed `s_waitcnt vmcnt(0)` at the two
     places the ring argument needs (igemm.hip: end of LOAD / MFMA of the odd phases).  hipcc's own wait insertion knows nothing about
     those asm waits: when the epilogue's VGPR loads looked pending to it at the K loop's header, it put `s_waitcnt vmcnt(1)` /
     `vmcnt(0)` in front of the first fragment reads of every 128-deep chunk and drained the stream there (round 3; fixed by ending the
     epilogue with the `s_waitcnt` BUILTIN, which its tracking sees).  Pinned here: inside the K walk every vmcnt wait sits in an asm
     block, each phase has its 12 fragment reads and 16 MFMAs, and the kernel uses no scratch."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    out = tmp_path / "g.s"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-result",
-                           os.path.join(ROOT, "dove_amd", "csrc", "igemm.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
-    text = open(out).read()
+    text = igemm_asm
     lines = text.split("\n")
     for variant in ("ILb0ELb0ELb0E", "ILb1ELb0ELb0E", "ILb0ELb1ELb0E"):          # plain, GELU, gated
         name = f"_Z13gemm8p_kernel{variant}Ev9IgemmArgsx"
@@ -103,14 +146,7 @@ def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(tmp_path):
         assert len(mf) == 64, f"{name}: expected 4 phases x 16 MFMAs in the unrolled chunk, found {len(mf)}"
         first_read = next(i for i, l in enumerate(body) if "ds_read_b128" in l)      # the prologue only stages; the epilogue's reads follow the last MFMA
         walk = body[first_read - 2:mf[-1] + 12]
-        in_asm, bare = False, []
-        for l in walk:
-            if "#ASMSTART" in l:
-                in_asm = True
-            elif "#ASMEND" in l:
-                in_asm = False
-            elif "s_waitcnt" in l and "vmcnt" in l and not in_asm:
-                bare.append(l.strip())
+        bare = _bare_vmcnt_waits(walk)
         assert not bare, f"{name}: compiler-inserted vmcnt waits inside the K walk would drain the operand stream: {bare}"
         assert sum("ds_read_b128" in l for l in walk) == 48, f"{name}: 12 fragment reads per phase expected"
         assert sum("lds" in l and "buffer_load_dwordx4" in l for l in walk) == 16, f"{name}: 8 LDS-DMAs in each of the two even phases expected"
