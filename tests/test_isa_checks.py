@@ -150,3 +150,30 @@ def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(igemm_asm):
         assert not bare, f"{name}: compiler-inserted vmcnt waits inside the K walk would drain the operand stream: {bare}"
         assert sum("ds_read_b128" in l for l in walk) == 48, f"{name}: 12 fragment reads per phase expected"
         assert sum("lds" in l and "buffer_load_dwordx4" in l for l in walk) == 16, f"{name}: 8 LDS-DMAs in each of the two even phases expected"
+
+
+def test_no_product_kernel_spills(igemm_asm, tmp_path):
+    """Every kernel of the product library (the translation units csrc/build.sh compiles for libdove_hip.so) fits its registers: no scratch
+    segment, no scratch instructions.  A spill would not fail any parity test - only the clock."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    build = open(os.path.join(ROOT, "dove_amd", "csrc", "build.sh")).read()
+    srcs = re.search(r'^SRCS="([^"]+)"', build, re.M).group(1).split()
+    assert "igemm" in srcs and "attention" in srcs, srcs
+    procs = []
+    for f in srcs:
+        if f == "igemm":
+            continue                                            # compiled once by the fixture
+        out = tmp_path / f"{f}.s"
+        procs.append((f, out, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-result",
+                                                os.path.join(ROOT, "dove_amd", "csrc", f + ".hip"), "-o", str(out)], stderr=subprocess.DEVNULL)))
+    texts = {"igemm": igemm_asm}
+    for f, out, pr in procs:
+        assert pr.wait() == 0, f"{f}.hip did not compile"
+        texts[f] = open(out).read()
+    n = 0
+    for f, text in texts.items():
+        for name, size in re.findall(r"\.set (\S+)\.private_seg_size, (\d+)", text):
+            n += 1
+            assert int(size) == 0, f"{f}.hip: {name} uses {size} bytes of scratch"
+        assert "scratch_load" not in text and "scratch_store" not in text, f"{f}.hip: scratch instructions"
+    assert n >= 60, f"only {n} kernel records found - did the assembly format change?"
