@@ -26,8 +26,16 @@ def timeit(fn, iters=5, warm=2):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+DATA = "normal"        # --data zeros: all-zero operands draw no switching power in the matrix pipe - the clock stays at its maximum, so the
+                       # time on zeros is the kernel's SCHEDULE-limited time and the ratio to the time on N(0,1) data its power give-back
+
+
+def rnd(*shape):
+    return torch.zeros(*shape, device="cuda") if DATA == "zeros" else torch.randn(*shape, device="cuda")
+
+
 def pack(cout, cin, k):
-    w = torch.randn(cout, cin, *k, device="cuda") * (cin * math.prod(k)) ** -0.5
+    w = rnd(cout, cin, *k) * (cin * math.prod(k)) ** -0.5
     return ops.pack_conv(w, torch.zeros(cout, device="cuda"), "cuda")
 
 
@@ -36,7 +44,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="comma list of substrings; run only matching cases")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--data", default="normal", choices=["normal", "zeros"])
     args = ap.parse_args()
+    global DATA
+    DATA = args.data
     only = [o for o in args.only.split(",") if o]
     want = lambda name: (not only) or any(o in name for o in only)   # noqa: E731
     res = {}
@@ -51,7 +62,7 @@ def main():
         pc = pack(cout, cin, k)
         if direct:                 # the forms without the pack-time weight sums (dove_conv_desc.w_first / w_sub = NULL)
             pc.w_first = pc.w_sub = None
-        x = torch.randn(T, H, W, pc.cin_pad, device=dev).to(BF)
+        x = rnd(T, H, W, pc.cin_pad).to(BF)
         y = ops.conv(x, pc, **kw)
         dt = timeit(lambda: ops.conv(x, pc, out=y, **kw))
         flops = 2.0 * y.shape[0] * y.shape[1] * y.shape[2] * cout * cin * math.prod(k)
@@ -74,7 +85,7 @@ def main():
         if not want(name):
             continue
         pc = pack(cout, cin, ())
-        x = torch.randn(N, cin, device=dev).to(BF)
+        x = rnd(N, cin).to(BF)
         y = ops.linear(x, pc, act=act)
         dt = timeit(lambda: ops.linear(x, pc, act=act, out=y))
         fl = 2.0 * N * cin * cout
@@ -85,9 +96,9 @@ def main():
     npad = (N + 127) // 128 * 128
     if only and not (want("attention") or want("gn_") or want("ln_mod") or want("qkv_post")):
         return
-    Qh = (torch.randn(heads, npad, 64, device=dev) * 0.3).to(BF)
-    Kh = (torch.randn(heads, npad, 64, device=dev) * 0.3).to(BF)
-    Vt = torch.randn(heads, 64, npad, device=dev).to(BF)
+    Qh = (rnd(heads, npad, 64) * 0.3).to(BF)
+    Kh = (rnd(heads, npad, 64) * 0.3).to(BF)
+    Vt = rnd(heads, 64, npad).to(BF)
     O = torch.empty(N, heads * 64, device=dev, dtype=BF)
     dt = timeit(lambda: ops.attention(Qh, Kh, Vt, N, npad, heads, O), iters=3, warm=1)
     fl = 4.0 * heads * N * N * 64
