@@ -14,7 +14,8 @@ if not os.path.exists(so):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tools", "exp", "convalt_exp.hip"), "-o", so])
 lib = C.CDLL(so)
 lib.convalt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-groups = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+SHAPE = len(sys.argv) > 1 and sys.argv[1] == "shape"       # only the MFMA-shape A/B (modes 0 / 4 / 5 / 6)
+groups = int(sys.argv[2 if SHAPE else 1]) if len(sys.argv) > (2 if SHAPE else 1) else 4000
 blocks = torch.cuda.get_device_properties(0).multi_processor_count
 init = torch.randn(8192 * 8, device="cuda").to(torch.bfloat16)
 out = torch.zeros(blocks * 16 * 256, device="cuda")
@@ -22,10 +23,13 @@ names = {0: "baseline: 4x4 blocks, 16 fragment reads : 32 MFMAs per step (halo4x
          4: "same tile, operands held in registers (no LDS reads): the matrix pipe in this harness",
          1: "baseline + GroupNorm-apply/SiLU rewrite of the staged halo in LDS (2 slots per lane in 6 of 9 steps)",
          2: "Winograd F(2x2,3x3): 16 independent transform-domain blocks, 64 fragment reads : 32 MFMAs",
-         3: "Winograd F(2,3) along W: 4 positions x 2x2 blocks, 32 fragment reads : 32 MFMAs"}
+         3: "Winograd F(2,3) along W: 4 positions x 2x2 blocks, 32 fragment reads : 32 MFMAs",
+         5: "the baseline walk in v_mfma_f32_16x16x32_bf16: 8x8 blocks of 16x16, 16 fragment reads : 64 MFMAs per step",
+         6: "the 16x16x32 walk with every step reading the same (conflict-free) fragments"}
 res = {}
+MODES = (0, 4, 5, 6) if SHAPE else (0, 4, 1, 2, 3, 5, 6)
 for rnd in range(3):
-    for mode in (0, 4, 1, 2, 3):
+    for mode in MODES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         assert lib.convalt(mode, init.data_ptr(), out.data_ptr(), groups, blocks, None) == 0
@@ -36,10 +40,14 @@ steps = groups * 9
 flop_step = 32 * 2 * 32 * 32 * 16 * 4 * blocks          # 32 MFMAs x 4 waves x CUs
 base = sorted(res[0])[1]
 print(f"# {blocks} workgroups x 4 waves (one per SIMD), {groups} groups of 9 steps, N(0,1) bf16 operands in LDS")
-for mode in (0, 4, 1, 2, 3):
+for mode in MODES:
     ms = sorted(res[mode])[1]
     ns = ms * 1e6 / steps
     print(f"mode {mode}: {ms:9.3f} ms  {ns:7.1f} ns per 32-MFMA step  {flop_step * steps / (ms * 1e-3) / 1e15:5.2f} PFLOP/s dense-equivalent  x{ms / base:5.3f} of the baseline   {names[mode]}")
+t5 = sorted(res[5])[1]
+print(f"16x16x32 instead of 32x32x16: step time x{t5 / base:.3f} (same MACs, same fragment reads, same accumulator registers)")
+if SHAPE:
+    sys.exit(0)
 t0, t1, t2, t3 = (sorted(res[m])[1] for m in (0, 1, 2, 3))
 print(f"GN-apply in LDS: K walk +{100 * (t1 / t0 - 1):.1f} %.  At the bench's 589 ms of conv3x3_halo4x per clip that is +{589 * (t1 / t0 - 1):.0f} ms (model: no staging, "
       f"every conv norm-fused) against the 67.7 ms of gn_apply_kernel it would remove.")

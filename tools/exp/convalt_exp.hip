@@ -12,6 +12,10 @@
 //          registers hold 16 blocks that share NO operand: every MFMA needs its own A and its own B fragment (2 reads : 1 MFMA)
 //  MODE 3  Winograd F(2, 3) along W only (4 positions, 1.5 x fewer MACs): 4 positions x (2 x 2 blocks): 1 read : 1 MFMA
 //  MODE 4  baseline tile with NO fragment reads in the loop (registers only): the matrix pipe's own rate in this harness
+//  MODE 5  the baseline walk in the OTHER MFMA shape: v_mfma_f32_16x16x32_bf16, 8 x 8 accumulator blocks of 16 x 16 (the same 128 x 128 tile,
+//          the same 256 accumulator registers, the same 16 fragment reads per step - one K-32 fragment of 16 rows each - and 64 MFMAs);
+//          tools/mfma_storm.py order: the pipe alone holds 2.0-2.1 PF in this shape on N(0,1) data against 1.8-1.9 PF for 32 x 32 x 16
+//  MODE 6  mode 5 with the operands held in registers (no LDS reads)
 // Per mode the host reports ns per 32-MFMA step and the equivalent dense rate; speed-up of a variant = (MAC reduction) x (rate ratio).
 #include "../../dove_amd/csrc/common.h"
 
@@ -102,6 +106,30 @@ __global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restric
           *(uint4*)(smem + 49152 + (2 * (tap - 2)) * 4096 + slot0) = pack8(s0.f);
           *(uint4*)(smem + 49152 + (2 * (tap - 2) + 1) * 4096 + slot0) = pack8(s1.f);
         }
+      } else if (MODE == 5 || MODE == 6) {
+        typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+        f32x4_t* acc4 = (f32x4_t*)acc;                                  // 64 blocks of 16 x 16 in the same 256 registers
+        const int l15 = lane & 15, q4 = lane >> 4;
+        const int abase5 = ((4 * wave) * 34 + l15) * 80 + q4 * 16, bbase5 = 98304 + l15 * 64 + q4 * 16;
+        bf16x8 xf[8], wf[8];
+        if (MODE == 5) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            xf[j] = lds128(smem, abase5 + toff + (j >> 1) * 34 * 80 + (j & 1) * 16 * 80);
+            wf[j] = lds128(smem, bbase5 + (tap % 6) * 8192 + j * 1024);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { xf[j] = lds128(smem, abase5 + j * 128); wf[j] = lds128(smem, bbase5 + j * 1024); }
+          if (g > 0 || tap > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(xf[j]), "+v"(wf[j])); }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int p = 0; p < 8; ++p) acc4[i * 8 + p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[p], acc4[i * 8 + p], 0, 0, 0);
       } else if (MODE == 2) {
         // 16 positions, one 32 x 32 block each: A and B fragment per MFMA
 #pragma unroll
@@ -159,6 +187,8 @@ extern "C" int convalt(int mode, const void* init, void* out, int groups, int bl
     case 2: return launch<2>(init, out, groups, blocks, s);
     case 3: return launch<3>(init, out, groups, blocks, s);
     case 4: return launch<4>(init, out, groups, blocks, s);
+    case 5: return launch<5>(init, out, groups, blocks, s);
+    case 6: return launch<6>(init, out, groups, blocks, s);
     default: return -1;
   }
 }
