@@ -15,9 +15,11 @@ if not os.path.exists(so):
 lib = C.CDLL(so)
 lib.convalt.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 SHAPE = len(sys.argv) > 1 and sys.argv[1] == "shape"       # only the MFMA-shape A/B (modes 0 / 4 / 5 / 6)
-groups = int(sys.argv[2 if SHAPE else 1]) if len(sys.argv) > (2 if SHAPE else 1) else 4000
+_nums = [a for a in sys.argv[1:] if a.isdigit()]
+groups = int(_nums[0]) if _nums else 4000
 blocks = torch.cuda.get_device_properties(0).multi_processor_count
-init = torch.randn(8192 * 8, device="cuda").to(torch.bfloat16)
+ZEROS = "zeros" in sys.argv            # all-zero operands: the walk's SCHEDULE-limited rate (no data-dependent clock give-back)
+init = (torch.zeros(8192 * 8, device="cuda") if ZEROS else torch.randn(8192 * 8, device="cuda")).to(torch.bfloat16)
 out = torch.zeros(blocks * 16 * 256, device="cuda")
 names = {0: "baseline: 4x4 blocks, 16 fragment reads : 32 MFMAs per step (halo4x's register tile)",
          4: "same tile, operands held in registers (no LDS reads): the matrix pipe in this harness",
@@ -39,7 +41,7 @@ for rnd in range(3):
 steps = groups * 9
 flop_step = 32 * 2 * 32 * 32 * 16 * 4 * blocks          # 32 MFMAs x 4 waves x CUs
 base = sorted(res[0])[1]
-print(f"# {blocks} workgroups x 4 waves (one per SIMD), {groups} groups of 9 steps, N(0,1) bf16 operands in LDS")
+print(f"# {blocks} workgroups x 4 waves (one per SIMD), {groups} groups of 9 steps, {'ALL-ZERO' if ZEROS else 'N(0,1)'} bf16 operands in LDS")
 for mode in MODES:
     ms = sorted(res[mode])[1]
     ns = ms * 1e6 / steps
