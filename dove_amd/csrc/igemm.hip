@@ -468,7 +468,15 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // (Round 3 tried two other placements of a step's 2-4 LDS-DMA instructions - spread by sched_group_barrier: -4 %, the compiler also
 // re-clusters the fragment reads; four sched_barrier-fenced quarters of {<= 1 DMA, 4 reads, 8 MFMAs}: +-0.3 % - profiles/r03_halo4x_dma.log.
 // Unlike gemm4x's eight DMAs per step, two to four do not back up the CU's address path; the pinned order below stays.)
-template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false>
+// kM16 (THE PRODUCT since the end of round 4; kM16 = false is the walk of rounds 1-4, kept in the TIMING build for tools/halo_m16_ab.py): the same
+// walk on v_mfma_f32_16x16x32_bf16 - 8 x 8 accumulator blocks of 16 couts x 16 pixels in the same 256 registers, one K-32 fragment per 16 rows
+// (the same 16 ds_read_b128 per step), 64 MFMAs per step split by COUT half: the step's 8 activation fragments and the first 4 weight fragments
+// are in registers when its barrier opens; the other 4 weight fragments are read under the first 32 MFMAs, the next step's 8 + 4 under the second
+// 32 (two activation register sets, alternating per step).  Why: the chip is power-limited on real operands, and in this shape
+// the matrix pipe alone sustains 2.0-2.1 PF on them against 1.88 PF (half the accumulator traffic per MAC; profiles/r04_mfma_shape_and_order.log).
+// Results are BIT-IDENTICAL to the 32 x 32 x 16 walk (same K order inside the pipe: every form of the kernel and the full-size VAE,
+// profiles/r04_halo_m16.log), 4.3-6.7 % faster at the headline shapes, -14.8 ms per clip.
+template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
@@ -482,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 4);
   const int hi = lane >> 5, l31 = lane & 31;
+  const int q4 = lane >> 4, l15 = lane & 15;                  // kM16: fragment row / 16-byte K chunk of the 16 x 16 x 32 shape
 
   // PERSISTENT workgroups: block b walks tiles b, b + G, b + 2G, ... as ONE continuous K walk of (frame tap, channel
   // chunk) GROUPS of 9 spatial taps.  While group `cur` is multiplied, the halo of group `nxt` (the next group of this
@@ -538,6 +547,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
                                                0, 0, 0);
     b_wp += wtap_stride;
   };
+  auto stage_b_half = [&](auto slotc, auto jc, int nrec) {     // kM16: one of stage_b's two instructions (the caller moves the stream pointer)
+    constexpr int slot = decltype(slotc)::value, j = decltype(jc)::value;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)b_wp, (short)0, nrec, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + B0 + slot * B_BYTES + j * 4096 + wave * 1024), 16, voffB[j], 0, 0, 0);
+  };
 
   // weight fragment offsets: 4 cout tiles x 2 k-halves (slot 0), XOR-swizzled 64-B rows
   int boff[4][2];
@@ -549,10 +563,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       boff[i][kk] = B0 + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
     }
   // activation fragment bases (padded 80-B halo rows -> base + immediate for every tap and either buffer)
-  const int abase0 = ((4 * wave) * HWID + l31) * APITCH + hi * 16;
+  const int abase0 = kM16 ? ((4 * wave) * HWID + l15) * APITCH + q4 * 16 : ((4 * wave) * HWID + l31) * APITCH + hi * 16;
   int abaseU[3];
 #pragma unroll
-  for (int dw = 0; dw < 3; ++dw) abaseU[dw] = ((2 * wave) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
+  for (int dw = 0; dw < 3; ++dw)
+    abaseU[dw] = kM16 ? ((2 * wave) * UHW + 1 + ((l15 + dw - 1) >> 1)) * APITCH + q4 * 16 : ((2 * wave) * UHW + 1 + ((l31 + dw - 1) >> 1)) * APITCH + hi * 16;
+  // kM16: weight rows 16 i + l15 share (row >> 2) & 3 = (l15 >> 2) & 3, so the staging-side XOR swizzle leaves ONE base + i * 16 rows
+  const int bbase16 = B0 + l15 * ROWB + ((q4 ^ ((l15 >> 2) & 3)) << 4);
 
   // ---- prologue (once per workgroup): whole first halo + the first BAHEAD weight taps ----
   using I0 = std::integral_constant<int, 0>;
@@ -622,10 +639,40 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[p], acc[i][p], 0, 0, 0);
   };
 
+  // ---- kM16: the 16 x 16 x 32 walk.  Fragment idx = 2 p + j of a step: tile row p, columns 16 j .. 16 j + 15 (one K-32 fragment each) ----
+  auto a16_addr = [&](auto tapc, auto bufc, int idx) -> int {
+    constexpr int tap = decltype(tapc)::value, gb = decltype(bufc)::value * A_BYTES;
+    constexpr int dh = tap / 3, dw = tap % 3;
+    const int p = idx >> 1, j = idx & 1;
+    if (kSub) return abaseT[tap & 3] + gb + (p * HWID + 16 * j) * APITCH;
+    if (kUp) return abaseU[dw] + gb + (((p + dh + 1) >> 1) * UHW + 8 * j) * APITCH;
+    return abase0 + gb + ((p + dh) * HWID + dw + 16 * j) * APITCH;
+  };
+  auto a16_addr_next0 = [&](auto bufc, int idx) -> int {          // kSub: tap 0 of group nxt (possibly another tile, another phase)
+    constexpr int gb = decltype(bufc)::value * A_BYTES;
+    return abaseN0 + gb + ((idx >> 1) * HWID + 16 * (idx & 1)) * APITCH;
+  };
+  auto b16_addr = [&](auto slotc, int ib) -> int {                // cout block ib (16 rows) of a ring slot
+    constexpr int slot = decltype(slotc)::value;
+    return bbase16 + slot * B_BYTES + ib * 16 * ROWB;
+  };
+  // Accumulator block (cout block ib, pixel block pb) = quad 8 ib + pb; lane: pixel l15, couts 4 q4 .. 4 q4 + 3.  The MFMAs of this walk are
+  // inline asm with the accumulator TIED and constrained to the AGPR file: as builtins on 64 separate quads the allocator rotates the quads
+  // through VGPRs (v_accvgpr_read after most MFMAs, 300-580 B of scratch).  hipcc does not model the hazards of an asm MFMA (guide 5.7); the
+  // walk needs none: A / B come from ds_read (lgkmcnt waits are register-based and are inserted), a quad is touched once per 64 MFMAs, and
+  // between the zeroing / the epilogue's reads and the nearest MFMA lie a barrier and the group bookkeeping.
+  f32x4 acc16[64];
+  auto mfma16 = [&](int k, const bf16x8& w, const bf16x8& x) {
+    asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[k]) : "v"(w), "v"(x));
+  };
+
   bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
+  bf16x8 xs[2][8], wl[4], wh[4];                  // kM16: activation sets (alternating per step), cout-low / cout-high weight fragments
   if (kSub) sub_bases(h4_decode(a, kc, (int)blockIdx.x).ph, abaseT);
-  load_a(I0{}, I0{}, I0{}, xa);
-  load_b(I0{}, I0{}, wa);
+  if (!kM16) {                                    // (kM16 reads its first fragments at the top of every tile: see the tile loop)
+    load_a(I0{}, I0{}, I0{}, xa);
+    load_b(I0{}, I0{}, wa);
+  }
 
   // one K-step = one spatial tap of group cur (parity par); fragments of k-half 0 are already in xa/wa
   auto step = [&](auto tapc, auto parc) {
@@ -640,14 +687,64 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     __builtin_amdgcn_s_barrier();                                  // then the step barrier (LDS hand-off point)
     __builtin_amdgcn_sched_barrier(0);
     // ---- from here to the end of the step: ONE basic block ----
-    if (stap == NT) b_wp = wg_nxt;
-    stage_b(std::integral_constant<int, (stap + NT * par) % BR>{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
-    if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
-    if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
-    if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? R0 + 2 : 0)>{}, NPar{});
-    if (NH >= 4) stage_halo_round(std::integral_constant<int, (NH >= 4 ? R0 + 3 : 0)>{}, NPar{});
-    if (NH >= 5) stage_halo_round(std::integral_constant<int, (NH >= 5 ? R0 + 4 : 0)>{}, NPar{});
-    if (NH >= 6) stage_halo_round(std::integral_constant<int, (NH >= 6 ? R0 + 5 : 0)>{}, NPar{});
+    if (!kM16) {
+      if (stap == NT) b_wp = wg_nxt;
+      stage_b(std::integral_constant<int, (stap + NT * par) % BR>{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+      if (NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
+      if (NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
+      if (NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? R0 + 2 : 0)>{}, NPar{});
+      if (NH >= 4) stage_halo_round(std::integral_constant<int, (NH >= 4 ? R0 + 3 : 0)>{}, NPar{});
+      if (NH >= 5) stage_halo_round(std::integral_constant<int, (NH >= 5 ? R0 + 4 : 0)>{}, NPar{});
+      if (NH >= 6) stage_halo_round(std::integral_constant<int, (NH >= 6 ? R0 + 5 : 0)>{}, NPar{});
+    }
+    if (kM16) {
+      // (the staging calls above are NOT made for kM16 - see the guard - they are issued from inside the MFMA stream below)
+      constexpr int SP = (tap + NT * par) & 1;                     // this step's activation register set (steps alternate; trips are even)
+      using SlotCur = std::integral_constant<int, (tap + NT * par) % BR>;
+      using SlotNxt = std::integral_constant<int, (tap + 1 + NT * par) % BR>;
+      // first half: cout blocks 0-3 (wl) x the 8 pixel blocks.  Behind every pair of MFMAs ONE other instruction, in a fixed order
+      // (sched_barrier-fenced: the MFMA mask of sched_group_barrier does not see an asm MFMA): the 4 cout-high fragments this step's
+      // second half needs, then the step's LDS-DMAs (2 weight halves + NH halo rounds)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        mfma16(2 * g, wl[(2 * g) >> 3], xs[SP][(2 * g) & 7]);
+        mfma16(2 * g + 1, wl[(2 * g + 1) >> 3], xs[SP][(2 * g + 1) & 7]);
+        if (g < 4) wh[g] = *(const bf16x8*)(smem + b16_addr(SlotCur{}, 4 + g));
+        if (g == 4) {
+          if (stap == NT) b_wp = wg_nxt;
+          stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I0{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+        }
+        if (g == 5) {
+          stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I1{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+          b_wp += wtap_stride;
+        }
+        if (g == 6 && NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
+        if (g == 7 && NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
+        if (g == 8 && NH >= 3) stage_halo_round(std::integral_constant<int, (NH >= 3 ? R0 + 2 : 0)>{}, NPar{});
+        if (g == 9 && NH >= 4) stage_halo_round(std::integral_constant<int, (NH >= 4 ? R0 + 3 : 0)>{}, NPar{});
+        if (g == 10 && NH >= 5) stage_halo_round(std::integral_constant<int, (NH >= 5 ? R0 + 4 : 0)>{}, NPar{});
+        if (g == 11 && NH >= 6) stage_halo_round(std::integral_constant<int, (NH >= 6 ? R0 + 5 : 0)>{}, NPar{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // second half: cout blocks 4-7 (wh); behind the first 12 pairs the next step's 8 activation + 4 cout-low weight fragments
+      // (last tap: tap 0 of group nxt - after a tile's last group that is the NEXT tile's first, which the tile loop reads again)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        mfma16(32 + 2 * g, wh[(2 * g) >> 3], xs[SP][(2 * g) & 7]);
+        mfma16(32 + 2 * g + 1, wh[(2 * g + 1) >> 3], xs[SP][(2 * g + 1) & 7]);
+        if (g < 8) {
+          int ad;
+          if (tap < NT - 1) ad = a16_addr(std::integral_constant<int, (tap + 1) % NT>{}, Par{}, g);
+          else if (kSub) ad = a16_addr_next0(NPar{}, g);
+          else ad = a16_addr(I0{}, NPar{}, g);
+          xs[SP ^ 1][g] = *(const bf16x8*)(smem + ad);
+        } else if (g < 12) {
+          wl[g - 8] = *(const bf16x8*)(smem + b16_addr(SlotNxt{}, g - 8));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     load_a(tapc, I1{}, Par{}, xb);
     load_b(I1{}, std::integral_constant<int, (tap + NT * par) % BR>{}, wb);
     mma(wa, xa);
@@ -698,12 +795,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       bias_r[h][0] = bias_r[h][1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a.bias) { bias_r[h][0] = *(const f32x4*)(a.bias + cbh); bias_r[h][1] = *(const f32x4*)(a.bias + cbh + 4); }
     }
+    if (kM16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int k = 0; k < 64; ++k) acc16[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+    }
 
     // a tile has an even number of groups (Cin % 64 == 0): two per trip, one of each halo-buffer parity - straight-line,
     // so there is no control-flow merge at which the register allocator would have to reconcile two step bodies
@@ -714,6 +816,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       int nb4[4];
       sub_bases(h4_decode(a, kc, tile + G).ph, nb4);
       next_base0 = nb4[0];
+    }
+    if (kM16) {
+      // The tile's first fragments are read HERE, not carried over from the previous tile's last step like the 32 x 32 x 16 walk does: 12
+      // fragments alive across the epilogue are 48 registers the epilogue does not have (one exposed LDS latency per tile of >= 72 steps)
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) xs[0][idx] = *(const bf16x8*)(smem + a16_addr(I0{}, I0{}, idx));
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib) wl[ib] = *(const bf16x8*)(smem + b16_addr(I0{}, ib));
     }
     for (int g = 0; g < ng_tile; g += 2) {
       if (kSub) abaseN0 = abaseT[0];                            // group(I0)'s last step prefetches this tile's next group
@@ -765,6 +875,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 #pragma unroll
           for (int q2 = 0; q2 < 2; ++q2) { gs[h][q2] = f32x2{0.f, 0.f}; gq[h][q2] = f32x2{0.f, 0.f}; }
         auto wr = [&](int p, int h) {                          // accumulators of tile row p, channel half h -> the wave's slice (fp32)
+          if (kM16) {                                            // four 16-cout blocks x two 16-pixel blocks, one register quad each
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) *(f32x4*)(eslice + (16 * j + l15) * EROW + (ib * 16 + 4 * q4) * 4) = acc16[(h * 4 + ib) * 8 + 2 * p + j];
+            return;
+          }
 #pragma unroll
           for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
@@ -1381,6 +1498,12 @@ extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
 }
 
 static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern);
+#ifdef DOVE_TIMING_BUILD
+static bool halo_m16() {                                       // DOVE_HALO_M16=0 selects the predecessor walk; read per call (the A/B tool toggles it)
+  const char* e = getenv("DOVE_HALO_M16");
+  return !(e && atoi(e) == 0);
+}
+#endif
 
 // GEMM tail: ntiles 256x256 tiles on G persistent workgroups take ceil(ntiles / G) rounds, and the last round of the DiT's
 // N = 3072 GEMMs (864 tiles on 256 CUs) keeps 96 CUs busy for a whole tile time.  When the rows behind the last FULL round fit
@@ -1550,10 +1673,17 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attrs;
-      if (attrs.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+      if (attrs.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
       const int cus = cu_count();
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
-      hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+#ifdef DOVE_TIMING_BUILD
+      if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
+        static PerDeviceOnce attrm;
+        if (attrm.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      } else
+#endif
+      hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x sub-pixel)");
       return DOVE_OK;
     }
@@ -1569,8 +1699,8 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attr4;
       if (attr4.first()) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #endif
@@ -1584,14 +1714,25 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       } else
 #endif
 #ifdef DOVE_TIMING_BUILD
+      if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
+        static PerDeviceOnce attrm;
+        if (attrm.first()) {
+          (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+          (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        }
+        if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false, true, false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      } else
+#endif
+#ifdef DOVE_TIMING_BUILD
       if ((a.debug & 64) && kern == K_HALO4X) {                  // tools/e2e_env_ab.py DOVE_IGEMM_ABLATE 64 0: epilogue without the early slice write
         static PerDeviceOnce attrp;
         if (attrp.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif
-      if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
       return DOVE_OK;
     }

@@ -16,6 +16,11 @@
 //          the same 256 accumulator registers, the same 16 fragment reads per step - one K-32 fragment of 16 rows each - and 64 MFMAs);
 //          tools/mfma_storm.py order: the pipe alone holds 2.0-2.1 PF in this shape on N(0,1) data against 1.8-1.9 PF for 32 x 32 x 16
 //  MODE 6  mode 5 with the operands held in registers (no LDS reads)
+//  MODE 7  mode 5 HAND-PIPELINED like the product kernel: fragments register-double-buffered across the step barrier (this step's x and the
+//          first half of its w are already in registers when the barrier opens; the second half of w and the NEXT step's x / first w half
+//          are read under this step's MFMAs), one ds_read pinned behind every 4 MFMAs with sched_group_barrier
+//  MODE 8  mode 0 pipelined the same way (k-half 1 and the next step's k-half 0 under the MFMAs: the product kernel's own scheme), so that
+//          7 vs 8 compares the two shapes at equal scheduling effort
 // Per mode the host reports ns per 32-MFMA step and the equivalent dense rate; speed-up of a variant = (MAC reduction) x (rate ratio).
 #include "../../dove_amd/csrc/common.h"
 
@@ -46,7 +51,83 @@ __global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restric
   const int tab = 147456 - 4096 + (lane & 3) * 64;                     // a[8], b[8] of the lane's channel chunk
   float sink = 0.f;
 
-  for (int g = 0; g < groups; ++g) {
+  if (MODE == 7) {
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    f32x4_t* acc4 = (f32x4_t*)acc;
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int abase5 = ((4 * wave) * 34 + l15) * 80 + q4 * 16, bbase5 = 98304 + l15 * 64 + q4 * 16;
+    bf16x8 xs[2][8], wl[2][4], wh[4];
+    auto xaddr = [&](int tap, int j) { return abase5 + (tap / 3) * 34 * 80 + (tap % 3) * 80 + (j >> 1) * 34 * 80 + (j & 1) * 16 * 80; };
+    auto waddr = [&](int tap, int j) { return bbase5 + (tap % 6) * 8192 + j * 1024; };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[0][j] = lds128(smem, xaddr(0, j));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wl[0][j] = lds128(smem, waddr(0, j));
+    for (int g = 0; g < groups; g += 2) {
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int tap = st % 9, ntap = (st + 1) % 9, cur = st & 1, nxt = cur ^ 1;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wh[j] = lds128(smem, waddr(tap, 4 + j));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < 8; ++p) acc4[i * 8 + p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[cur][i], xs[cur][p], acc4[i * 8 + p], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[nxt][j] = lds128(smem, xaddr(ntap, j));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wl[nxt][j] = lds128(smem, waddr(ntap, j));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < 8; ++p) acc4[(4 + i) * 8 + p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xs[cur][p], acc4[(4 + i) * 8 + p], 0, 0, 0);
+        // pinned interleave: 4 MFMAs, then one fragment read; wh (4 reads) must land before the second half - they go first
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (MODE == 8) {
+    const int abase8 = abase, bbase8 = bbase;
+    bf16x8 xa[2][4], wa[2][4], xb[4], wb[4];
+    auto xaddr = [&](int tap, int kk, int p) { return abase8 + (tap / 3) * 34 * 80 + (tap % 3) * 80 + p * 34 * 80 + kk * 32; };
+    auto waddr = [&](int tap, int kk, int p) { return bbase8 + (tap % 6) * 8192 + p * 2048 + kk * 32; };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { xa[0][p] = lds128(smem, xaddr(0, 0, p)); wa[0][p] = lds128(smem, waddr(0, 0, p)); }
+    for (int g = 0; g < groups; g += 2) {
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int tap = st % 9, ntap = (st + 1) % 9, cur = st & 1, nxt = cur ^ 1;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { xb[p] = lds128(smem, xaddr(tap, 1, p)); wb[p] = lds128(smem, waddr(tap, 1, p)); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[i * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][i], xa[cur][p], acc[i * 4 + p], 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { xa[nxt][p] = lds128(smem, xaddr(ntap, 0, p)); wa[nxt][p] = lds128(smem, waddr(ntap, 0, p)); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[i * 4 + p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[i], xb[p], acc[i * 4 + p], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  for (int g = 0; g < ((MODE == 7 || MODE == 8) ? 0 : groups); ++g) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       __builtin_amdgcn_s_barrier();
@@ -130,6 +211,9 @@ __global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restric
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int p = 0; p < 8; ++p) acc4[i * 8 + p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[p], acc4[i * 8 + p], 0, 0, 0);
+      } else if (MODE == 7) {
+        // handled outside the tap loop (needs two register sets alternating at compile time)
+      } else if (MODE == 8) {
       } else if (MODE == 2) {
         // 16 positions, one 32 x 32 block each: A and B fragment per MFMA
 #pragma unroll
@@ -189,6 +273,8 @@ extern "C" int convalt(int mode, const void* init, void* out, int groups, int bl
     case 4: return launch<4>(init, out, groups, blocks, s);
     case 5: return launch<5>(init, out, groups, blocks, s);
     case 6: return launch<6>(init, out, groups, blocks, s);
+    case 7: return launch<7>(init, out, groups, blocks, s);
+    case 8: return launch<8>(init, out, groups, blocks, s);
     default: return -1;
   }
 }
