@@ -330,7 +330,7 @@ def main():
             "whole_path_tflops_per_gpu": macs["flop"] * args.steps / elapsed / 1e12,
             # the same with the taps the weight-summed conv forms skip taken out (what the matrix pipes were actually asked to do)
             "whole_path_tflops_issued_per_gpu": (macs["flop"] * args.steps - sum(r[1] - r[5] for r in records)) / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": DOM + " (persistent LDS-halo implicit-GEMM 3x3(x3) conv, bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": DOM + " (persistent LDS-halo implicit-GEMM 3x3(x3) conv, bf16 MFMA 16x16x32)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": pmc_src, "launches": len(dom) // max(args.steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
