@@ -310,7 +310,7 @@ def main():
         if os.path.exists(pmc) and pj is not None:
             traffic = pj.get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
             pmc_busy = {"whole_step": pj.get("whole_step_mfma_busy_frac"), "per_kernel": pj.get("mfma_busy_frac_per_kernel"),
-                        "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc pass, not this run)"}
+                        "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc pass, not this run)", "note": pj.get("note")}
             pmc_src = "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, not this run)"
         fp8_parts = (["qkv/out/ff linears"] if args.dit_linear == "mxfp8" else []) + (["attention"] if args.dit_attention == "mxfp8" else [])
         headline = not fp8_parts
