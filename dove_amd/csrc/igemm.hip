@@ -1043,7 +1043,12 @@ constexpr int XB = 0, WB = 2 * OPB;                          // x buffers at 0 /
 constexpr int EPI = 4 * OPB;                                 // epilogue staging: 8 waves x 32 rows x 128 B (XOR-swizzled)
 constexpr int LDS_BYTES = EPI + 8 * 4096;                    // 163840
 }  // namespace gemm8p
-template <bool kAct, bool kGate, bool kTiming = false>
+// kM16 (THE PRODUCT since the end of round 4; kM16 = false = round 3's phases, kept in the TIMING build for tools/gemm_m16_ab.py, DOVE_GEMM_M16=0):
+// the same phases on v_mfma_f32_16x16x32_bf16 - the MFMA shape the power-limited pipe sustains best on real operands and to which the dominant
+// conv moved.  A wave's 128 tokens x 64 channels = 8 x 4 blocks of 16 x 16 (the same 128 accumulator registers), a phase =
+// 12 K-32 fragment reads + 32 MFMAs.  Results are BIT-IDENTICAL to the 32 x 32 x 16 phases on every form the DiT uses (so the row tails on
+// igemm_fast still sum like the main launch), 3-7 % faster at N = 18 226: qkv 1.29 -> 1.38 PF, ff1 1.26 -> 1.34 PF (profiles/r04_gemm_m16.log).
+template <bool kAct, bool kGate, bool kTiming = false, bool kM16 = false>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long long M) {
   using gemm4x::BM;
   using namespace gemm8p;
@@ -1052,6 +1057,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < 8);
   const int hi = lane >> 5, l31 = lane & 31;
+  const int q4 = lane >> 4, l15 = lane & 15;                  // kM16: fragment row / 16-byte K chunk of the 16 x 16 x 32 shape
   const int grp = wave >> 2, wc = wave & 3;                   // token half = phase group, 64-channel slab
 
   G4Const kc;
@@ -1107,6 +1113,20 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
   }
   f32x16 acc[2][4];
   bf16x8 xf[4][2], wf[2][2];
+  // kM16: one address per K-32 half and operand (row l15 of a 16-row block, chunk 4 h + q4 of the 128-B row; +16 rows keep the swizzle's
+  // (row >> 1) & 7 term, so the blocks are immediates), token block pb = 16 rows, channel block ib = 16 rows of the wave's slab
+  int aoff16[2], boff16[2];
+  {
+    const int ra = grp * 128 + l15, rb = wc * 64 + l15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      aoff16[h] = XB + ra * ROWB + (((h * 4 + q4) ^ ((ra >> 1) & 7)) << 4);
+      boff16[h] = WB + rb * ROWB + (((h * 4 + q4) ^ ((rb >> 1) & 7)) << 4);
+      if (kM16) asm volatile("" : "+v"(aoff16[h]), "+v"(boff16[h]));
+    }
+  }
+  f32x4 acc16[4][8];                                          // [channel block][token block]; lane: token l15, channels 4 q4 .. 4 q4 + 3
+  bf16x8 x16[8], w16[4];
 
   // ---- prologue (once per workgroup): K-64 step 0 of the first tile ----
   g4_open_tile(st, a, kc, (int)blockIdx.x);
@@ -1129,12 +1149,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     constexpr int u = decltype(uc)::value;
     constexpr int buf = u >> 1, h = u & 1;
     // ---- LOAD ----
+    if (kM16) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+      for (int pb = 0; pb < 8; ++pb) x16[pb] = *(const bf16x8*)(smem + aoff16[h] + buf * OPB + pb * (16 * ROWB));
 #pragma unroll
-      for (int p = 0; p < 4; ++p) xf[p][kk] = *(const bf16x8*)(smem + aoff[h][kk] + buf * OPB + p * (32 * ROWB));
+      for (int ib = 0; ib < 4; ++ib) w16[ib] = *(const bf16x8*)(smem + boff16[h] + buf * OPB + ib * (16 * ROWB));
+    } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) wf[i][kk] = *(const bf16x8*)(smem + boff[h][kk] + buf * OPB + i * (32 * ROWB));
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xf[p][kk] = *(const bf16x8*)(smem + aoff[h][kk] + buf * OPB + p * (32 * ROWB));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i][kk] = *(const bf16x8*)(smem + boff[h][kk] + buf * OPB + i * (32 * ROWB));
+      }
     }
     if (u == 0) stage(std::integral_constant<int, 1>{}, ca_base, ca_nrec, cw_base, cw_nrec, c_soff + ROWB);   // step 1 of this chunk
     if (u == 2) stage(std::integral_constant<int, 0>{}, na_base, na_nrec, nw_base, nw_nrec, n_soff);          // step 0 of the next one
@@ -1148,12 +1175,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     __builtin_amdgcn_sched_barrier(0);
     // ---- MFMA ----
     __builtin_amdgcn_s_setprio(1);                            // (with / without: 0.825 / 0.824 ms - kept for the hand-over at the barrier)
+    if (kM16) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int pb = 0; pb < 8; ++pb) acc16[ib][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w16[ib], x16[pb], acc16[ib][pb], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], xf[p][kk], acc[i][p], 0, 0, 0);
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][kk], xf[p][kk], acc[i][p], 0, 0, 0);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (h == 1 && !grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1171,12 +1205,19 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
     if (kTiming) tm0 = __builtin_amdgcn_s_memtime();
     const G4Tile c = g4_decode(kc, tile);
     const int col0 = c.n0 + wc * 64;
+    if (kM16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+        for (int pb = 0; pb < 8; ++pb) acc16[ib][pb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][p][r] = 0.f;
+    }
 
     for (int kq = 0; kq < nk4; ++kq) {
       step(std::integral_constant<int, 0>{}, false);
@@ -1239,13 +1280,23 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const IgemmArgs a, long 
 #pragma unroll
               for (int it = 0; it < 2; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 64, 0);
             }
+            if (kM16) {                                              // the block's 32 tokens x 32 channels = 2 x 2 quads of 16 x 16
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-              f32x4 o;
+              for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = acc[h][p][gq * 4 + e];
-              const int ch = 2 * gq + hi;                            // 16-B chunk of the 128-B row
-              *(f32x4*)(eslice + l31 * 128 + ((ch ^ (l31 & 7)) << 4)) = o;
+                for (int di = 0; di < 2; ++di) {
+                  const int row = dj * 16 + l15, ch = di * 4 + q4;
+                  *(f32x4*)(eslice + row * 128 + ((ch ^ (row & 7)) << 4)) = acc16[2 * h + di][2 * p + dj];
+                }
+            } else {
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[h][p][gq * 4 + e];
+                const int ch = 2 * gq + hi;                            // 16-B chunk of the 128-B row
+                *(f32x4*)(eslice + l31 * 128 + ((ch ^ (l31 & 7)) << 4)) = o;
+              }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private slice: no barrier needed
             f32x4 lo[2], hi4[2];
@@ -1628,6 +1679,22 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
           else if (d->act == 1) variant = 1;
           return launch_gemm4x_timing(a, M, grid4, variant, s);
         }
+        {
+          const char* em = getenv("DOVE_GEMM_M16");               // tools/gemm_m16_ab.py: DOVE_GEMM_M16=0 = the 32 x 32 x 16 phases of round 3, read per call
+          if (em && atoi(em) == 0 && !DOVE_DBG_BUF) {
+            static PerDeviceOnce attr8m;
+            if (attr8m.first()) {
+              (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+              (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+              (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+            }
+            if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true, false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+            else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false, false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+            else hipLaunchKernelGGL((gemm8p_kernel<false, false, false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+            DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p 32x32x16)");
+            return DOVE_OK;
+          }
+        }
         if (DOVE_DBG_BUF) {
           static PerDeviceOnce attr8t;
           if (attr8t.first()) {
@@ -1646,13 +1713,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
 #endif
       static PerDeviceOnce attr8;
       if (attr8.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
       }
-      if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
-      else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
-      else hipLaunchKernelGGL((gemm8p_kernel<false, false>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      if (d->gate) hipLaunchKernelGGL((gemm8p_kernel<false, true, false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      else if (d->act == 1) hipLaunchKernelGGL((gemm8p_kernel<true, false, false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
+      else hipLaunchKernelGGL((gemm8p_kernel<false, false, false, true>), dim3(grid4), dim3(512), gemm8p::LDS_BYTES, s, a, M);
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(gemm8p)");
       return DOVE_OK;
     }

@@ -144,23 +144,28 @@ def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(igemm_asm):
     those asm waits: when the epilogue's VGPR loads looked pending to it at the K loop's header, it put `s_waitcnt vmcnt(1)` /
     `vmcnt(0)` in front of the first fragment reads of every 128-deep chunk and drained the stream there (round 3; fixed by ending the
     epilogue with the `s_waitcnt` BUILTIN, which its tracking sees).  Pinned here: inside the K walk every vmcnt wait sits in an asm
-    block, each phase has its 12 fragment reads and 16 MFMAs, and the kernel uses no scratch."""
+    block, each phase has its 12 fragment reads and 32 MFMAs of v_mfma_f32_16x16x32_bf16 (two waves per SIMD: 256 registers each, the
+    128 accumulator registers are VGPRs), and the kernel uses no scratch."""
     text = igemm_asm
     lines = text.split("\n")
-    for variant in ("ILb0ELb0ELb0E", "ILb1ELb0ELb0E", "ILb0ELb1ELb0E"):          # plain, GELU, gated
+    for variant in ("ILb0ELb0ELb0ELb1E", "ILb1ELb0ELb0ELb1E", "ILb0ELb1ELb0ELb1E"):          # plain, GELU, gated
         name = f"_Z13gemm8p_kernel{variant}Ev9IgemmArgsx"
         m = re.search(rf"\.set {name}\.private_seg_size, (\d+)", text)
         assert m and int(m.group(1)) == 0, f"{name}: scratch in use"
+        m = re.search(rf"\.set {name}\.num_vgpr, (\d+)", text)
+        assert m and int(m.group(1)) <= 256, f"{name}: {m.group(1)} VGPRs: two waves per SIMD no longer fit"
         body = _kernel_body(lines, name)
         # the K walk = the stretch between the first and the last MFMA of the kernel (the epilogue has none)
-        mf = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
-        assert len(mf) == 64, f"{name}: expected 4 phases x 16 MFMAs in the unrolled chunk, found {len(mf)}"
+        mf = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
+        assert len(mf) == 128, f"{name}: expected 4 phases x 32 MFMAs in the unrolled chunk, found {len(mf)}"
+        assert not any("v_mfma_f32_32x32x16_bf16" in l for l in body), f"{name}: a 32x32x16 MFMA in the 16x16x32 phases"
         first_read = next(i for i, l in enumerate(body) if "ds_read_b128" in l)      # the prologue only stages; the epilogue's reads follow the last MFMA
         walk = body[first_read - 2:mf[-1] + 12]
         bare = _bare_vmcnt_waits(walk)
         assert not bare, f"{name}: compiler-inserted vmcnt waits inside the K walk would drain the operand stream: {bare}"
         assert sum("ds_read_b128" in l for l in walk) == 48, f"{name}: 12 fragment reads per phase expected"
         assert sum("lds" in l and "buffer_load_dwordx4" in l for l in walk) == 16, f"{name}: 8 LDS-DMAs in each of the two even phases expected"
+        assert not any("v_accvgpr" in l for l in walk), f"{name}: accumulator moves inside the K walk"
 
 
 def test_no_product_kernel_spills(igemm_asm, tmp_path):
