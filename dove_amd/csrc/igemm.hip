@@ -1777,7 +1777,11 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
 #ifdef DOVE_TIMING_BUILD
       if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/halo4x_timing.py
         a.gate = (const float*)DOVE_DBG_BUF;
-        hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+        static PerDeviceOnce attrt;
+        if (attrt.first())
+          (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        if (halo_m16()) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif
 #ifdef DOVE_TIMING_BUILD

@@ -1,5 +1,6 @@
-"""Cycle accounting of one persistent conv3x3_halo4x workgroup (TIMING build: DOVE_CONV_HALO4X=1 DOVE_HALO4X_CFG=9):
-per wave, s_memtime ticks per tile spent in the K walk, the pre-epilogue barrier, the epilogue body and the store drain."""
+"""Cycle accounting of one persistent conv3x3_halo4x workgroup (TIMING build): per wave, s_memtime ticks per tile spent in the K walk, the
+pre-epilogue barrier, the epilogue body and the store drain.  The product's 16x16x32 walk by default; DOVE_HALO_M16=0 in the environment:
+the 32x32x16 walk of rounds 1-4."""
 import os
 import sys
 
