@@ -29,9 +29,11 @@ names = {0: "baseline: 4x4 blocks, 16 fragment reads : 32 MFMAs per step (halo4x
          5: "the baseline walk in v_mfma_f32_16x16x32_bf16: 8x8 blocks of 16x16, 16 fragment reads : 64 MFMAs per step",
          6: "the 16x16x32 walk with every step reading the same (conflict-free) fragments",
          7: "16x16x32, fragments register-pipelined across the barrier, one read pinned behind every 4 MFMAs",
-         8: "32x32x16, pipelined the same way (the product kernel's scheme): one read behind every 2 MFMAs"}
+         8: "32x32x16, pipelined the same way (the product kernel's scheme): one read behind every 2 MFMAs",
+         10: "16x16x32, the product kernel's step as written (asm MFMAs in AGPRs, one other instruction per MFMA pair), no LDS-DMA",
+         9: "mode 10 + the product walk's LDS-DMA traffic (13.3 KB per step and workgroup from an L2-resident buffer)"}
 res = {}
-MODES = (0, 8, 5, 7) if SHAPE else (0, 4, 1, 2, 3, 5, 6, 7, 8)
+MODES = (0, 8, 5, 7, 10, 9) if SHAPE else (0, 4, 1, 2, 3, 5, 6, 7, 8, 10, 9)
 for rnd in range(3):
     for mode in MODES:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

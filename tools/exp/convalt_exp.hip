@@ -21,6 +21,12 @@
 //          are read under this step's MFMAs), one ds_read pinned behind every 4 MFMAs with sched_group_barrier
 //  MODE 8  mode 0 pipelined the same way (k-half 1 and the next step's k-half 0 under the MFMAs: the product kernel's own scheme), so that
 //          7 vs 8 compares the two shapes at equal scheduling effort
+//  MODE 10 the PRODUCT's 16x16x32 step as it is written in igemm.hip (asm MFMAs with the accumulator quad tied in the AGPR file, one other
+//          instruction behind every MFMA pair, sched_barrier-fenced), without its LDS-DMAs
+//  MODE 9  mode 10 + the product walk's LDS-DMA traffic: per step two 1-KB weight instructions per wave (8 KB per workgroup, ring slot three
+//          steps ahead) and in six of nine steps two halo instructions per wave (48 KB per group into the other halo buffer), sourced from a
+//          128 KB global buffer (L2-resident, like the weights), drained with a counted vmcnt before the step barrier - what the global ->
+//          LDS path costs on top of the register-pipelined walk (10 vs 9), with no epilogue and no HBM stream
 // Per mode the host reports ns per 32-MFMA step and the equivalent dense rate; speed-up of a variant = (MAC reduction) x (rate ratio).
 #include "../../dove_amd/csrc/common.h"
 
@@ -93,6 +99,64 @@ __global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restric
       }
     }
   }
+  if (MODE == 9 || MODE == 10) {
+    // the PRODUCT's step (conv3x3_halo4x_kernel<kM16>): asm MFMAs with the accumulator quad tied in the AGPR file, one other instruction behind
+    // every MFMA pair in a fixed, sched_barrier-fenced order - cout-high fragments, then (MODE 9) the step's LDS-DMAs, then in the second
+    // half the next step's 8 + 4 fragments
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    const auto srd = __builtin_amdgcn_make_buffer_rsrc((void*)init, (short)0, 8192 * 16, 0x00020000);
+    const unsigned dvoff = (unsigned)(lane * 16);
+    const int l15 = lane & 15, q4 = lane >> 4;
+    const int abase5 = ((4 * wave) * 34 + l15) * 80 + q4 * 16, bbase5 = 98304 + l15 * 64 + q4 * 16;
+    f32x4_t q[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) q[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8 xs[2][8], wl[4], wh[4];
+    auto xaddr = [&](int tap, int j) { return abase5 + (tap / 3) * 34 * 80 + (tap % 3) * 80 + (j >> 1) * 34 * 80 + (j & 1) * 16 * 80; };
+    auto waddr = [&](int tap, int j) { return bbase5 + (tap % 6) * 8192 + j * 1024; };
+    auto mf = [&](int k, const bf16x8& w, const bf16x8& x) { asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(q[k]) : "v"(w), "v"(x)); };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xs[0][j] = lds128(smem, xaddr(0, j));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wl[j] = lds128(smem, waddr(0, j));
+    for (int g = 0; g < groups; g += 2) {
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {
+        const int tap = st % 9, ntap = (st + 1) % 9, cur = st & 1, nxt = cur ^ 1;
+        if (MODE == 9) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+          mf(2 * gg, wl[(2 * gg) >> 3], xs[cur][(2 * gg) & 7]);
+          mf(2 * gg + 1, wl[(2 * gg + 1) >> 3], xs[cur][(2 * gg + 1) & 7]);
+          if (gg < 4) wh[gg] = lds128(smem, waddr(tap, 4 + gg));
+          if (MODE == 9 && (gg == 4 || gg == 5))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + 98304 + ((tap + 3) % 6) * 8192 + (gg - 4) * 4096 + wave * 1024), 16, dvoff,
+                                                     ((st * 2 + gg) * 1024 + wave * 4096) & 0x1fc00, 0, 0);
+          if (MODE == 9 && tap < 6 && (gg == 6 || gg == 7))
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(smem + (((st / 9) & 1) ^ 1) * 49152 + (tap * 2 + gg - 6) * 4096 + wave * 1024), 16, dvoff,
+                                                     ((st * 2 + gg) * 1024 + 65536 + wave * 4096) & 0x1fc00, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+          mf(32 + 2 * gg, wh[(2 * gg) >> 3], xs[cur][(2 * gg) & 7]);
+          mf(32 + 2 * gg + 1, wh[(2 * gg + 1) >> 3], xs[cur][(2 * gg + 1) & 7]);
+          if (gg < 8) xs[nxt][gg] = lds128(smem, xaddr(ntap, gg));
+          else if (gg < 12) wl[gg - 8] = lds128(smem, waddr(ntap, gg - 8));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (MODE == 9) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_nop 7\ns_nop 7\ns_nop 7" ::: "memory");         // asm MFMA results -> VALU reads below
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[k >> 2][(k & 3) * 4 + e] = q[k][e];
+  }
   if (MODE == 8) {
     const int abase8 = abase, bbase8 = bbase;
     bf16x8 xa[2][4], wa[2][4], xb[4], wb[4];
@@ -127,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void convalt_kernel(const bf16_t* __restric
       }
     }
   }
-  for (int g = 0; g < ((MODE == 7 || MODE == 8) ? 0 : groups); ++g) {
+  for (int g = 0; g < ((MODE >= 7 && MODE <= 10) ? 0 : groups); ++g) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       __builtin_amdgcn_s_barrier();
@@ -275,6 +339,8 @@ extern "C" int convalt(int mode, const void* init, void* out, int groups, int bl
     case 6: return launch<6>(init, out, groups, blocks, s);
     case 7: return launch<7>(init, out, groups, blocks, s);
     case 8: return launch<8>(init, out, groups, blocks, s);
+    case 9: return launch<9>(init, out, groups, blocks, s);
+    case 10: return launch<10>(init, out, groups, blocks, s);
     default: return -1;
   }
 }
