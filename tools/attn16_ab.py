@@ -1,0 +1,98 @@
+"""Flash attention on the 16x16x32 MFMA shape (tools/exp/attn16_exp.hip; constant-shift softmax only) against the product kernel, within one
+process: both against a torch fp32 softmax attention on sampled query rows, the difference between the two, and back-to-back timings at the
+headline size (N = 18 226 tokens, 48 heads).  The two kernels want the keys of V^T in different orders (the contraction order of P V is free;
+each kernel's order makes a lane's own probabilities its slice of the MFMA operand): the product's is dove_qkv_post_bf16's v_order 1.
+    python tools/attn16_ab.py [N] [heads]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dove_amd import ops  # noqa: E402
+
+so = os.path.join(ROOT, "tools", "exp", "libattn16_exp.so")
+if not os.path.exists(so):
+    import subprocess
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tools", "exp", "attn16_exp.hip"), "-o", so])
+lib = C.CDLL(so)
+lib.attn16.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 18226
+heads = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+dev = torch.device("cuda", 0)
+BF = torch.bfloat16
+npad = (N + 127) // 128 * 128
+g = torch.Generator(device="cuda").manual_seed(11)
+q = (torch.randn(heads, npad, 64, device=dev, generator=g) * 0.45).to(BF)          # already times scale * log2(e), as dove_qkv_post_bf16 leaves it
+k = (torch.randn(heads, npad, 64, device=dev, generator=g) * 0.9).to(BF)
+v = torch.randn(heads, npad, 64, device=dev, generator=g).to(BF)
+q[:, N:] = 0
+k[:, N:] = 0
+v[:, N:] = 0
+norm2 = torch.stack([(q.float() ** 2).sum(-1).amax(1), (k.float() ** 2).sum(-1).amax(1)], dim=1).contiguous()      # [heads, 2]
+print(f"N = {N}, heads = {heads}; score bound 1.01 sqrt(max|q|^2 max|k|^2): {float((1.01 * (norm2[:, 0] * norm2[:, 1]).sqrt()).max()):.1f} (cutoff 40)")
+
+vt = v.transpose(1, 2).contiguous()                                                 # [heads, 64, npad], keys in natural order
+idx16 = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=dev)
+perm_prod = (torch.arange(npad, device=dev) // 16 * 16).view(-1, 16)[:, :1] + idx16[None]
+vt_prod = vt[:, :, perm_prod.reshape(-1)].contiguous()
+src32 = torch.tensor([4 * (p // 8) + (p % 8) if p % 8 < 4 else 16 + 4 * (p // 8) + (p % 8 - 4) for p in range(32)], device=dev)
+perm16 = (torch.arange(npad, device=dev) // 32 * 32).view(-1, 32)[:, :1] + src32[None]
+vt16 = vt[:, :, perm16.reshape(-1)].contiguous()
+
+o_prod = torch.zeros(N, heads * 64, device=dev, dtype=BF)
+o16 = torch.zeros(N, heads * 64, device=dev, dtype=BF)
+
+
+def run_prod():
+    ops.attention(q, k, vt_prod, N, npad, heads, o_prod, norm2=norm2)
+
+
+def run16():
+    rc = lib.attn16(q.data_ptr(), k.data_ptr(), vt16.data_ptr(), o16.data_ptr(), N, npad, heads, heads * 64, norm2.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+
+
+run_prod()
+run16()
+torch.cuda.synchronize()
+rows = torch.cat([torch.arange(0, 40, device=dev), torch.arange(N // 2, N // 2 + 24, device=dev), torch.arange(N - 50, N, device=dev)])
+worst = {}
+for h in sorted({0, heads // 2, heads - 1}):
+    s = q[h, rows].float() @ k[h, :N].float().T                                       # base-2 logits
+    p = torch.softmax(s * 0.6931471805599453, dim=-1)
+    ref = p @ v[h, :N].float()
+    for name, o in (("32x32x16 (product)", o_prod), ("16x16x32", o16)):
+        d = (o[rows, h * 64:(h + 1) * 64].float() - ref)
+        e = float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        worst[name] = max(worst.get(name, 0.0), e)
+for name, e in worst.items():
+    print(f"{name:20s} rms-rel error vs fp32 softmax attention on {len(rows)} sampled rows x 3 heads: {e:.3e}")
+d = (o16.float() - o_prod.float())
+print(f"between the two kernels, whole output: rms-rel {float(d.pow(2).mean().sqrt() / o_prod.float().pow(2).mean().sqrt()):.3e}, max |d| {float(d.abs().max()):.3e}; "
+      f"finite: {bool(torch.isfinite(o16.float()).all())}")
+assert worst["16x16x32"] < 1.5 * worst["32x32x16 (product)"] + 1e-3
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+res = {}
+for rnd in range(3):
+    res.setdefault("p", []).append(timeit(run_prod))
+    res.setdefault("m", []).append(timeit(run16))
+tp, tm = sorted(res["p"])[1], sorted(res["m"])[1]
+fl = 4.0 * heads * N * N * 64
+print(f"attention N = {N}, {heads} heads: 32x32x16 {tp:7.3f} ms ({fl / tp / 1e9:6.1f} TFLOP/s)   16x16x32 {tm:7.3f} ms ({fl / tm / 1e9:6.1f} TFLOP/s)   x{tm / tp:.3f}")
