@@ -25,8 +25,12 @@ dev = torch.device("cuda", 0)
 BF = torch.bfloat16
 npad = (N + 127) // 128 * 128
 g = torch.Generator(device="cuda").manual_seed(11)
-q = (torch.randn(heads, npad, 64, device=dev, generator=g) * 0.45).to(BF)          # already times scale * log2(e), as dove_qkv_post_bf16 leaves it
-k = (torch.randn(heads, npad, 64, device=dev, generator=g) * 0.9).to(BF)
+# q already times scale * log2(e), as dove_qkv_post_bf16 leaves it.  0.3 / 0.3 keeps the score bound near 12 (what LayerNorm'd q / k give): BOTH
+# kernels then run the constant-shift softmax.  (The first run of this tool, profiles/r04_attn16.log, had 0.45 / 0.9: bound 52 > the product's
+# cutoff of 40, so the product kernel ran its running-maximum path there - 4.16 ms instead of ~3.9 - and the x 0.911 of that log overstates.)
+QS, KS = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (0.3, 0.3)
+q = (torch.randn(heads, npad, 64, device=dev, generator=g) * QS).to(BF)
+k = (torch.randn(heads, npad, 64, device=dev, generator=g) * KS).to(BF)
 v = torch.randn(heads, npad, 64, device=dev, generator=g).to(BF)
 q[:, N:] = 0
 k[:, N:] = 0
