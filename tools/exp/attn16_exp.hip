@@ -1,7 +1,9 @@
-// EXPERIMENT (tools/attn16_ab.py; never loaded by dove_amd; NOT yet run on a GPU - written after round 4's GPU budget was spent): the
-// flash-attention forward of dove_attention_fwd_bf16 on v_mfma_f32_16x16x32_bf16, the MFMA shape the power-limited matrix pipe sustains best
-// on real operands (the conv and the GEMMs moved to it, bit-identical and 3-7 % faster).  Constant-shift softmax only (the
-// path every head of the DiT takes: a per-head score bound rides in the C operand of the first MFMA of each S chain).
+// EXPERIMENT (tools/attn16_ab.py; never loaded by dove_amd; its constant-shift path ran once on a GPU with round 4's last seconds -
+// profiles/r04_attn16.log: correct - the running-maximum path has not run yet): the flash-attention forward of dove_attention_fwd_bf16 on
+// v_mfma_f32_16x16x32_bf16, the MFMA shape the power-limited matrix pipe sustains best on real operands (the conv and the
+// GEMMs moved to it, bit-identical and 3-7 % faster).  Both softmax paths of the product kernel: the constant shift from a per-head score
+// bound (what every head of the DiT takes) and the lazily updated running maximum (bound == nullptr or above the cutoff of 40); either way
+// the shift rides in the C operand of the first MFMA of each S chain.
 //
 // Same workgroup / staging as the product kernel: 4 waves x 32 queries, 64-key K and V^T tiles by LDS-DMA into XOR-swizzled 128-B rows,
 // four 16 KB stages, one barrier per two tiles.  What changes is the register tile:
@@ -54,11 +56,17 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) qf[b][kk] = *(const bf16x8*)(qp + kk * 32);
   }
-  f32x4 o[4][2], negm;
-  float lsum[2] = {0.f, 0.f};
-  const float bnd = 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) negm[e] = -bnd;
+  constexpr float THR = 6.0f;                                 // running maximum: rescale when a score exceeds it by 2^6 (as the product kernel)
+  f32x4 o[4][2], negm[2];
+  float lsum[2] = {0.f, 0.f}, m[2] = {0.f, 0.f};
+  bool fixed = false;
+  negm[0] = negm[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (bound) {
+    const float bnd = 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);
+    fixed = bnd <= 40.0f;                                     // NaN compares false: the running maximum
+    if (fixed) negm[0] = negm[1] = f32x4{-bnd, -bnd, -bnd, -bnd};
+  }
+  fixed = __builtin_amdgcn_readfirstlane(fixed);
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -89,8 +97,9 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) foff[kk] = l15 * 128 + (((kk * 4 + q4) ^ ((l15 >> 1) & 7)) << 4);
 
-  auto compute = [&](auto bufc, int tile) {
+  auto compute = [&](auto bufc, int tile, auto fixc) {
     constexpr int BUF = decltype(bufc)::value;
+    constexpr bool kFixed = decltype(fixc)::value;
     f32x4 st[4][2];                                           // [key block][query block]
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const bf16_t* __restrict
         const bf16x8 kf = *(const bf16x8*)(smem + BUF * STAGE + foff[kk] + kb * 2048);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          if (kk == 0) st[kb][b] = mfma16_c_in(kf, qf[b][kk], negm);
+          if (kk == 0) st[kb][b] = mfma16_c_in(kf, qf[b][kk], negm[b]);
           else st[kb][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[b][kk], st[kb][b], 0, 0, 0);
         }
       }
@@ -110,6 +119,34 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (kv0 + kb * 16 + 4 * q4 + e >= N) { st[kb][0][e] = -1e30f; st[kb][1][e] = -1e30f; }
+    }
+    if (!kFixed) {                                            // lazy online softmax, per query block (a lane owns one query of each)
+      float mt[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        mt[b] = st[0][b][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mt[b] = fmaxf(mt[b], st[kb][b][e]);
+        mt[b] = fmaxf(mt[b], __shfl_xor(mt[b], 16));          // the other three key quarters of the same query column
+        mt[b] = fmaxf(mt[b], __shfl_xor(mt[b], 32));
+      }
+      const bool first = tile == 0;
+      if (first || __any(fmaxf(mt[0], mt[1]) > THR)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float delta = first ? mt[b] : fmaxf(mt[b], 0.f);
+          const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+          m[b] += delta;
+          lsum[b] *= alpha;
+#pragma unroll
+          for (int db = 0; db < 4; ++db) o[db][b] *= alpha;
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) st[kb][b] -= delta;
+          negm[b] = f32x4{-m[b], -m[b], -m[b], -m[b]};
+        }
+      }
     }
     float ps[2] = {0.f, 0.f};
 #pragma unroll
@@ -147,21 +184,24 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const bf16_t* __restrict
   using B3 = std::integral_constant<int, 3>;
   stage(B0{}, 0);
   if (1 < ntiles) stage(B1{}, 1);
-  for (int it = 0; it < ntiles; it += 4) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 2 < ntiles) stage(B2{}, it + 2);
-    if (it + 3 < ntiles) stage(B3{}, it + 3);
-    compute(B0{}, it);
-    if (it + 1 < ntiles) compute(B1{}, it + 1);
-    if (it + 2 >= ntiles) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (it + 4 < ntiles) stage(B0{}, it + 4);
-    if (it + 5 < ntiles) stage(B1{}, it + 5);
-    compute(B2{}, it + 2);
-    if (it + 3 < ntiles) compute(B3{}, it + 3);
+#define ATTN16_LOOP(FX)                                                     \
+  for (int it = 0; it < ntiles; it += 4) {                                  \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                        \
+    if (it + 2 < ntiles) stage(B2{}, it + 2);                               \
+    if (it + 3 < ntiles) stage(B3{}, it + 3);                               \
+    compute(B0{}, it, FX{});                                                \
+    if (it + 1 < ntiles) compute(B1{}, it + 1, FX{});                       \
+    if (it + 2 >= ntiles) break;                                            \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                        \
+    if (it + 4 < ntiles) stage(B0{}, it + 4);                               \
+    if (it + 5 < ntiles) stage(B1{}, it + 5);                               \
+    compute(B2{}, it + 2, FX{});                                            \
+    if (it + 3 < ntiles) compute(B3{}, it + 3, FX{});                       \
   }
+  if (fixed) { ATTN16_LOOP(std::true_type) } else { ATTN16_LOOP(std::false_type) }
+#undef ATTN16_LOOP
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     float l = lsum[b];
