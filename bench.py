@@ -55,6 +55,17 @@ def prepare_clip(lr, upscale=4):
     return (up / 255.0 * 2.0 - 1.0).permute(1, 0, 2, 3)[None].contiguous()
 
 
+def frame_checksums(x):
+    """[1, 3, f, H, W] -> int64 [f]: a position-weighted sum of each frame's raw bits (wrapping int64 arithmetic).  Equal checksums on
+    two ranks <=> the same frame bits for every practical purpose; 8 bytes per frame cross the wire instead of 5.5 MB."""
+    f = x.shape[2]
+    if f == 0:
+        return torch.zeros(0, dtype=torch.int64, device=x.device)
+    bits = x[0].transpose(0, 1).contiguous().view(torch.int16 if x.element_size() == 2 else torch.int32).reshape(f, -1).to(torch.int64)
+    w = torch.arange(bits.shape[1], device=x.device, dtype=torch.int64) % 65521 + 1
+    return (bits * w).sum(dim=1)
+
+
 def cpu_baseline(text, v, t, s, seed, dev):
     """Oracle (clean-room port of the reference's diffusers CPU path) on a bounded sample, all host cores, fp32: the FULL
     model (42 DiT layers, same deterministic weights as the timed GPU run, read tensor-by-tensor from the GPU generator so
@@ -219,7 +230,7 @@ def main():
         assert out.shape == (1, 3, args.frames, args.height, args.width) and bool(torch.isfinite(out).all())
 
     def measure_single_clip():
-        fault = os.environ.get("DOVE_BENCH_STRONG_FAULT", "")      # debug only (tests of the guard below): "raise:<rank>" / "hang:<rank>"
+        fault = os.environ.get("DOVE_BENCH_STRONG_FAULT", "")      # debug only (tests of the guard below): "raise:<rank>" / "hang:<rank>" / "corrupt:<rank>"
         if fault == f"raise:{rank}":
             raise RuntimeError("injected fault (DOVE_BENCH_STRONG_FAULT)")
         if fault == f"hang:{rank}":
@@ -242,6 +253,24 @@ def main():
         el1 = max(float(x[0]) for x in infos)
         assert mine is None or bool(torch.isfinite(mine).all())
         assert sum(int(x[1]) for x in infos) == args.frames, "the ranks' decoded frames do not add up to the clip"
+        # SELF-VALIDATION of the wires: the frames every rank decoded in this mode against the frames of the ONE-GPU result of the same clip
+        # (rank 0's `out` of the weak region above: clip seed 42, same posterior noise, same weights) - per-frame checksums of the raw bits
+        # travel, not the tensor.  The mode is bit-identical to the one-GPU operator by construction (tests/test_dist_gpu.py), so anything
+        # but equality means the transport delivered other bytes than the kernels sent
+        cs = torch.full((args.frames,), -1, dtype=torch.int64, device=dev)
+        if fault == f"corrupt:{rank}" and mine is not None:       # debug only: one flipped bit in this rank's last frame must be caught
+            mine.view(torch.int16 if mine.element_size() == 2 else torch.int32)[0, 1, -1, 3, 5] ^= 1
+        if mine is not None and mine.shape[2] > 0:
+            cs[:mine.shape[2]] = frame_checksums(mine)
+        cs = cs.to(gdev)
+        css = [torch.zeros_like(cs) for _ in range(observed_world)]
+        dist.all_gather(css, cs)
+        bit_identical, mismatched = None, None
+        if rank == 0:
+            want = frame_checksums(out).cpu()
+            got = torch.cat([c.cpu()[:int(x[1])] for c, x in zip(css, infos)])
+            bad = (got != want).nonzero().flatten().tolist()
+            bit_identical, mismatched = not bad, bad
         macs1 = flops.clip_macs(v, t, args.frames, args.height, args.width)
         n_tok = macs1["tokens"]
         return {
@@ -257,9 +286,11 @@ def main():
             "one_gpu_ms_per_clip_this_run": elapsed / args.steps * 1e3,
             "efficiency_vs_n1": (elapsed / args.steps) / (observed_world * (el1 / args.steps)),
             "transport": "gloo through host memory (--oversubscribe debug run)" if args.oversubscribe else "RCCL (backend nccl) over xGMI",
-            "validation": "bit-identity of this mode with the one-GPU result is tested on the HIP kernels with gloo-staged wires (tests/test_dist_gpu.py: "
-                          "2 / 4 / 8 ranks, and 8 ranks at 33x720x1280); before this measurement the RCCL transport had run with ONE rank only - "
-                          "a first multi-GPU run validates the wires, not the arithmetic",
+            "bit_identical": bit_identical, "mismatched_frames": mismatched,
+            "validation": "per-frame checksums of every rank's decoded frames in THIS run against the frames of rank 0's one-GPU result of the same "
+                          "clip (`bit_identical`); the mode's bit-identity with the one-GPU operator is a tested property of the kernels "
+                          "(tests/test_dist_gpu.py: 2 / 4 / 8 ranks with gloo-staged wires, and 8 ranks at 33x720x1280) - before this "
+                          "measurement the RCCL transport had run with ONE rank only, so a False here points at the wires",
         }
 
     if rank == 0:
@@ -303,14 +334,22 @@ def main():
             # re-dispatched since the PMC pass makes the numbers stale - then the fields stay null and say why)
             pk = pj.get("per_kernel", {}).get(DOM)
             seen = len(dom) // max(args.steps, 1)
-            if pk is None or int(pk.get("launches", -1)) != seen:
+            from dove_amd.lib import kernel_source_sha256
+            tree = kernel_source_sha256()
+            if pj.get("kernel_source_sha256") != tree:
+                # the summary was measured on OTHER kernel code than this tree's (any edit of csrc/*.hip, csrc/*.h or the ABI header)
+                pmc_src = (f"profiles/pmc_traffic.json NOT replayed: it was collected on kernel sources {str(pj.get('kernel_source_sha256'))[:16]}, "
+                           f"this tree is {tree[:16]} - re-run tools/runs/gpu_pmc_bench.sh")
+                pj = None
+            elif pk is None or int(pk.get("launches", -1)) != seen:
                 pmc_src = (f"profiles/pmc_traffic.json NOT replayed: it holds {None if pk is None else pk.get('launches')} launches of {DOM} per clip, "
                            f"this run made {seen} - re-run tools/runs/gpu_pmc_bench.sh")
                 pj = None
         if os.path.exists(pmc) and pj is not None:
             traffic = pj.get("per_kernel", {}).get(DOM, {}).get("hbm_bytes_per_launch")
             pmc_busy = {"whole_step": pj.get("whole_step_mfma_busy_frac"), "per_kernel": pj.get("mfma_busy_frac_per_kernel"),
-                        "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc pass, not this run)", "note": pj.get("note")}
+                        "source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc pass, not this run; same kernel sources: "
+                                  f"sha256 {tree[:16]})", "note": pj.get("note")}
             pmc_src = "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, not this run)"
         fp8_parts = (["qkv/out/ff linears"] if args.dit_linear == "mxfp8" else []) + (["attention"] if args.dit_attention == "mxfp8" else [])
         headline = not fp8_parts
@@ -517,6 +556,8 @@ def main():
         dog.cancel()
         if rank == 0:
             res["single_clip"] = single
+            if single.get("bit_identical") is not True:
+                res["single_clip_failed"] = True           # the sharded mode did not reproduce the one-GPU frames: its numbers are not a result
     if rank == 0:
         print(json.dumps(res), flush=True)
     if use_dist:

@@ -281,7 +281,7 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   constexpr int LDS = 4 * 16384;
   constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_ = attr_set.guard()) {
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   }
   const int qblocks = (int)((Npad + NW * 32 - 1) / (NW * 32));
@@ -302,7 +302,7 @@ extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const 
                                           long long ldo, int nw, void* stream) {
   constexpr int LDS = 4 * 16384;
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) {
+  if (auto once_ = attr_set.guard()) {
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

@@ -40,13 +40,22 @@ extern "C" void dove_set_error(const char* fmt, ...);
 constexpr int DOVE_MAX_DEVICES = 32;
 struct PerDeviceOnce {
   std::atomic<bool> done[DOVE_MAX_DEVICES] = {};
-  // true for exactly one caller per device - two host threads driving different (or the same) devices may race here; setting the
-  // attribute twice would be harmless, a torn read of a plain bool was not guaranteed to be
-  bool first() {
+  // Usage:  if (auto once = flag.guard()) { hipFuncSetAttribute(...); }
+  // The guard tests true for EVERY caller until one of them has LEFT the block (its destructor publishes), i.e. until the attribute is known
+  // to be set on this device: a second host thread that arrives while the first is still inside hipFuncSetAttribute sets the attribute itself
+  // (twice is harmless) instead of launching a > 64 KB-LDS kernel before the limit is raised (ranks-as-threads on one GPU:
+  // tests/test_graph_gpu.py drives the library that way).
+  struct Guard {
+    std::atomic<bool>* flag;                 // nullptr: already published (or no table slot for this device: always set, never publish)
+    bool todo;
+    explicit operator bool() const { return todo; }
+    ~Guard() { if (todo && flag) flag->store(true, std::memory_order_release); }
+  };
+  Guard guard() {
     int d = 0;
     (void)hipGetDevice(&d);
-    if (d < 0 || d >= DOVE_MAX_DEVICES) return true;
-    return !done[d].exchange(true, std::memory_order_acq_rel);
+    if (d < 0 || d >= DOVE_MAX_DEVICES) return Guard{nullptr, true};
+    return Guard{&done[d], !done[d].load(std::memory_order_acquire)};
   }
 };
 

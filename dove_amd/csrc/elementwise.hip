@@ -155,7 +155,7 @@ extern "C" int dove_conv_out_gather(const float* p, long long ldp, int T, int H,
                  "conv_out_gather: need 1 <= C <= 4 and 9 C <= ldp <= 36, ldp %% 4 == 0");
   const int lds = 10 * 66 * ((int)ldp + 1) * 4;
   static PerDeviceOnce attr;
-  if (attr.first()) { (void)hipFuncSetAttribute((const void*)conv_out_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 66 * 37 * 4); }
+  if (auto once_ = attr.guard()) { (void)hipFuncSetAttribute((const void*)conv_out_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 66 * 37 * 4); }
   dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 7) / 8), (unsigned)T);
   hipLaunchKernelGGL(conv_out_gather_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, (int)ldp, T, H, W, C, bias, scale, shift, lo, hi, y, dtype);
   DOVE_CHECK_LAUNCH("dove_conv_out_gather");

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void gemm4x_kernel(const IgemmArgs a, long 
 
 int launch_gemm4x_timing(const IgemmArgs& a, long long M, unsigned grid, int variant, hipStream_t s) {
   static PerDeviceOnce attr4g;
-  if (attr4g.first()) {
+  if (auto once_ = attr4g.guard()) {
     (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm4x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm4x::LDS_BYTES);

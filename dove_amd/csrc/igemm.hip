@@ -1509,7 +1509,7 @@ template <int BN, int BK>
 static int launch_igemm_fast(const IgemmArgs& a, unsigned grid, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (auto once_ = attr_set.guard()) (void)hipFuncSetAttribute((const void*)igemm_fast_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((igemm_fast_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16");
   return DOVE_OK;
@@ -1563,7 +1563,8 @@ static bool halo_m16() {                                       // DOVE_HALO_M16=
 // (bias / GELU / gated residual; gate_split shifted by the row offset) is the same code path as for any igemm_fast GEMM.
 static bool gemm_tail_split(const dove_conv_desc* d, long long* rows_main) {
   const long long M = (long long)d->t_out * d->h_out * d->w_out;
-  if (d->t_out != 1 || d->h_out != 1) return false;                                  // token-major [1, 1, N] linears only
+  if (d->t_out != 1 || d->h_out != 1 || desc_nb(d) > 1) return false;               // token-major [1, 1, N] linears only, ONE instance (x, out
+                                                                                      // and resid are split per row below: nb instances are not)
   const int cus = cu_count(), tiles_n = d->cout_pad / 256;
   const long long row_tiles = (M + gemm4x::BM - 1) / gemm4x::BM, ntiles = row_tiles * tiles_n;
   if (ntiles <= cus || ntiles % cus == 0) return false;
@@ -1683,7 +1684,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
           const char* em = getenv("DOVE_GEMM_M16");               // tools/gemm_m16_ab.py: DOVE_GEMM_M16=0 = the 32 x 32 x 16 phases of round 3, read per call
           if (em && atoi(em) == 0 && !DOVE_DBG_BUF) {
             static PerDeviceOnce attr8m;
-            if (attr8m.first()) {
+            if (auto once_ = attr8m.guard()) {
               (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
               (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
               (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
@@ -1697,7 +1698,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
         }
         if (DOVE_DBG_BUF) {
           static PerDeviceOnce attr8t;
-          if (attr8t.first()) {
+          if (auto once_ = attr8t.guard()) {
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
             (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
@@ -1712,7 +1713,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       }
 #endif
       static PerDeviceOnce attr8;
-      if (attr8.first()) {
+      if (auto once_ = attr8.guard()) {
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm8p_kernel<false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, gemm8p::LDS_BYTES);
@@ -1740,13 +1741,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attrs;
-      if (attrs.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+      if (auto once_ = attrs.guard()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
       const int cus = cu_count();
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
 #ifdef DOVE_TIMING_BUILD
       if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
         static PerDeviceOnce attrm;
-        if (attrm.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        if (auto once_ = attrm.guard()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif
@@ -1765,7 +1766,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attr4;
-      if (attr4.first()) {
+      if (auto once_ = attr4.guard()) {
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #ifdef DOVE_TIMING_BUILD
@@ -1778,7 +1779,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/halo4x_timing.py
         a.gate = (const float*)DOVE_DBG_BUF;
         static PerDeviceOnce attrt;
-        if (attrt.first())
+        if (auto once_ = attrt.guard())
           (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         if (halo_m16()) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
         else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
@@ -1787,7 +1788,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
 #ifdef DOVE_TIMING_BUILD
       if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
         static PerDeviceOnce attrm;
-        if (attrm.first()) {
+        if (auto once_ = attrm.guard()) {
           (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
           (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         }
@@ -1798,7 +1799,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
 #ifdef DOVE_TIMING_BUILD
       if ((a.debug & 64) && kern == K_HALO4X) {                  // tools/e2e_env_ab.py DOVE_IGEMM_ABLATE 64 0: epilogue without the early slice write
         static PerDeviceOnce attrp;
-        if (attrp.first()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        if (auto once_ = attrp.guard()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       } else
 #endif

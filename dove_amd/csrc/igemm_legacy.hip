@@ -175,7 +175,7 @@ template <int BN, int BK>
 static int launch_v1(const IgemmArgs& a, unsigned grid, hipStream_t s) {
   constexpr int lds = 2 * (128 * BK * 2 + BN * BK * 2);
   static PerDeviceOnce attr_set;
-  if (attr_set.first()) (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (auto once_ = attr_set.guard()) (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((igemm_kernel<BN, BK>), dim3(grid), dim3(256), lds, s, a);
   DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16");
   return DOVE_OK;

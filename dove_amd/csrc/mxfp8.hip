@@ -485,7 +485,7 @@ extern "C" int dove_linear_mxfp8(const void* xq, const void* xs, const void* wq,
   a.bias = bias; a.resid = (const bf16_t*)resid; a.gate = gate; a.out = (bf16_t*)out;
   a.M = M; a.ldo = ldo; a.ldr = ldr; a.gate_split = gate_split; a.N = N; a.K = K; a.tiles_n = N / 256;
   static PerDeviceOnce attr;
-  if (attr.first()) {
+  if (auto once_ = attr.guard()) {
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mxg::LDS_BYTES);

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__
                                                       const float* __restrict__ gk, const float* __restrict__ bk,
                                                       const float* __restrict__ cosT, const float* __restrict__ sinT, float qscale, float eps,
                                                       bf16_t* __restrict__ Qh, bf16_t* __restrict__ Kh, float* __restrict__ norm2) {
-  __shared__ float smax[4][QK_HB];
+  __shared__ unsigned smax[4][QK_HB];
   const int c = threadIdx.x & 7;                               // 8-value chunk of the 64-vector
   const int h0 = blockIdx.y * QK_HB, which = blockIdx.z;       // 0 q, 1 k
   const long long n = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -527,16 +527,18 @@ __global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 8; ++e) q += r[e] * r[e];
       q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4);          // the row (8 lanes)
-      q = fmaxf(q, __shfl_xor(q, 8)); q = fmaxf(q, __shfl_xor(q, 16)); q = fmaxf(q, __shfl_xor(q, 32));   // the wave's 8 rows
-      if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6][j] = q;
+      // the wave's 8 rows: the maximum of the BIT PATTERNS (a sum of squares is non-negative: same order) so that a NaN row - larger than
+      // +inf as an unsigned - survives every stage up to the attention kernel, whose `b <= 40` test then picks the running maximum
+      unsigned qb = __float_as_uint(q);
+      qb = max(qb, (unsigned)__shfl_xor((int)qb, 8)); qb = max(qb, (unsigned)__shfl_xor((int)qb, 16)); qb = max(qb, (unsigned)__shfl_xor((int)qb, 32));
+      if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6][j] = qb;
     }
   }
   if (norm2) {                                                 // one atomic per workgroup, head and operand (dead rows repeat row N - 1)
     __syncthreads();
     const int j = threadIdx.x;
     if (j < QK_HB && h0 + j < heads) {
-      const float q = fmaxf(fmaxf(smax[0][j], smax[1][j]), fmaxf(smax[2][j], smax[3][j]));
-      atomicMax((unsigned*)(norm2 + (h0 + j) * 2 + which), __float_as_uint(q));     // non-negative floats order like their bit patterns
+      atomicMax((unsigned*)(norm2 + (h0 + j) * 2 + which), max(max(smax[0][j], smax[1][j]), max(smax[2][j], smax[3][j])));
     }
   }
 }
@@ -649,12 +651,14 @@ __global__ __launch_bounds__(256) void ulysses_place_kernel(const UlyPlaceArgs a
   if (blockIdx.y == 3) {                                        // the score bound that rode in the K blocks' extra rows
     if (t >= a.hloc * 2) return;
     const int h = (int)(t >> 1), e = (int)(t & 1);
-    float m = 0.f;
+    // the same maximum of bit patterns as qk_post_kernel's atomicMax on one GPU: a NaN norm from ANY rank (larger than +inf as an unsigned)
+    // reaches the attention kernel, which then runs that head on the running maximum - fmaxf would have dropped it
+    unsigned m = 0u;
     for (int i = 0; i < a.world; ++i) {
       const long long ci = a.bound[i + 1] - a.bound[i];
-      m = fmaxf(m, ((const float*)(a.rk + a.off[i] + ((long long)h * (ci + 1) + ci) * 64))[e]);
+      m = max(m, ((const unsigned*)(a.rk + a.off[i] + ((long long)h * (ci + 1) + ci) * 64))[e]);
     }
-    a.norm2_out[t] = m;
+    ((unsigned*)a.norm2_out)[t] = m;
     return;
   }
   if (blockIdx.y < 2) {                                         // Q', K': one 16-byte chunk (8 of the 64 d) of one row

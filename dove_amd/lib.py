@@ -128,6 +128,23 @@ PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []),
          "dove_workspace_high_water": (C.c_size_t, [_VP])}
 
 
+def kernel_source_sha256() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/dove_hip.h; names and bytes, sorted): what a measurement of the kernels
+    is a measurement OF.  tools/pmc_bench_traffic.py stores it in profiles/pmc_traffic.json and bench.py replays that summary only when it
+    equals the tree's - a PMC pass taken on other kernel code (round 4: the MFMA-shape move) can no longer be replayed as this build's."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "dove_hip.h"))
+    for fn in files:
+        h.update(os.path.basename(fn).encode() + b"\0")
+        with open(fn, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def use_timing_build():
     """tools/ only: bind the separate -DDOVE_TIMING_BUILD library (ablation switches, s_memtime phase logs; built by
     ``dove_amd/csrc/build.sh timing``) instead of the product library.  Must be called before the first ``load()``."""

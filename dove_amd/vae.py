@@ -326,27 +326,30 @@ class AutoencoderKLCogVideoX:
             if self.tile_streams > 1 and len(order) > 1 and x_cl.is_cuda:
                 if self._tile_stream is None:
                     self._tile_stream = torch.cuda.Stream(device=self.device)
-                side, main = self._tile_stream, torch.cuda.current_stream()
+                side, main = self._tile_stream, torch.cuda.current_stream(self.device)
                 side.wait_stream(main)                          # x_cl was produced on the caller's stream
-            for k, ((th, tw, _), members) in enumerate(order):
-                nb = len(members)
-                cache, parts = {}, []
-                self._nb = nb
-                with torch.cuda.stream(side if (side is not None and k > 0) else None):
-                    try:
-                        for s, e in frame_batches(T, batch):
-                            xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
-                            o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
-                            parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
-                    finally:
-                        self._nb = 1
-                    out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
-                if side is not None and k > 0:
-                    out.record_stream(main)                     # blended / cropped on the caller's stream below
-                for n, (a, b) in enumerate(members):
-                    rows[a][b] = out[n]
-            if side is not None:
-                main.wait_stream(side)
+            try:
+                for k, ((th, tw, _), members) in enumerate(order):
+                    nb = len(members)
+                    cache, parts = {}, []
+                    self._nb = nb
+                    with torch.cuda.stream(side if (side is not None and k > 0) else None):
+                        try:
+                            for s, e in frame_batches(T, batch):
+                                xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
+                                o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
+                                parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
+                        finally:
+                            self._nb = 1
+                        out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
+                    if side is not None and k > 0:
+                        out.record_stream(main)                     # blended / cropped on the caller's stream below
+                    for n, (a, b) in enumerate(members):
+                        rows[a][b] = out[n]
+            finally:
+                # also when a class raised: kernels of the side stream may still be reading x_cl, which the caller is free to drop
+                if side is not None:
+                    main.wait_stream(side)
         else:
             for a, i in enumerate(ii):
                 for b, j in enumerate(jj):
@@ -394,7 +397,7 @@ class AutoencoderKLCogVideoX:
             return outs
         if self._streams is None:
             self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.device)
         cache, outs = StreamCache(), []
         for st in self._streams:
             st.wait_stream(main)                   # x_cl was produced on the caller's stream

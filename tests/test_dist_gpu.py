@@ -117,6 +117,37 @@ def test_process_video_sharded_on_hip_bit_identical(world):
     assert not bad, f"sharded result differs from the single-process one on ranks {[r['rank'] for r in bad]}: {bad[0]}"
 
 
+def _bench_line(env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--layers", "1", "--steps", "1", "--warmup", "1",
+           "--frames", "17", "--height", "128", "--width", "192", "--no-variants"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    return json.loads(lines[0])
+
+
+def test_bench_single_clip_self_validation():
+    """bench.py --gpus N validates its own single-clip (configs[2]) measurement: every rank's decoded frames are compared, by per-frame
+    checksums of the raw bits, with the frames of rank 0's one-GPU result of the same clip, and the line carries `single_clip.bit_identical`
+    (+ `single_clip_failed` when it is not True).  Exercised here on the debug path (2 ranks as 2 processes on this box's one GPU, gloo
+    wires): a clean run reads True; with one bit flipped in rank 1's last frame (DOVE_BENCH_STRONG_FAULT=corrupt:1) the same run reads
+    False, names the frame and flags the line.  Shard axis: /root/reference/inference_script.py:249-279, 690-703."""
+    d = _bench_line({})
+    sc = d["single_clip"]
+    print(f"[bench single_clip] clean: bit_identical {sc['bit_identical']} frames per rank {sc['frames_decoded_per_rank']}")
+    assert sc["bit_identical"] is True and sc["mismatched_frames"] == [] and "single_clip_failed" not in d, sc
+    assert sum(sc["frames_decoded_per_rank"]) == 17 and min(sc["frames_decoded_per_rank"]) > 0
+    d = _bench_line({"DOVE_BENCH_STRONG_FAULT": "corrupt:1"})
+    sc = d["single_clip"]
+    print(f"[bench single_clip] one flipped bit on rank 1: bit_identical {sc['bit_identical']} mismatched frames {sc['mismatched_frames']}")
+    assert sc["bit_identical"] is False and sc["mismatched_frames"] == [16] and d.get("single_clip_failed") is True, sc
+
+
 # ---- BASELINE configs[2] at its REAL size: 33x720x1280, 8 ranks (as 8 processes on the one GPU), full-width VAE, 2-layer DiT -------------
 RF, RH, RW = 33, 720, 1280
 HALO_L0_128 = 2 * 128 * RH * RW * 2          # 471 859 200 B: the 2-frame halo of a 128-channel conv at full resolution (SURVEY.md 8e: "472 MB")

@@ -806,6 +806,73 @@ def test_prodshape_conv3d_128_cache_resid_sampled():
             close(f"prod_conv3d t{t} rows {r0}-{r1}", y[t, r0:r1 + 1], ref)
 
 
+def _rms_rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt().clamp_min(1e-20))
+
+
+def test_prodshape_conv3d_128_no_cache_w_first_sampled():
+    """The FIRST frame-batch of a clip: 128 -> 128 3x3x3 causal conv on 9 x 720 x 1280 WITHOUT a conv cache (frame 0 replicated twice in
+    front: CogVideoXCausalConv3d's constant-replicate pad, /root/reference/inference_script.py:408, 500).  The product runs frames 0 / 1 of
+    such a launch on the temporal weight sums (dove_conv_desc.w_first: W0+W1+W2 on frame 0; W0+W1 on frame 0, then W2 on frame 1) - one / two
+    temporal groups instead of three.  Checked against plain F.conv3d of the replicate-padded input at frames 0, 1, 2 and 8, on the rows a
+    tile / round indexing bug would hit; and the error of BOTH weight-sum forms (w_first here, w_sub of the upsample conv) is printed next
+    to the direct (per-tap) forms of the same launches, so the price of the one extra bf16 rounding of the summed weights has a number."""
+    import dataclasses
+
+    import torch.nn.functional as F
+    T, H, W, Cc = 9, 720, 1280, 128
+    g = torch.Generator(device="cuda").manual_seed(151)
+    gw = torch.Generator().manual_seed(152)
+    w = (torch.randn(Cc, Cc, 3, 3, 3, generator=gw) * (Cc * 27) ** -0.5).to(BF).float()
+    b = torch.randn(Cc, generator=gw) * 0.1
+    pc = ops.pack_conv(w, b, "cuda")
+    assert pc.w_first is not None
+    x = torch.randn(T, H, W, Cc, device="cuda", generator=g).to(BF)
+    y = ops.conv(x, pc)                                              # w_first form (no cache handed over)
+    y_direct = ops.conv(x, dataclasses.replace(pc, w_first=None))    # the same launch on the per-tap weights (replicated frame read 3 / 2 times)
+    assert ops.conv_kernel_name(x.shape, pc) == "conv3x3_halo4x_kernel"
+    torch.cuda.synchronize()
+    xin = torch.cat([x[:1], x[:1], x], dim=0)                        # frame t of the output reads xin[t : t + 3]
+    refs, gots, gots_d = [], [], []
+    for t in (0, 1, 2, 8):
+        for r0, r1 in _bands(H, (0, 15, 351, 703, 718)):
+            rows = r1 - r0 + 1
+            slab = torch.zeros(3, rows + 2, W + 2, Cc, device="cuda")
+            a, bnd = max(r0 - 1, 0), min(r1 + 2, H)
+            slab[:, a - (r0 - 1): a - (r0 - 1) + (bnd - a), 1:W + 1] = xin[t:t + 3, a:bnd].float()
+            ref = F.conv3d(slab.cpu().permute(3, 0, 1, 2)[None], w, b)[0, :, 0].permute(1, 2, 0)      # [rows, W, Cc] fp32
+            close(f"prod_conv3d_first t{t} rows {r0}-{r1}", y[t, r0:r1 + 1], ref.to(BF))
+            close(f"prod_conv3d_first(direct) t{t} rows {r0}-{r1}", y_direct[t, r0:r1 + 1], ref.to(BF))
+            if t < 2:
+                refs.append(ref); gots.append(y[t, r0:r1 + 1].float().cpu()); gots_d.append(y_direct[t, r0:r1 + 1].float().cpu())
+    # frames >= 2 never touch the sums: the two launches agree bit for bit there
+    assert torch.equal(y[2:], y_direct[2:])
+    R = torch.cat(refs)
+    e_sum, e_dir = _rms_rel(torch.cat(gots), R), _rms_rel(torch.cat(gots_d), R)
+    print(f"[weight sums] 3x3x3 128->128 no cache, frames 0-1 at 720x1280, rms-rel vs fp32 F.conv3d: w_first {e_sum:.3e}  direct {e_dir:.3e}  "
+          f"| vs the bf16-rounded reference: w_first {_rms_rel(torch.cat(gots), R.to(BF)):.3e}  direct {_rms_rel(torch.cat(gots_d), R.to(BF)):.3e}")
+    # upsample-fused 256 -> 256 3x3 at 360x640 -> 720x1280 (the launch of test_prodshape_upsample_conv_256_sampled): w_sub vs direct taps
+    H2, W2, C2 = 360, 640, 256
+    w2 = (torch.randn(C2, C2, 3, 3, generator=gw) * (C2 * 9) ** -0.5).to(BF).float()
+    b2 = torch.randn(C2, generator=gw) * 0.1
+    pc2 = ops.pack_conv(w2, b2, "cuda")
+    x2 = torch.randn(2, H2, W2, C2, device="cuda", generator=g).to(BF)
+    y2 = ops.conv(x2, pc2, up=1, pad=(1, 1))
+    y2_direct = ops.conv(x2, dataclasses.replace(pc2, w_sub=None), up=1, pad=(1, 1))
+    torch.cuda.synchronize()
+    r0, r1 = 350, 357
+    up = x2[1].float()[(torch.arange(r0 - 1, r1 + 2, device="cuda") >> 1)][:, (torch.arange(-1, 2 * W2 + 1, device="cuda").clamp(0, 2 * W2 - 1) >> 1)]
+    up[:, 0] = 0
+    up[:, -1] = 0
+    ref2 = F.conv2d(up.cpu().permute(2, 0, 1)[None], w2, b2)[0].permute(1, 2, 0)
+    e2_sum, e2_dir = _rms_rel(y2[1, r0:r1 + 1], ref2), _rms_rel(y2_direct[1, r0:r1 + 1], ref2)
+    print(f"[weight sums] up 3x3 256->256 360x640 -> 720x1280, rows {r0}-{r1}, rms-rel vs fp32 F.conv2d: w_sub {e2_sum:.3e}  direct {e2_dir:.3e}  "
+          f"| vs the bf16-rounded reference: w_sub {_rms_rel(y2[1, r0:r1 + 1], ref2.to(BF)):.3e}  direct {_rms_rel(y2_direct[1, r0:r1 + 1], ref2.to(BF)):.3e}")
+    # both forms round their result to bf16 (rms 1.1e-3 by itself); the summed weights add one rounding of the WEIGHTS (2^-9 relative per sum)
+    assert e_sum < 4e-3 and e_dir < 4e-3 and e2_sum < 4e-3 and e2_dir < 4e-3, (e_sum, e_dir, e2_sum, e2_dir)
+
+
 @pytest.mark.parametrize("tmode,T_in,t_out", [(0, 8, 8), (1, 4, 8)])
 def test_prodshape_upsample_conv_256_sampled(tmode, T_in, t_out):
     """Upsample-fused 256 -> 256 3x3 conv, 360 x 640 -> 720 x 1280 (CogVideoXUpsample3D of decoder up-block 2: the nearest x2

@@ -259,6 +259,9 @@ def heavy_tail_scales(v, t, seed=5):
     return sc_v, sc_t
 
 
+HEAVY_SEEDS = ((4, 10), (14, 20), (24, 30), (34, 40))           # (clip seed, posterior-noise seed); the first is the stage-wise test's clip
+
+
 @pytest.fixture(scope="module")
 def heavy(golden_dir):
     from safetensors.torch import load_file
@@ -275,16 +278,26 @@ def heavy(golden_dir):
     text = load_file(os.path.join(golden_dir, "empty_prompt_embedding.safetensors"))["prompt_embedding"].clone()
     text[17] = text[17] * 30                                     # one text row far out of scale
     F, H, W = 9, 256, 256
-    video = synth_clip(F, H, W, seed=4)
-    noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=torch.Generator().manual_seed(10))
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
-    tr32, trbf = {}, {}
-    t0 = time.time()
-    ref = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt_gpu.moved("cpu")), s, video, text.float()[None], noise, trace=tr32)
-    refbf = odit.process_video(OracleVAE(v, wv, torch.bfloat16), odit.OracleDiT(t, wt_gpu.moved("cpu"), torch.bfloat16), s, video, text[None], noise,
-                               trace=trbf)
-    print(f"[heavy] fp32 + bf16-emulated oracle, 9x256x256 / 42 layers, heavy-tailed weights: {time.time() - t0:.1f} s")
-    return dict(pipe=pipe, cfg=(v, t, s), wv=wv, wt=wt_gpu, text=text, video=video, noise=noise, ref=ref, refbf=refbf, tr32=tr32, trbf=trbf)
+    runs = {}
+
+    def oracle_run(clip_seed, noise_seed):
+        """fp32 oracle + bf16-emulated reference of the whole operator on one (clip, noise) pair - same weights; cached per pair."""
+        key = (clip_seed, noise_seed)
+        if key not in runs:
+            video = synth_clip(F, H, W, seed=clip_seed)
+            noise = torch.randn(1, 16, 3, H // 8, W // 8, generator=torch.Generator().manual_seed(noise_seed))
+            tr32, trbf = {}, {}
+            t0 = time.time()
+            ref = odit.process_video(OracleVAE(v, wv), odit.OracleDiT(t, wt_gpu.moved("cpu")), s, video, text.float()[None], noise, trace=tr32)
+            refbf = odit.process_video(OracleVAE(v, wv, torch.bfloat16), odit.OracleDiT(t, wt_gpu.moved("cpu"), torch.bfloat16), s, video,
+                                       text[None], noise, trace=trbf)
+            print(f"[heavy] fp32 + bf16-emulated oracle, 9x256x256 / 42 layers, heavy-tailed weights, clip seed {clip_seed}: {time.time() - t0:.1f} s")
+            runs[key] = dict(video=video, noise=noise, ref=ref, refbf=refbf, tr32=tr32, trbf=trbf)
+        return runs[key]
+
+    first = oracle_run(*HEAVY_SEEDS[0])
+    return dict(pipe=pipe, cfg=(v, t, s), wv=wv, wt=wt_gpu, text=text, oracle_run=oracle_run, **first)
 
 
 def test_heavy_tailed_weights_stagewise(heavy):
@@ -343,7 +356,43 @@ def test_heavy_tailed_weights_stagewise(heavy):
     print(f"[heavy] decoder on IDENTICAL input (the fp32 oracle's x0): hip {e_iso_h:.3e}  bf16 reference {e_iso_b:.3e}; "
           f"whole-operator decoded ratio hip / reference {eh['decoded'] / eb['decoded']:.2f}")
     assert e_iso_h <= 1.25 * e_iso_b + 1e-3, (e_iso_h, e_iso_b)
-    assert eh["decoded"] <= 2.0 * eb["decoded"] + 1e-3, (eh["decoded"], eb["decoded"])
+    assert eh["decoded"] <= 2.0 * eb["decoded"] + 1e-3, (eh["decoded"], eb["decoded"])      # one seed: a sanity bound only -
+    # the statement about the reference is test_heavy_tailed_decoded_multi_seed below (geometric mean over four clips <= 1.25)
+
+
+def test_heavy_tailed_decoded_multi_seed(heavy):
+    """The whole-operator `decoded` stage under the heavy-tailed weights as a statement about the REFERENCE (/root/reference/
+    inference_script.py:408, 500: encode ... decode in bf16), not a loose per-seed bound: over FOUR (clip, posterior-noise) pairs on one weight
+    set, the ratio  rms-rel(hip, fp32 oracle) / rms-rel(bf16-emulated reference, fp32 oracle)  of the un-clamped decoder output has a
+    GEOMETRIC MEAN <= 1.25 (the north-star stage gate, unchanged) and no single pair above 2 x.  One pair is a lottery (91 % of the squared
+    error sits in 1 % of the pixels: profiles/r04_heavy_tail_lottery.log reads 1.58 / 0.74 / 1.09 / 0.96 on a CPU restatement of this operator
+    graph); the mean over pairs is what an implementation that is as accurate as the reference's own bf16 run has to hold.  The other stages
+    (moments, latent, v, x0) are gated per pair at the unchanged 1.25 x + 1e-3, and the PSNR gate (>= reference - 0.05 dB) holds on the MEAN."""
+    import math
+    pipe, text = heavy["pipe"], heavy["text"]
+    keys = ("moments", "latent", "v", "x0", "decoded")
+    ratios, dpsnr = [], []
+    for cs, ns in HEAVY_SEEDS:
+        r = heavy["oracle_run"](cs, ns)
+        st = hip_stages(pipe, r["video"].cuda(), text, r["noise"].cuda())
+        got = process_video(pipe, r["video"].cuda(), empty_prompt_embedding=text, posterior_noise=r["noise"].cuda())
+        torch.cuda.synchronize()
+        eh = {k: rms_rel(st[k], r["tr32"][k]) for k in keys}
+        eb = {k: rms_rel(r["trbf"][k], r["tr32"][k]) for k in keys}
+        p_hip, p_bf = psnr(got.float().cpu(), r["ref"]), psnr(r["refbf"].float(), r["ref"])
+        ratios.append(eh["decoded"] / eb["decoded"])
+        dpsnr.append(p_hip - p_bf)
+        print(f"[heavy x4] clip seed {cs}: decoded hip {eh['decoded']:.3e} | bf16 reference {eb['decoded']:.3e} -> ratio {ratios[-1]:.3f};  "
+              f"PSNR hip - reference {dpsnr[-1]:+.3f} dB;  other stages (hip|ref) " + "  ".join(f"{k}:{eh[k]:.2e}|{eb[k]:.2e}" for k in keys[:4]))
+        for k in keys[:4]:
+            assert eh[k] <= 1.25 * eb[k] + 1e-3, (cs, k, eh[k], eb[k])
+        del st, got
+    gmean = math.exp(sum(math.log(x) for x in ratios) / len(ratios))
+    print(f"[heavy x4] decoded ratio hip / bf16 reference per pair: {[round(x, 3) for x in ratios]}  geometric mean {gmean:.3f} (gate 1.25); "
+          f"PSNR hip - reference, mean over pairs {sum(dpsnr) / len(dpsnr):+.3f} dB (gate -0.05)")
+    assert gmean <= 1.25, (gmean, ratios)
+    assert max(ratios) <= 2.0, ratios
+    assert sum(dpsnr) / len(dpsnr) >= -0.05, dpsnr
 
 
 def test_heavy_tailed_weights_mxfp8_velocity(heavy):
