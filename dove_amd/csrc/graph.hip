@@ -90,6 +90,13 @@ __global__ void pack_first_kernel(const bf16_t* __restrict__ w, long long n, bf1
     dst[n + i] = f2bf(s01 + bf2f(w[2 * n + i]));
   }
 }
+// pair sums of a packed kt = 3 weight [3][taps][n]: dst [2][taps][n] = w0 + w1, w1 + w2 in fp32, rounded once (dove_amd/ops.py pack_conv, pair=True)
+__global__ void pack_pair_kernel(const bf16_t* __restrict__ w, long long n, bf16_t* __restrict__ dst) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    dst[i] = f2bf(bf2f(w[i]) + bf2f(w[n + i]));
+    dst[n + i] = f2bf(bf2f(w[n + i]) + bf2f(w[2 * n + i]));
+  }
+}
 // sub-pixel form of an upsample-fused 3x3 conv: w [3][3][n] packed bf16 -> dst [4 phases][2x2][n]; fp32 sums in (dh, dw) order, one rounding
 __global__ void pack_sub_kernel(const bf16_t* __restrict__ w, long long n, bf16_t* __restrict__ dst) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -155,6 +162,7 @@ inline int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size
 
 struct Raw { const void* p; std::vector<long long> shape; int dt; long long numel() const { long long n = 1; for (auto d : shape) n *= d; return n; } };
 struct Packed { bf16_t* w = nullptr; float* bias = nullptr; bf16_t* w_first = nullptr, *w_sub = nullptr;   // dove_conv_desc.w_first (kt == 3) / .w_sub (3x3, kt == 1)
+                bf16_t* w_pair = nullptr;                                                                   // dove_conv_desc.w_pair (kt == 3, on request)
                 int kt = 1, kh = 1, kw = 1, cin = 0, cin_pad = 0, cout = 0, cout_pad = 0;
                 int cout_store() const { return (int)ru(cout, 4); } };
 struct Tensor { bf16_t* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long long elems() const { return (long long)T * H * W * C; } size_t bytes() const { return (size_t)elems() * 2; } };
@@ -263,7 +271,7 @@ struct dove_ctx {
   int piece_partner = -1; bool piece_lower = false;
   dove_group_fn group_begin = nullptr, group_end = nullptr;   // bracket of one exchange for rendezvous transports (RCCL: ncclGroupStart / End)
   // options (dove_set_option)
-  bool opt_tiling = false, opt_linear_mx = false, opt_attn_mx = false;
+  bool opt_tiling = false, opt_linear_mx = false, opt_attn_mx = false, opt_weight_sums = true;
   int sample_h = 480, sample_w = 720;                   // vae/config.json sample_height / sample_width: tile geometry of enable_tiling()
   bool direct_io_convs = false;                         // inside a spatial tile: conv_in / conv_out in their direct forms (dove_amd/vae.py)
   uint8_t *Q8 = nullptr, *K8 = nullptr, *V8 = nullptr, *Vs8 = nullptr; long long attn8_n = 0;   // MXFP8 attention operands
@@ -302,7 +310,8 @@ int to_bf16(dove_ctx* c, const std::string& name, bf16_t** out) {
   return 0;
 }
 // pack one or several weights (stacked along cout) + optional biases into the implicit-GEMM layout (dove_amd/ops.py pack_conv)
-int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, Packed* out) {
+// `sub`: build the sub-pixel sums of a 3x3 Conv2d (read by upsample-fused launches only); `pair`: build the pair sums of a 3x3x3 conv
+int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<std::string>& bnames, Packed* out, bool sub = false, bool pair = false) {
   Packed q;
   int cout = 0;
   std::vector<const Raw*> ws;
@@ -335,7 +344,13 @@ int pack(dove_ctx* c, const std::vector<std::string>& wnames, const std::vector<
     hipLaunchKernelGGL(pack_first_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wf);
     q.w_first = (bf16_t*)wf;
   }
-  if (q.kt == 1 && q.kh == 3 && q.kw == 3) {                     // sub-pixel form for the upsample-fused use of this conv (dove_conv_desc.w_sub)
+  if (q.kt == 3 && pair) {                                       // pair sums for a conv behind a time-doubling upsampler (dove_conv_desc.w_pair)
+    const long long n = (long long)q.kh * q.kw * q.cout_pad * q.cin_pad;
+    void* wpp; CHK(dev_alloc(c, (size_t)2 * n * 2, &wpp));
+    hipLaunchKernelGGL(pack_pair_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wpp);
+    q.w_pair = (bf16_t*)wpp;
+  }
+  if (q.kt == 1 && q.kh == 3 && q.kw == 3 && sub) {              // sub-pixel form for the upsample-fused use of this conv (dove_conv_desc.w_sub)
     const long long n = (long long)q.cout_pad * q.cin_pad;
     void* wsb; CHK(dev_alloc(c, (size_t)16 * n * 2, &wsb));
     hipLaunchKernelGGL(pack_sub_kernel, dim3(1024), dim3(256), 0, 0, (const bf16_t*)wp, n, (bf16_t*)wsb);
@@ -387,7 +402,7 @@ struct ConvOpt { const Tensor* cache = nullptr; int stride = 1, pad_h = -1, pad_
                  const bf16_t* resid = nullptr; int ldr = 0; const float* gate = nullptr; long long gate_split = 0; bf16_t* out = nullptr; int ldo = -1;
                  float gn_eps = -1.f; float** gn_stats = nullptr;
                  bool out_f32 = false;
-                 int nb = 1; long long cache_stride = 0; };   // nb > 1: dove_conv_desc.nb (x.T = nb x frames, t_out per instance)   // out_f32: the returned Tensor holds float [..][ldo] (its C counts bf16 units = 2 * ldo)
+                 int nb = 1; long long cache_stride = 0; int tdup = 0; };   // nb > 1: dove_conv_desc.nb (x.T = nb x frames, t_out per instance)   // out_f32: the returned Tensor holds float [..][ldo] (its C counts bf16 units = 2 * ldo)
 // x [T,H,W,cin_pad] -> out (allocated unless opt.out).  When opt.gn_eps >= 0 and the kernel fuses GroupNorm statistics, *opt.gn_stats
 // receives [32][2] (mean, rstd) from the arena (caller releases); otherwise it is left NULL.
 int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tensor* out, void* stream) {
@@ -409,8 +424,9 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
   d.x = x.p; d.cache = o.cache ? o.cache->p : nullptr; d.w = pc.w; d.bias = pc.bias; d.resid = o.resid; d.gate = o.gate; d.out = y.p;
   d.t_in = t_in; d.h_in = x.H; d.w_in = x.W; d.cin = x.C; d.t_out = t_out; d.h_out = ho; d.w_out = wo;
   d.nb = nb; d.cache_stride = o.cache ? o.cache_stride : 0;
-  d.w_first = o.cache ? nullptr : pc.w_first;
-  d.w_sub = o.up == 1 ? pc.w_sub : nullptr;
+  d.w_first = (o.cache || !c->opt_weight_sums) ? nullptr : pc.w_first;
+  d.w_sub = (o.up == 1 && c->opt_weight_sums) ? pc.w_sub : nullptr;
+  if (o.tdup && c->opt_weight_sums && pc.w_pair && pc.kt == 3 && !(o.tdup == 2 && o.cache)) { d.tdup = o.tdup; d.w_pair = pc.w_pair; }   // dove_amd/ops.py conv
   d.cout_pad = pc.cout_pad; d.cout_store = pc.cout_store();
   d.kt = pc.kt; d.kh = pc.kh; d.kw = pc.kw; d.stride = o.stride; d.pad_h = ph; d.pad_w = pw; d.up = o.up; d.tmode = o.tmode; d.act = o.act;
   d.ldo = ldo; d.ldr = o.ldr; d.gate_split = o.gate_split;
@@ -733,12 +749,14 @@ int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::strin
   return 0;
 }
 // x (+ its fused stats, consumed) -> block output (+ its fused stats).  x is released.
-int resnet(dove_ctx* c, Tensor* x, float** xstats, const std::string& name, const Tensor* zq, void* stream) {
+// `tdup`: x came out of a time-doubling Upsample3D (its frames are bit-identical pairs; 1 / 2 = the upsampler's tmode): the per-pixel norm1 keeps
+// the pairs, conv1 is told (dove_conv_desc.tdup)
+int resnet(dove_ctx* c, Tensor* x, float** xstats, const std::string& name, const Tensor* zq, void* stream, int tdup = 0) {
   const float eps = c->cfg.vae_norm_eps;
   Tensor h1, h, h2, y;
   CHK(norm_silu(c, *x, *xstats, name + ".norm1", zq, &h1, stream));
   float* hs = nullptr;
-  ConvOpt o1; o1.gn_eps = eps; o1.gn_stats = &hs;
+  ConvOpt o1; o1.gn_eps = eps; o1.gn_stats = &hs; o1.tdup = tdup;
   CHK(cconv(c, h1, true, name + ".conv1", o1, &h, stream));
   CHK(norm_silu(c, h, hs, name + ".norm2", zq, &h2, stream));
   free_t(c, h);
@@ -809,8 +827,9 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
   int n_tdown = 0;
   for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
   for (int j = 0; j < 2; ++j) { snprintf(nm, sizeof nm, "decoder.mid_block.resnets.%d", j); CHK(resnet(c, &h, &hs, nm, &z, stream)); }
+  int tdup = 0;                                                 // the last upsampler's time map: the next block's first conv reads frame pairs
   for (int i = 0; i < cf.vae_num_blocks; ++i) {
-    for (int j = 0; j < cf.vae_layers_per_block + 1; ++j) { snprintf(nm, sizeof nm, "decoder.up_blocks.%d.resnets.%d", i, j); CHK(resnet(c, &h, &hs, nm, &z, stream)); }
+    for (int j = 0; j < cf.vae_layers_per_block + 1; ++j) { snprintf(nm, sizeof nm, "decoder.up_blocks.%d.resnets.%d", i, j); CHK(resnet(c, &h, &hs, nm, &z, stream, j == 0 ? tdup : 0)); }
     if (i < cf.vae_num_blocks - 1) {
       snprintf(nm, sizeof nm, "decoder.up_blocks.%d.upsamplers.0", i);
       if (hs) { c->arena.release(hs); hs = nullptr; }
@@ -825,6 +844,7 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
       CHK(conv(c, h, c->pc.at(nm), ou, &u, stream));
       free_t(c, h);
       h = u;
+      tdup = ou.tmode;
     }
   }
   Tensor n;
@@ -1079,6 +1099,7 @@ extern "C" int dove_set_option(dove_ctx* c, int option, long long value) {
                      "dove_set_option: DOVE_OPT_DIT_LINEAR_MXFP8 must be chosen before dove_finalize_weights (the weights are quantised there)");
       c->opt_linear_mx = value != 0; return DOVE_OK;
     case DOVE_OPT_DIT_ATTN_MXFP8: c->opt_attn_mx = value != 0; return DOVE_OK;
+    case DOVE_OPT_WEIGHT_SUMS: c->opt_weight_sums = value != 0; return DOVE_OK;
     default: break;
   }
   dove_set_error("dove_set_option: unknown option %d", option);
@@ -1092,6 +1113,7 @@ extern "C" long long dove_get_option(dove_ctx* c, int option) {
     case DOVE_OPT_VAE_SAMPLE_WIDTH: return c->sample_w;
     case DOVE_OPT_DIT_LINEAR_MXFP8: return c->opt_linear_mx;
     case DOVE_OPT_DIT_ATTN_MXFP8: return c->opt_attn_mx;
+    case DOVE_OPT_WEIGHT_SUMS: return c->opt_weight_sums;
     default: return -1;
   }
 }
@@ -1114,7 +1136,12 @@ extern "C" int dove_finalize_weights(dove_ctx* c) {
     if (k.compare(0, 8, "encoder.") && k.compare(0, 8, "decoder.")) continue;
     if (ends_with(k, ".conv.weight") && k.find(".conv_y.") == std::string::npos && k.find(".conv_b.") == std::string::npos) {
       const std::string n = k.substr(0, k.size() - strlen(".conv.weight"));
-      Packed p; CHK(pack(c, {k}, {n + ".conv.bias"}, &p)); c->pc[n] = p;
+      // sub-pixel sums only for the upsamplers; pair sums for the first causal conv behind a TIME-doubling upsampler (decoder up-block
+      // i > 0 whose predecessor compresses time: dove_amd/vae.py _pack)
+      int ub = -1, n_td = 0;
+      for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_td;
+      const bool pair = sscanf(n.c_str(), "decoder.up_blocks.%d.resnets.0.conv1", &ub) == 1 && ends_with(n, ".resnets.0.conv1") && ub > 0 && ub <= n_td;
+      Packed p; CHK(pack(c, {k}, {n + ".conv.bias"}, &p, n.find(".upsamplers.") != std::string::npos, pair)); c->pc[n] = p;
     } else if (ends_with(k, ".conv_shortcut.weight")) {
       const std::string n = k.substr(0, k.size() - strlen(".weight"));
       Packed p; CHK(pack(c, {k}, {n + ".bias"}, &p)); c->pc[n] = p;

@@ -366,8 +366,10 @@ struct H4State {
   int t;                                                      // output frame of nxt's tile WITHIN its instance (dove_conv_desc.nb)
   long long f0;                                               // first input frame of that instance
   const bf16_t* cache_b;                                      // that instance's conv cache (nullptr: none)
-  int ndt;                                                    // temporal groups of nxt's tile: a.kt, or 1 / 2 for an instance's first two frames
-  const bf16_t* wf_base;                                      //   (IgemmArgs.w_first: the replicated-frame taps pre-summed), cout tile applied
+  int ndt;                                                    // temporal groups of nxt's tile: a.kt, or 1 / 2 where taps read equal frames
+  int split;                                                  //   how the three causal taps fall into groups (h4_split)
+  const bf16_t* wf_base;                                      //   IgemmArgs.w_first (W0 + W1 | W0 + W1 + W2), cout tile applied
+  const bf16_t* wp_base;                                      //   IgemmArgs.w_pair (W0 + W1 | W1 + W2), cout tile applied
   const bf16_t* wt_base;                                      // weights of nxt's cout tile
   const bf16_t* h_base;                                       // nxt's halo source: frame + channel chunk
   const bf16_t* wg_nxt;                                       // nxt's weights: tap 0 of (frame tap, chunk)
@@ -391,12 +393,31 @@ __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k
   q.oh0 = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_w) * halo8::TH);
   return q;
 }
-// temporal groups of the tile whose output frame (global index over the instances) is t: see IgemmArgs.w_first
-__device__ __forceinline__ int h4_tile_ndt(const IgemmArgs& a, int t) {
-  if (a.w_first == nullptr || a.kt != 3 || a.cache != nullptr) return a.kt;
+// How the three causal taps (frames t - 2, t - 1, t of the instance; before its first frame: the conv cache, else frame 0 replicated) of the
+// tile whose output frame (global index over the instances) is t fall into TEMPORAL GROUPS - taps that read bit-identical frames share one
+// group on the pre-summed weights:
+//   0  one group per tap (kt groups)                     the general case
+//   1  {0 1 2}: (W0 + W1 + W2) x[t]                       w_first block 1
+//   2  {0 1}{2}: (W0 + W1) x[t-1], then W2 x[t]           w_first / w_pair block 0, then tap block 2 of w
+//   3  {0}{1 2}: W0 x[t-2], then (W1 + W2) x[t]           tap block 0 of w, then w_pair block 1
+// Without a declaration (tdup == 0) only the cache-less first two frames of an instance split (IgemmArgs.w_first).  tdup == 1: the frames
+// are pairs (0,1), (2,3), ... and the cache, if any, is a pair; tdup == 2: frame 0 single, then pairs (1,2), (3,4), ... (no cache).
+__device__ __forceinline__ int h4_split(const IgemmArgs& a, int t) {
+  if (a.kt != 3) return 0;
   const int tl = a.seg_out == a.T_out ? t : t % a.seg_out;
-  return tl == 0 ? 1 : (tl == 1 ? 2 : 3);
+  const bool cached = a.cache != nullptr;
+  if (a.tdup == 0) {
+    if (a.w_first == nullptr || cached) return 0;
+    return tl == 0 ? 1 : (tl == 1 ? 2 : 0);
+  }
+  if (a.tdup == 1) {
+    if (!cached && tl < 2) return 1;                          // frames 0 and 1 are equal and so is the replicated front
+    return (tl & 1) ? 3 : 2;
+  }
+  if (tl == 0) return 1;
+  return (tl & 1) ? 2 : 3;
 }
+__device__ __forceinline__ int h4_split_ndt(const IgemmArgs& a, int split) { return split == 0 ? a.kt : (split == 1 ? 1 : 2); }
 template <bool kUp>
 __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, const H4Const& k, int id) {
   using namespace halo8;
@@ -430,8 +451,10 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
   s.f0 = (long long)b * a.seg_in;
   s.cache_b = a.cache ? h4_pin64(a.cache + (long long)b * a.cache_bs) : nullptr;
   s.wt_base = a.w + (long long)q.n0 * a.Cin + (long long)(q.ph * 4) * k.wtap_stride;   // sub-pixel form: [phase][2x2 tap][Cout_pad][Cin]
-  s.ndt = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, q.t));
+  s.split = __builtin_amdgcn_readfirstlane(h4_split(a, q.t));
+  s.ndt = h4_split_ndt(a, s.split);
   s.wf_base = a.w_first ? a.w_first + (long long)q.n0 * a.Cin : nullptr;
+  s.wp_base = a.w_pair ? a.w_pair + (long long)q.n0 * a.Cin : nullptr;
   s.n_dt = 0; s.n_kc = 0;
 }
 __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const H4Const& k) {   // descriptors of group nxt
@@ -441,12 +464,14 @@ __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const
   // load from the struct and keep all of it in scratch memory
   const int t = s.t;
   const int tin = a.tmode == 0 ? t : (a.tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
-  // an instance's first two frames without a conv cache (ndt < kt): group j of frame 0 is (W0+W1+W2) on frame 0; of frame 1: (W0+W1) on
-  // frame 0, then W2 on frame 1 - `dtw` is the tap block of the weights, `fv` the source frame
-  const bool first = s.ndt < a.kt;
-  const int dtw = first ? (s.ndt == 2 && s.n_dt == 1 ? 2 : 0) : s.n_dt;
-  const bf16_t* wsel = first && !(s.ndt == 2 && s.n_dt == 1) ? h4_pin64(s.wf_base + (s.ndt == 1 ? 9 : 0) * k.wtap_stride) : s.wt_base;
-  const int fv = first ? s.n_dt : t + s.n_dt - (a.kt - 1);
+  // group n_dt of the tile under its tap split (h4_split): `wsel` + tap block `dtw` = the group's weights, `fv` its source frame (an instance
+  // frame index; negative: before the first frame).  Where taps share a group any of their (equal) frames may be read: the LAST one is
+  const int sp = s.split, g1 = s.n_dt;
+  const int dtw = sp == 0 ? g1 : (sp == 2 && g1 == 1 ? 2 : 0);
+  const int fv = sp == 0 ? t + g1 - (a.kt - 1) : (sp == 1 ? t : (g1 == 1 ? t : (sp == 2 ? t - 1 : t - 2)));
+  const bf16_t* w01 = a.tdup ? s.wp_base : s.wf_base;        // W0 + W1 lives in block 0 of both tables
+  const bf16_t* wsel = sp == 1 ? s.wf_base + 9 * k.wtap_stride : (sp == 2 && g1 == 0 ? w01 : (sp == 3 && g1 == 1 ? s.wp_base + 9 * k.wtap_stride : s.wt_base));
+  wsel = h4_pin64(wsel);
   const bool from_cache = a.kt > 1 && fv < 0 && s.cache_b != nullptr;
   const int fidx = a.kt > 1 ? (fv >= 0 ? fv : (from_cache ? a.kt - 1 + fv : 0)) : tin;
   const bf16_t* f = h4_pin64(from_cache ? s.cache_b + (long long)fidx * k.frame_elems : a.x + (s.f0 + fidx) * k.frame_elems);
@@ -809,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 
     // a tile has an even number of groups (Cin % 64 == 0): two per trip, one of each halo-buffer parity - straight-line,
     // so there is no control-flow merge at which the register allocator would have to reconcile two step bodies
-    const int ng_tile = __builtin_amdgcn_readfirstlane(h4_tile_ndt(a, c.t)) * kc.kcn;   // (2 or 1 temporal groups for an instance's first frames)
+    const int ng_tile = h4_split_ndt(a, __builtin_amdgcn_readfirstlane(h4_split(a, c.t))) * kc.kcn;   // (2 or 1 temporal groups where taps read equal frames)
     int next_base0 = 0;
     if (kSub) {                                                 // halo offsets of this tile's phase; tap 0 of the next tile's
       sub_bases(c.ph, abaseT);
@@ -1596,6 +1621,10 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d->cache_stride == 0 || (d->cache && d->cache_stride >= (long long)(d->kt - 1) * d->h_in * d->w_in * d->cin),
                  "conv_igemm: cache_stride (%lld) is smaller than one instance's cache", d->cache_stride);
   DOVE_CHECK_ARG(desc_nb(d) == 1 || (!d->gate && !d->out_f32), "conv_igemm: nb > 1 is not combined with gate / out_f32");
+  DOVE_CHECK_ARG(d->reserved2 == 0 && d->tdup >= 0 && d->tdup <= 2, "conv_igemm: bad tdup %d", d->tdup);
+  DOVE_CHECK_ARG(!d->tdup || (d->kt == 3 && d->w_pair), "conv_igemm: tdup declares frame pairs of a kt == 3 conv and needs w_pair");
+  DOVE_CHECK_ARG(!d->tdup || d->cache || d->w_first, "conv_igemm: tdup without a conv cache needs w_first too (frames whose three taps read one frame)");
+  DOVE_CHECK_ARG(d->tdup != 2 || !d->cache, "conv_igemm: tdup == 2 (first frame single) is the head of a clip: no conv cache");
   DOVE_CHECK_ARG(!d->gn_partial || dove_conv_gn_partial_rows(d) > 0,
                  "conv_igemm: gn_partial requested but this call does not dispatch to a kernel that fuses the statistics");
   const ConvKernel kern0 = select_kernel(d);
@@ -1637,6 +1666,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
   a.up = d->up; a.tmode = d->tmode; a.act = d->act; a.ldo = d->ldo; a.ldr = d->ldr; a.gate_split = d->gate_split;
   a.gn_partial = nullptr; a.cpg_log = 0;
   a.w_first = nullptr;
+  a.w_pair = nullptr; a.tdup = 0;
   a.sub = 0;
   a.out_f32 = d->out_f32;
   a.nt_out = 0;
@@ -1759,6 +1789,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
     case K_HALO4X_UP: {
       a.gn_partial = d->gn_partial;
       a.w_first = (kern == K_HALO4X && d->kt == 3 && !d->cache) ? (const bf16_t*)d->w_first : nullptr;
+      if (kern == K_HALO4X && d->kt == 3 && d->tdup) { a.tdup = d->tdup; a.w_pair = (const bf16_t*)d->w_pair; }   // (validated in dove_conv_igemm_bf16)
       a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;

@@ -56,6 +56,11 @@ struct IgemmArgs {
   // temporal groups instead of three.  w_first = [2][9][Cout_pad][Cin]: the temporal sums W0 + W1 and W0 + W1 + W2, formed in fp32 and
   // rounded to bf16 ONCE at pack time (dove_conv_desc.w_first); nullptr = three groups for every frame
   const bf16_t* w_first;
+  // conv3x3_halo4x, kt == 3, dove_conv_desc.tdup: the instance's frames come in bit-identical pairs (Upsample3D's time doubling), so two of
+  // every frame's three causal taps read the same bits - two temporal groups per frame: (W0 + W1) x[t-1] + W2 x[t] or W0 x[t-2] + (W1 + W2) x[t].
+  // w_pair = [2][9][Cout_pad][Cin]: W0 + W1 and W1 + W2, fp32 sums rounded once at pack time.  See h4_split
+  const bf16_t* w_pair;
+  int tdup;
   int sub;             // conv3x3_halo4x<kSub>: sub-pixel form of the upsample-fused conv - `w` = dove_conv_desc.w_sub, tiling over the LOW-RES grid
 };
 

@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("ldo", C.c_longlong), ("ldr", C.c_longlong), ("gate_split", C.c_longlong),
         ("gn_partial", C.c_void_p), ("out_f32", C.c_int),
         ("nb", C.c_int), ("cache_stride", C.c_longlong), ("w_first", C.c_void_p), ("w_sub", C.c_void_p),
+        ("w_pair", C.c_void_p), ("tdup", C.c_int), ("reserved2", C.c_int),
     ]
 
     def __init__(self, *a, **k):
@@ -56,7 +57,7 @@ class PreNoise(C.Structure):
 
 
 # dove_set_option keys (include/dove_hip.h)
-OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP8, OPT_DIT_ATTN_MXFP8 = 1, 2, 3, 4, 5
+OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP8, OPT_DIT_ATTN_MXFP8, OPT_WEIGHT_SUMS = 1, 2, 3, 4, 5, 6
 
 
 _VP, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float

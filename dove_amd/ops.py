@@ -33,14 +33,19 @@ class PackedConv:
     # 3x3, kt == 1: [4 phases][2x2 taps][cout_pad][cin_pad] - the sub-pixel form of an upsample-fused conv (dove_conv_desc.w_sub): per output
     # phase the 3x3 weights summed over the taps that read the same low-res pixel (fp32 sums of the bf16 weights, one rounding)
     w_sub: torch.Tensor | None = None
+    # kt == 3, on request: [2][kh*kw][cout_pad][cin_pad] - w0 + w1 and w1 + w2 for a conv whose input frames come in bit-identical pairs
+    # (dove_conv_desc.w_pair / tdup: the first causal conv behind Upsample3D's time doubling); fp32 sums of the bf16 weights, one rounding
+    w_pair: torch.Tensor | None = None
 
     @property
     def cout_store(self) -> int:
         return _ru(self.cout, 4)
 
 
-def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> PackedConv:
-    """weight: Conv3d [Cout,Cin,kt,kh,kw], Conv2d [Cout,Cin,kh,kw] or Linear [Cout,Cin] (any float dtype)."""
+def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device, *, sub: bool = True, pair: bool = False) -> PackedConv:
+    """weight: Conv3d [Cout,Cin,kt,kh,kw], Conv2d [Cout,Cin,kh,kw] or Linear [Cout,Cin] (any float dtype).
+    ``sub``: build the sub-pixel sums of a 3x3 Conv2d (only an upsample-fused use reads them: the VAE passes False for its down-samplers);
+    ``pair``: build the pair sums of a 3x3x3 conv (``conv(..., tdup=)``)."""
     w = weight.detach()
     if w.dim() == 2:
         w = w[:, :, None, None, None]
@@ -61,8 +66,12 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
         t = wp.float().view(3, kh * kw, cout_pad, cin_pad)
         s01 = t[0] + t[1]
         w_first = torch.stack([s01, s01 + t[2]]).to(torch.bfloat16).contiguous()
+    w_pair = None
+    if kt == 3 and pair:
+        t = wp.float().view(3, kh * kw, cout_pad, cin_pad)
+        w_pair = torch.stack([t[0] + t[1], t[1] + t[2]]).to(torch.bfloat16).contiguous()
     w_sub = None
-    if kt == 1 and kh == 3 and kw == 3:
+    if kt == 1 and kh == 3 and kw == 3 and sub:
         t = wp.float().view(3, 3, cout_pad, cin_pad)
         w_sub = torch.zeros(4, 4, cout_pad, cin_pad, dtype=torch.float32, device=device)
         for py in range(2):
@@ -72,7 +81,31 @@ def pack_conv(weight: torch.Tensor, bias: torch.Tensor | None, device) -> Packed
                         a, b = (py + dh + 1) // 2 - py, (px + dw + 1) // 2 - px
                         w_sub[2 * py + px, 2 * a + b] += t[dh, dw]
         w_sub = w_sub.to(torch.bfloat16).contiguous()
-    return PackedConv(wp, bp, kt, kh, kw, cin, cin_pad, cout, cout_pad, w_first, w_sub)
+    return PackedConv(wp, bp, kt, kh, kw, cin, cin_pad, cout, cout_pad, w_first, w_sub, w_pair)
+
+
+def temporal_split(tl: int, tdup: int, cached: bool, first_sums: bool = True):
+    """Host restatement of csrc/igemm.hip h4_split + h4_set_nxt: the temporal groups conv3x3_halo4x runs for output frame tl of an instance,
+    as [(weights, source frame)] with weights in {"w0", "w1", "w2", "w01", "w12", "w012"} (tap blocks of w / their pack-time sums) and the
+    source an instance frame index (negative: before the first frame = the conv cache, else frame 0 replicated).
+    tdup 0: no declaration (only the cache-less first two frames split, when ``first_sums``); 1: frames are pairs (0,1), (2,3), ... and the
+    cache too; 2: frame 0 single, then pairs (1,2), (3,4), ... (no cache)."""
+    plain = [("w0", tl - 2), ("w1", tl - 1), ("w2", tl)]
+    if tdup == 0:
+        if cached or not first_sums or tl > 1:
+            return plain
+        return [("w012", 0)] if tl == 0 else [("w01", 0), ("w2", 1)]
+    if tdup == 1:
+        if not cached and tl < 2:
+            return [("w012", tl)]
+        return [("w0", tl - 2), ("w12", tl)] if tl & 1 else [("w01", tl - 1), ("w2", tl)]
+    if tl == 0:
+        return [("w012", 0)]
+    return [("w01", tl - 1), ("w2", tl)] if tl & 1 else [("w0", tl - 2), ("w12", tl)]
+
+
+def temporal_groups(tl: int, tdup: int, cached: bool) -> int:
+    return len(temporal_split(tl, tdup, cached))
 
 
 _profiler = None
@@ -112,7 +145,7 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
          up: int = 0, tmode: int = 0, t_out: int | None = None, hw_out=None, resid: torch.Tensor | None = None,
          gate: torch.Tensor | None = None, gate_split: int = 0, act: int = 0, ldo: int | None = None,
          out: torch.Tensor | None = None, debug_buf: torch.Tensor | None = None,
-         gn_eps: float | None = None, out_f32: bool = False, nb: int = 1) -> torch.Tensor:
+         gn_eps: float | None = None, out_f32: bool = False, nb: int = 1, tdup: int = 0, weight_sums: bool = True) -> torch.Tensor:
     """Implicit-GEMM conv on channels-last x [T,H,W,cin_pad] -> [t_out,h_out,w_out,ldo].
 
     ``gn_eps``: the output feeds an nn.GroupNorm(32, C, eps) (resnet norm1/norm2, SpatialNorm's norm_layer).  When the
@@ -122,7 +155,12 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
 
     ``nb`` > 1: x holds nb independent instances back to back along the frame axis ([nb*T, H, W, C]; ``t_out`` stays the per-instance
     count) - the same-shaped tiles of the tiled VAE in one launch (include/dove_hip.h dove_conv_desc.nb).  ``cache`` is then
-    [nb, kt-1, H, W, C], possibly a strided view (dim 0) of the previous frame-batch's input; statistics come back as [nb, 32, 2]."""
+    [nb, kt-1, H, W, C], possibly a strided view (dim 0) of the previous frame-batch's input; statistics come back as [nb, 32, 2].
+
+    ``tdup`` (kt == 3, ``pc.w_pair`` packed): the caller declares that every instance's frames come in bit-identical pairs - 1: (0,1), (2,3), ...
+    and the cache too; 2: frame 0 single, then (1,2), (3,4), ..., no cache (include/dove_hip.h dove_conv_desc.tdup): two temporal groups per
+    frame instead of three.  ``weight_sums=False``: none of the pack-time weight sums (w_first / w_sub / w_pair) is handed over - the launch
+    computes the reference's per-tap arithmetic."""
     L.require_cuda(x, resid, gate, out)
     assert x.dtype == torch.bfloat16 and x.dim() == 4, (x.dtype, x.shape)
     T, H, W, Cx = x.shape
@@ -154,10 +192,12 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
             assert cache.shape == (pc.kt - 1, H, W, Cx) and cache.dtype == torch.bfloat16, (cache.shape, x.shape)
     d = L.ConvDesc()
     d.nb, d.cache_stride = nb, cache_stride
-    if cache is None and pc.w_first is not None:
+    if cache is None and pc.w_first is not None and weight_sums:
         d.w_first = pc.w_first.data_ptr()
-    if up == 1 and pc.w_sub is not None:
+    if up == 1 and pc.w_sub is not None and weight_sums:
         d.w_sub = pc.w_sub.data_ptr()
+    if tdup and weight_sums and pc.w_pair is not None and pc.kt == 3 and not (tdup == 2 and cache is not None):
+        d.tdup, d.w_pair = tdup, pc.w_pair.data_ptr()
     d.x, d.cache, d.w = x.data_ptr(), (cache.data_ptr() if cache is not None else None), pc.w.data_ptr()
     d.bias = pc.bias.data_ptr() if pc.bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None
@@ -196,7 +236,9 @@ def conv(x: torch.Tensor, pc: PackedConv, *, cache: torch.Tensor | None = None, 
         # input is a duplicate (w_first: 2 + 1 of the first two frames' 3 + 3 temporal taps per instance; w_sub: 5 of 9 spatial taps)
         real = flops
         if name == "conv3x3_halo4x_kernel":
-            if d.w_first and pc.kt == 3 and up == 0:
+            if d.tdup and pc.kt == 3 and up == 0:
+                real = flops * sum(temporal_groups(tl, d.tdup, cache is not None) for tl in range(t_out)) / (3.0 * t_out)
+            elif d.w_first and pc.kt == 3 and up == 0:
                 real = flops * (1.0 - (2.0 + (1.0 if t_out > 1 else 0.0)) / (3.0 * t_out))
             elif d.w_sub and up == 1 and H >= 16 and W >= 32:
                 real = flops * 4.0 / 9.0

@@ -12,6 +12,7 @@ operators of libdove_hip.so (dove_amd.ops).  B > 1 is looped (the reference alwa
 from __future__ import annotations
 
 import math
+import re
 
 import torch
 
@@ -103,6 +104,9 @@ class AutoencoderKLCogVideoX:
         # per-kernel durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
         self.n_streams = 1
         self._streams = None
+        # False: no conv is handed a pack-time weight sum (first-frame temporal sums, sub-pixel upsample sums, frame-pair sums): every launch
+        # computes the reference's per-tap arithmetic - for validating a checkpoint without the one extra bf16 rounding of the summed weights
+        self.weight_sums = True
         # enable_tiling(): run all tiles of one shape as one batch (False: one tile at a time, the round-3 loop - kept for the A/B)
         self.tile_batching = True
         self.tile_streams = 2
@@ -117,7 +121,11 @@ class AutoencoderKLCogVideoX:
         for k in sd:
             if k.endswith(".conv.weight") and ".conv_y." not in k and ".conv_b." not in k:
                 n = k[: -len(".conv.weight")]
-                self.pc[n] = ops.pack_conv(sd[k], sd[n + ".conv.bias"], dev)
+                # sub-pixel sums only where an upsample-fused launch reads them; pair sums for the first causal conv behind a TIME-doubling
+                # upsampler (decoder up-block i > 0 whose predecessor compresses time: its input frames are bit-identical pairs)
+                m = re.fullmatch(r"decoder\.up_blocks\.(\d+)\.resnets\.0\.conv1", n)
+                self.pc[n] = ops.pack_conv(sd[k], sd[n + ".conv.bias"], dev, sub=".upsamplers." in n,
+                                           pair=bool(m) and 0 < int(m.group(1)) <= self.n_tdown)
             elif k.endswith(".conv_shortcut.weight"):
                 n = k[: -len(".weight")]
                 self.pc[n] = ops.pack_conv(sd[k], sd[n + ".bias"], dev)
@@ -169,6 +177,7 @@ class AutoencoderKLCogVideoX:
     def _cconv(self, x, name, cache, **kw):
         """CogVideoXCausalConv3d with conv_cache: the front halo is the last kt-1 input frames of the previous batch."""
         pc = self.pc[name]
+        kw["weight_sums"] = self.weight_sums
         if pc.kt == 1:
             return ops.conv(x, pc, nb=self._nb, **kw)
         k = pc.kt - 1
@@ -231,9 +240,11 @@ class AutoencoderKLCogVideoX:
         return ops.groupnorm_apply(x, stats, g, b, silu=True, yb=yb, sshift=ratio.bit_length() - 1,
                                    tmap=spatial_norm_tmap(x.shape[0] // nb, zq.shape[0] // nb), nb=nb)
 
-    def _resnet(self, x, name, cache, zq=None):
+    def _resnet(self, x, name, cache, zq=None, tdup=0):
+        """``tdup``: x came out of a time-doubling Upsample3D (its frames are bit-identical pairs; 1 / 2 = the upsampler's tmode) - the
+        per-pixel norm1 keeps the pairs (same statistics, same zq frame for both halves of a pair), conv1 is told (ops.conv tdup)."""
         h = self._norm_silu(x, name + ".norm1", zq)
-        h = self._cconv(h, name + ".conv1", cache, gn_eps=self.eps)         # feeds norm2
+        h = self._cconv(h, name + ".conv1", cache, gn_eps=self.eps, tdup=tdup)   # feeds norm2
         h = self._norm_silu(h, name + ".norm2", zq)
         if name + ".conv_shortcut" in self.pc:
             x = ops.conv(x, self.pc[name + ".conv_shortcut"])   # pointwise: the same call for one tile or a batch of tiles
@@ -254,7 +265,8 @@ class AutoencoderKLCogVideoX:
             tmode, t_out = (2, 2 * T - 1) if T % 2 == 1 else (1, 2 * T)
         else:
             tmode, t_out = 0, T
-        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps, nb=self._nb)
+        return ops.conv(x, self.pc[name], up=1, tmode=tmode, t_out=t_out, pad=(1, 1), gn_eps=self.eps, nb=self._nb,
+                        weight_sums=self.weight_sums), tmode
 
     def _encoder(self, x, cache, split_in=False):
         """``split_in``: x is the im2col'ed input of ``ops.cl_im2col3x3_from_ncthw`` (untiled encode: a spatial tile must see zero
@@ -278,11 +290,12 @@ class AutoencoderKLCogVideoX:
         for j in range(2):
             h = self._resnet(h, f"decoder.mid_block.resnets.{j}", cache, zq=z)
         nb = len(self.boc)
+        tdup = 0
         for i in range(nb):
             for j in range(self.layers + 1):
-                h = self._resnet(h, f"decoder.up_blocks.{i}.resnets.{j}", cache, zq=z)
+                h = self._resnet(h, f"decoder.up_blocks.{i}.resnets.{j}", cache, zq=z, tdup=tdup if j == 0 else 0)
             if i < nb - 1:
-                h = self._upsample(h, f"decoder.up_blocks.{i}.upsamplers.0", i < self.n_tdown)
+                h, tdup = self._upsample(h, f"decoder.up_blocks.{i}.upsamplers.0", i < self.n_tdown)
         h = self._norm_silu(h, "decoder.norm_out", zq=z)
         if split_out and self._conv_out_split:
             return self._cconv(h, "decoder.conv_out.taps", cache, out_f32=True)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 12
+#define DOVE_ABI_VERSION 13
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -96,6 +96,21 @@ typedef struct dove_conv_desc {
    * (integer division), formed in fp32 and rounded to bf16 ONCE at pack time - 4 / 9 of the MACs of Upsample3D's conv.  Used when the low-res grid
    * is at least 16 x 32; NULL = the direct form (upsample folded into the addressing, all 9 taps). */
   const void* w_sub;
+  /* optional (ABI 13), kt == 3 only: the caller DECLARES that the input frames of every instance come in bit-identical pairs - the frames
+   * CogVideoXUpsample3D's time doubling produces (F.interpolate(scale_factor=2) along t, the first frame kept single when the frame-batch has an
+   * odd length; decode_latents, /root/reference/inference_script.py:500), carried unchanged through the per-pixel SpatialNorm + SiLU to the
+   * first causal conv of the next up-block.
+   *   tdup == 1: pairs (0,1), (2,3), ... ; a conv cache, if any, holds an equal pair too (it is the end of the previous batch's input)
+   *   tdup == 2: frame 0 single, pairs (1,2), (3,4), ... ; cache must be NULL (the head of a clip)
+   * Two of the three causal taps of every output frame then read the same bits: the launch runs TWO temporal groups per frame instead of
+   * three - (w0 + w1) x[t-1] + w2 x[t]  or  w0 x[t-2] + (w1 + w2) x[t]  by frame parity (frames whose three taps all read one frame: one
+   * group on w_first's w0 + w1 + w2) - two thirds of the MACs.  w_pair = [2][kh*kw][cout_pad][cin]: the sums w[0] + w[1] and w[1] + w[2]
+   * (tap blocks of `w`), formed in fp32 and rounded to bf16 ONCE at pack time, like w_first (which a cache-less launch needs as well).
+   * Used by conv3x3_halo4x_kernel; every other kernel ignores the declaration and computes the three taps (the same function of equal frames up
+   * to the rounding of the summed weights).  0 / NULL: no declaration. */
+  const void* w_pair;
+  int tdup;
+  int reserved2; /* 0 */
 } dove_conv_desc;
 int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
 /* name of the kernel this call dispatches to (one of igemm_kernel, igemm_fast_kernel, conv3x3_halo4x_kernel, gemm8p_kernel,
@@ -349,12 +364,17 @@ void dove_destroy(dove_ctx* ctx);
  *   attn1.to_out.0, ff.net.0.proj and ff.net.2 of every block in MXFP8.  Choose BEFORE dove_finalize_weights: the weights are
  *   quantised there and their bf16 copies dropped.
  * DOVE_OPT_DIT_ATTN_MXFP8 (0 / 1; same variant): attention on dove_qkv_post_mxfp8 / dove_attention_fwd_mxfp8; any time.
+ * DOVE_OPT_WEIGHT_SUMS: see below.
  * Stage results with an option set are bit-identical to the Python facade with the same switch (tests/test_graph_gpu.py). */
 #define DOVE_OPT_VAE_TILING 1
 #define DOVE_OPT_VAE_SAMPLE_HEIGHT 2
 #define DOVE_OPT_VAE_SAMPLE_WIDTH 3
 #define DOVE_OPT_DIT_LINEAR_MXFP8 4
 #define DOVE_OPT_DIT_ATTN_MXFP8 5
+/* DOVE_OPT_WEIGHT_SUMS (0 / 1, default 1; any time): 0 = the VAE never hands the pack-time weight sums (dove_conv_desc.w_first / w_sub /
+ * w_pair) to its convolutions - every launch computes the reference's per-tap arithmetic (+7.6 % conv MACs), for a caller who wants a
+ * checkpoint validated without the one extra bf16 rounding of the summed weights.  The Python facade's switch: pipe.vae.weight_sums. */
+#define DOVE_OPT_WEIGHT_SUMS 6
 int dove_set_option(dove_ctx* ctx, int option, long long value);
 long long dove_get_option(dove_ctx* ctx, int option); /* -1: unknown option */
 int dove_set_weight(dove_ctx* ctx, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype);

@@ -64,7 +64,20 @@ def _frame_index(t, tmode):
 
 
 def conv(x, pc, *, cache=None, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, resid=None,
-         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None, out_f32=False, nb=1):
+         gate=None, gate_split=0, act=0, ldo=None, out=None, gn_eps=None, out_f32=False, nb=1, tdup=0, weight_sums=True):
+    if tdup:
+        # dove_conv_desc.tdup is a DECLARATION by the caller (dove_amd/vae.py: the conv behind a time-doubling Upsample3D): the emulation
+        # computes the plain per-tap conv - the same function of such frames - and checks that the declaration is true, bit for bit
+        assert pc.kt == 3 and not (tdup == 2 and cache is not None)
+        xs = x.view(nb, x.shape[0] // nb, *x.shape[1:])
+        Ti = xs.shape[1]
+        pairs = [(i, i + 1) for i in range(0, Ti - 1, 2)] if tdup == 1 else [(i, i + 1) for i in range(1, Ti - 1, 2)]
+        assert (Ti % 2 == 0) if tdup == 1 else (Ti % 2 == 1), (tdup, Ti)
+        for a, b in pairs:
+            assert torch.equal(xs[:, a], xs[:, b]), f"tdup={tdup}: frames {a} and {b} of the conv input are not bit-identical"
+        if cache is not None:
+            cc = cache if cache.dim() == 5 else cache[None]
+            assert torch.equal(cc[:, 0], cc[:, 1]), "tdup: the conv cache is not an equal pair"
     if nb > 1:
         # dove_conv_desc.nb: nb independent instances back to back along the frame axis = nb separate calls (that IS the contract)
         assert out is None and gate is None and x.shape[0] % nb == 0

@@ -873,6 +873,69 @@ def test_prodshape_conv3d_128_no_cache_w_first_sampled():
     assert e_sum < 4e-3 and e_dir < 4e-3 and e2_sum < 4e-3 and e2_dir < 4e-3, (e_sum, e_dir, e2_sum, e2_dir)
 
 
+def _time_doubled(src, first_single):
+    """[Ts,H,W,C] -> Upsample3D's time doubling: every frame twice, the first one once when ``first_single``."""
+    Ts = src.shape[0]
+    idx = ([0] + [1 + i // 2 for i in range(2 * (Ts - 1))]) if first_single else [i // 2 for i in range(2 * Ts)]
+    return src[idx].contiguous()
+
+
+@pytest.mark.parametrize("name,cin,cout,Ts,H,W,tdup,cached,nb,resid", [
+    ("head_odd", 128, 128, 3, 20, 40, 2, False, 1, False),          # 1 + 4 frames, no cache: frame 0 on w012, then {01}{2} / {0}{12} by parity
+    ("tail_even_cache", 128, 256, 2, 17, 33, 1, True, 1, True),      # 4 frames behind an equal-pair cache, ragged tiles, residual epilogue
+    ("even_no_cache", 64, 128, 2, 16, 32, 1, False, 1, False),       # an even first batch: frames 0 / 1 on w012
+    ("one_pair_cache", 256, 128, 1, 16, 64, 1, True, 1, False),      # a single doubled frame (a 1-frame piece of a split batch)
+    ("tiles_nb3", 128, 128, 2, 16, 32, 1, True, 3, False),           # three instances (tiled VAE batches), each with its own cache
+    ("head_odd_nb2", 128, 128, 2, 18, 34, 2, False, 2, False),
+])
+def test_conv_frame_pairs_tdup(name, cin, cout, Ts, H, W, tdup, cached, nb, resid):
+    """dove_conv_desc.tdup / w_pair: the first causal conv behind CogVideoXUpsample3D's time doubling (decode_latents, /root/reference/
+    inference_script.py:500) told that its input frames come in bit-identical pairs runs two temporal groups per frame - against plain
+    F.conv3d on the same (doubled) input, against the same launch WITHOUT the declaration (per-tap arithmetic), and the fused GroupNorm
+    statistics against a pass over the stored output."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(171)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * (cin * 27) ** -0.5).to(BF).float()
+    b = torch.randn(cout, generator=g) * 0.1
+    pc = ops.pack_conv(w, b, "cuda", pair=True)
+    xs = [_time_doubled(rnd(Ts, H, W, cin, seed=180 + i), tdup == 2) for i in range(nb)]
+    T = xs[0].shape[0]
+    caches = [_time_doubled(rnd(1, H, W, cin, seed=190 + i), False) for i in range(nb)] if cached else None
+    x = torch.cat(xs).cuda()
+    cache = None
+    if cached:
+        cache = torch.stack(caches).cuda() if nb > 1 else caches[0].cuda()
+    r = rnd(nb * T, H, W, cout, seed=175).cuda() if resid else None
+    y = ops.conv(x, pc, cache=cache, resid=r, nb=nb, tdup=tdup, gn_eps=1e-6)
+    y_plain = ops.conv(x, pc, cache=cache, resid=r, nb=nb, weight_sums=False)
+    torch.cuda.synchronize()
+    assert ops.conv_kernel_name((T, H, W, cin), pc, resid=resid) == "conv3x3_halo4x_kernel"
+    for i in range(nb):
+        front = caches[i] if cached else torch.cat([xs[i][:1]] * 2)
+        xin = torch.cat([front, xs[i]]).float().permute(3, 0, 1, 2)[None]                      # [1, C, T + 2, H, W]
+        ref = F.conv3d(F.pad(xin, (1, 1, 1, 1)), w, b)[0].permute(1, 2, 3, 0)                    # [T, H, W, cout]
+        if resid:
+            ref = ref + r[i * T:(i + 1) * T].float().cpu()
+        close(f"tdup_{name} instance {i}", y[i * T:(i + 1) * T], ref.to(BF))
+        close(f"tdup_{name} instance {i} (no declaration)", y_plain[i * T:(i + 1) * T], ref.to(BF))
+    st = y.gn_stats[0] if getattr(y, "gn_stats", None) is not None else None
+    if st is not None:                                            # epilogue statistics == a pass over what was stored
+        want = ops.groupnorm_stats(y, 1e-6, nb)
+        torch.cuda.synchronize()
+        assert float((st - want).abs().max()) < 1e-4 * float(want.abs().max().clamp_min(1.0)), (st - want).abs().max()
+    # the declaration is refused where it cannot hold: frame 0 single (2) behind a cache; a declaration without the pair sums
+    d = ops.L.ConvDesc()
+    d.x = d.w = d.out = x.data_ptr()
+    d.t_in = d.t_out = T
+    d.h_in = d.h_out = H
+    d.w_in = d.w_out = W
+    d.cin, d.cout_pad, d.cout_store, d.kt, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.ldo = cin, cout, cout, 3, 3, 3, 1, 1, 1, cout
+    d.tdup = 1
+    assert ops.L.load().dove_conv_igemm_bf16(d, None) != 0 and b"w_pair" in ops.L.load().dove_last_error()
+    d.w_pair, d.tdup, d.cache = pc.w_pair.data_ptr(), 2, x.data_ptr()
+    assert ops.L.load().dove_conv_igemm_bf16(d, None) != 0 and b"tdup == 2" in ops.L.load().dove_last_error()
+
+
 @pytest.mark.parametrize("tmode,T_in,t_out", [(0, 8, 8), (1, 4, 8)])
 def test_prodshape_upsample_conv_256_sampled(tmode, T_in, t_out):
     """Upsample-fused 256 -> 256 3x3 conv, 360 x 640 -> 720 x 1280 (CogVideoXUpsample3D of decoder up-block 2: the nearest x2
