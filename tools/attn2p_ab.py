@@ -1,0 +1,128 @@
+"""The software-pipelined attention experiment (tools/exp/attn2p_exp.hip: one wave per SIMD, two query blocks per wave, the softmax VALU
+issued behind the MFMAs of the neighbouring tiles, no shift under a score bound <= 40) against the product kernel, within one process:
+  1. correctness on small and ragged sequence lengths (1, 2, 3, 4, 5 KV tiles; ragged last tile; queries not a multiple of 256) against a
+     torch fp32 softmax attention of the same bf16 operands (every row), next to the product kernel's own error;
+  2. the same on sampled rows at the headline size N = 18 226, 48 heads, and the difference between the two kernels;
+  3. back-to-back timings at the headline size on N(0, 1)-like operands and (argument `zeros`) on all-zero operands (the schedule ceiling).
+    python tools/attn2p_ab.py [zeros]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dove_amd import ops  # noqa: E402
+
+so = os.path.join(ROOT, "tools", "exp", "libattn2p_exp.so")
+if not os.path.exists(so):
+    import subprocess
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tools", "exp", "attn2p_exp.hip"), "-o", so])
+lib = C.CDLL(so)
+lib.attn2p.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+dev = torch.device("cuda", 0)
+BF = torch.bfloat16
+idx16 = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=dev)
+
+
+def make(N, heads, qs, ks, seed, zeros=False):
+    npad = (N + 127) // 128 * 128
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(heads, npad, 64, device=dev, generator=g) * qs).to(BF)
+    k = (torch.randn(heads, npad, 64, device=dev, generator=g) * ks).to(BF)
+    v = torch.randn(heads, npad, 64, device=dev, generator=g).to(BF)
+    if zeros:
+        q.zero_(); k.zero_(); v.zero_()
+    q[:, N:] = 0
+    k[:, N:] = 0
+    v[:, N:] = 0
+    norm2 = torch.stack([(q.float() ** 2).sum(-1).amax(1), (k.float() ** 2).sum(-1).amax(1)], dim=1).contiguous()
+    vt = v.transpose(1, 2).contiguous()
+    perm = (torch.arange(npad, device=dev) // 16 * 16).view(-1, 16)[:, :1] + idx16[None]
+    vt_prod = vt[:, :, perm.reshape(-1)].contiguous()           # dove_qkv_post_bf16 v_order 1
+    return npad, q, k, v, vt_prod, norm2
+
+
+def run_prod(q, k, vt, N, npad, heads, out, norm2):
+    ops.attention(q, k, vt, N, npad, heads, out, norm2=norm2)
+
+
+def run_new(q, k, vt, N, npad, heads, out, norm2):
+    rc = lib.attn2p(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), N, npad, heads, heads * 64, norm2.data_ptr(),
+                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, rc
+
+
+def rel(a, b):
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-20))
+
+
+zeros = len(sys.argv) > 1 and sys.argv[1] == "zeros"
+if not zeros:
+    worst = 0.0
+    for N in (50, 64, 100, 128, 129, 200, 256, 300, 321, 700):
+        heads = 3
+        npad, q, k, v, vt, n2 = make(N, heads, 0.35, 0.35, 100 + N)
+        op = torch.zeros(N, heads * 64, device=dev, dtype=BF)
+        on = torch.full((N, heads * 64), 7.0, device=dev, dtype=BF)
+        run_prod(q, k, vt, N, npad, heads, op, n2)
+        run_new(q, k, vt, N, npad, heads, on, n2)
+        torch.cuda.synchronize()
+        s = torch.einsum("hqd,hkd->hqk", q[:, :N].float(), k[:, :N].float())
+        ref = torch.einsum("hqk,hkd->hqd", torch.softmax(s * 0.6931471805599453, dim=-1), v[:, :N].float()).permute(1, 0, 2).reshape(N, heads * 64)
+        ep, en = rel(op.float(), ref), rel(on.float(), ref)
+        worst = max(worst, en / max(ep, 1e-9))
+        print(f"N = {N:5d} ({(N + 63) // 64} tiles): rms-rel vs fp32 softmax attention: product {ep:.3e}  pipelined {en:.3e}  finite {bool(torch.isfinite(on.float()).all())}", flush=True)
+        assert en < 1.5 * ep + 1e-3, (N, ep, en)
+    # a head above the cutoff is left alone (the running-maximum kernel's): the output buffer keeps its contents there
+    N, heads = 300, 3
+    npad, q, k, v, vt, n2 = make(N, heads, 0.35, 0.35, 7)
+    n2[1, 0] = 1e6
+    on = torch.full((N, heads * 64), 7.0, device=dev, dtype=BF)
+    run_new(q, k, vt, N, npad, heads, on, n2)
+    torch.cuda.synchronize()
+    assert bool((on[:, 64:128] == 7.0).all()) and not bool((on[:, :64] == 7.0).all())
+    print("a head above the cutoff is skipped: ok")
+
+N, heads = 18226, 48
+npad, q, k, v, vt, n2 = make(N, heads, 0.3, 0.3, 11, zeros)
+print(f"N = {N}, heads = {heads}, operands {'ALL ZERO' if zeros else 'N(0,1) x 0.3'}; score bound {float((1.01 * (n2[:, 0] * n2[:, 1]).sqrt()).max()):.1f} (cutoff 40)")
+op = torch.zeros(N, heads * 64, device=dev, dtype=BF)
+on = torch.zeros(N, heads * 64, device=dev, dtype=BF)
+run_prod(q, k, vt, N, npad, heads, op, n2)
+run_new(q, k, vt, N, npad, heads, on, n2)
+torch.cuda.synchronize()
+if not zeros:
+    rows = torch.cat([torch.arange(0, 40, device=dev), torch.arange(N // 2, N // 2 + 24, device=dev), torch.arange(N - 50, N, device=dev)])
+    w = {"product": 0.0, "pipelined": 0.0}
+    for h in (0, heads // 2, heads - 1):
+        s = q[h, rows].float() @ k[h, :N].float().T
+        ref = torch.softmax(s * 0.6931471805599453, dim=-1) @ v[h, :N].float()
+        for name, o in (("product", op), ("pipelined", on)):
+            w[name] = max(w[name], rel(o[rows, h * 64:(h + 1) * 64].float(), ref))
+    d = on.float() - op.float()
+    print(f"sampled rows x 3 heads, rms-rel vs fp32 softmax attention: product {w['product']:.3e}  pipelined {w['pipelined']:.3e}; between the two (whole output) "
+          f"rms-rel {float(d.pow(2).mean().sqrt() / op.float().pow(2).mean().sqrt()):.3e}  max |d| {float(d.abs().max()):.3e}  finite {bool(torch.isfinite(on.float()).all())}", flush=True)
+    assert w["pipelined"] < 1.5 * w["product"] + 1e-3
+
+
+def timeit(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+fl = 4.0 * heads * N * N * 64
+res = {"p": [], "n": []}
+for rnd in range(3):
+    res["p"].append(timeit(lambda: run_prod(q, k, vt, N, npad, heads, op, n2)))
+    res["n"].append(timeit(lambda: run_new(q, k, vt, N, npad, heads, on, n2)))
+tp, tn = sorted(res["p"])[1], sorted(res["n"])[1]
+print(f"attention N = {N}, {heads} heads: product {tp:7.3f} ms ({fl / tp / 1e9:6.1f} TFLOP/s)   pipelined {tn:7.3f} ms ({fl / tn / 1e9:6.1f} TFLOP/s)   x{tn / tp:.3f}", flush=True)
