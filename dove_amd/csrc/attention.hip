@@ -36,6 +36,9 @@
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
+                               const float* norm2, void* stream);   // attention_pipe.hip
+
 __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
   u32x4 v = {a, b, c, d};
@@ -62,7 +65,7 @@ template <int NW, bool XCD = true, bool FIXED = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                           long long N, long long Npad, long long ldo, int qblocks,
-                                                          const float* __restrict__ bound = nullptr) {
+                                                          const float* __restrict__ bound = nullptr, int skip_bounded = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = 16384, VOFF = 8192;
   constexpr float THR = 6.0f;                    // rescale when a score exceeds the running max by 2^6
@@ -108,6 +111,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     }
   }
   fixed = __builtin_amdgcn_readfirstlane(fixed);
+  // skip_bounded: the bounded heads of this launch run on attn_pipe_kernel (attention_pipe.hip); this kernel keeps the others
+  if (fixed && skip_bounded) return;
 
   const int ntiles = (int)((N + 63) / 64);
   const int srow = tid >> 3;
@@ -289,8 +294,22 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
 #ifdef DOVE_TIMING_BUILD
   { const char* e = getenv("DOVE_ATTN_BOUND"); if (e && atoi(e) == 0) norm2 = nullptr; }   // tools/e2e_env_ab.py: running maximum vs bound
 #endif
+  // With a score bound per head (norm2) the heads it bounds by 40 run on the software-pipelined kernel (attention_pipe.hip: one wave per SIMD,
+  // no shift needed), the others - and every head when no bound is given - here on the running maximum.  Both kernels decide per head from
+  // the same two numbers, so each output row is written by exactly one of them.
+  int skip_bounded = 0;
+  if (norm2) {
+    skip_bounded = 1;
+#ifdef DOVE_TIMING_BUILD
+    { const char* e = getenv("DOVE_ATTN_PIPE"); if (e && atoi(e) == 0) skip_bounded = 0; }   // tools/e2e_env_ab.py: the bounded heads on this kernel's constant-shift loop
+#endif
+    if (skip_bounded) {
+      const int rc = dove_attention_pipe_launch(Qh, Kh, Vt, O, N, Npad, heads, ldo, norm2, stream);
+      if (rc) return rc;
+    }
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), dim3((unsigned)(qblocks * heads)), dim3(NW * 64), LDS, (hipStream_t)stream, (const bf16_t*)Qh,
-                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
+                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2, skip_bounded);
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
 }

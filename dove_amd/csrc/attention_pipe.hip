@@ -1,9 +1,10 @@
-// EXPERIMENT (tools/attn2p_ab.py; never loaded by dove_amd): flash-attention forward of dove_attention_fwd_bf16, BOUNDED-SCORE path only, in the
-// one-wave-per-SIMD software-pipelined structure the CDNA4 guide describes (cdna_hip_programming.md "4-wave, one-wave-per-SIMD, persistent
-// structure"; MI355X_MICROARCH "single-issue instructions HIDDEN per v_mfma_f32_32x32x16_bf16 gap: <= 5"): on gfx950 the VALU work of one wave
-// hides under the MFMAs of the SAME wave's stream (about five single-issue instructions per 32-cycle MFMA) and not under another wave's - the
-// product kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) therefore adds its 16 MFMAs and its ~200 ns of softmax per 32 x 64
-// wave-tile (510 ns measured), and it reads 16 KB of LDS per 16 MFMAs.  Here:
+// Flash-attention forward, BOUNDED-SCORE path of dove_attention_fwd_bf16 (every head of the DiT whose LayerNorm'd q / k give a score bound
+// 1.01 sqrt(max |q|^2 max |k|^2) <= 40 - all of them with unit gains; replaces F.scaled_dot_product_attention inside diffusers'
+// CogVideoXAttnProcessor2_0, /root/reference/inference_script.py:483-489) in the one-wave-per-SIMD software-pipelined structure of the CDNA4 guide
+// (cdna_hip_programming.md "4-wave, one-wave-per-SIMD, persistent structure"; MI355X_MICROARCH "single-issue instructions HIDDEN per
+// v_mfma_f32_32x32x16_bf16 gap: <= 5"): on gfx950 the VALU work of one wave hides under the MFMAs of the SAME wave's stream and not under
+// another wave's (tools/coissue.py) - attn_fwd_kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) adds its 16 MFMAs and its
+// ~200 ns of softmax per 32 x 64 wave-tile and reads 16 KB of LDS per 16 MFMAs.  Here:
 //   * ONE wave per SIMD (256 threads, one workgroup per CU); a wave owns TWO query blocks of 32 (A, B): every K / V^T fragment read from LDS
 //     feeds two MFMAs (half the LDS traffic per MFMA);
 //   * software pipeline over the KV tiles inside the wave: a step issues the 16 QK^T MFMAs of tile j + 1 and the 16 PV MFMAs of tile j, and
@@ -22,14 +23,18 @@
 //     fragments are read half a step ahead of their MFMAs, four counted lgkmcnt waits per step;
 //   * the tile loop runs to a multiple of four steps: tiles at and past the ragged end are masked to -inf before their exponentials, so a
 //     step on a tile that does not exist adds zeros - no tail variants, no copies of O at region boundaries.
-// Operand layout = the product's (dove_qkv_post_bf16 v_order 1).  Heads whose bound is above the cutoff (or NaN) are LEFT UNTOUCHED: the caller
-// runs them on the product's running-maximum kernel.
+// Operand layout: dove_qkv_post_bf16's (v_order 1), as attn_fwd_kernel.  Heads whose bound is above the cutoff (or NaN) are LEFT UNTOUCHED:
+// dove_attention_fwd_bf16 runs them on attn_fwd_kernel's running maximum.
+// Measured (tools/attn2p_ab.py on the experiment twin tools/exp/attn2p_exp.hip, N = 18 226, 48 heads, within one process, profiles/r05_attn2p_*.log):
+// 3.52 ms against attn_fwd_kernel's 3.77-3.96 ms by box (x 0.89-0.93; 1.16 PF), 2.56 vs 2.95 ms on all-zero operands; by parts (ns per step of
+// 32 MFMAs on real operands): MFMAs alone 606, + fragment reads 698, + exponentials and packs 841, + row sums 916.
 #include <stdint.h>
 #include <stdlib.h>
 
 #include <type_traits>
 
-#include "../../dove_amd/csrc/common.h"
+#include "common.h"
+#include "../../include/dove_hip.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -88,16 +93,14 @@ __device__ __forceinline__ uint32_t cvtpk(float lo, float hi) {
   return r;
 }
 
-namespace a2p {
+namespace attn_pipe {
 constexpr int SLOT = 8192, VBASE = 4 * SLOT, LDS = 8 * SLOT;    // K slots 0-3 at 0 .. 24 KB, V^T slots 0-3 at 32 .. 56 KB
 }
 
-// VAR (timing experiments; 0 = the kernel): bit 1: no row sums; bit 3: no softmax VALU at all; bit 6: no LDS fragment reads; bit 7: no barrier
-template <int VAR>
-__global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vt,
+__global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long long N, long long Npad, long long ldo, int qblocks,
                                                         const float* __restrict__ bound) {
-  using namespace a2p;
+  using namespace attn_pipe;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,10 +189,9 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
   auto chunk_q = [&](f32x16 (&s)[2][2], auto x_, auto c_, auto q_) {
     constexpr int x = decltype(x_)::value, c = decltype(c_)::value, quarter = decltype(q_)::value;
     constexpr int kb = c >> 1, b = 8 * (c & 1);
-    if constexpr (VAR & 8) { pf[x][c] = __builtin_bit_cast(bf16x8, f32x4{s[x][kb][b], s[x][kb][b + 2], s[x][kb][b + 4], s[x][kb][b + 6]}); return; }
     auto E = [&](int i) { float v = s[x][kb][b + i]; exp2_inplace(v); s[x][kb][b + i] = v; };
     auto C = [&](int i) { pk[i] = cvtpk(s[x][kb][b + 2 * i], s[x][kb][b + 2 * i + 1]); };
-    auto A = [&](int i) { if constexpr (!(VAR & 2)) add1(ls[x][i], s[x][kb][b + i]); };
+    auto A = [&](int i) { add1(ls[x][i], s[x][kb][b + i]); };
     // (packs and adds at least a quarter behind the exponentials they read: closer, hipcc pads every pack with an s_nop for the trans-use hazard)
     if constexpr (quarter == 0) { E(0); E(1); E(2); E(3); E(4); }
     if constexpr (quarter == 1) { E(5); E(6); E(7); A(0); A(1); }
@@ -212,11 +214,11 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
     constexpr int P = decltype(pc)::value;
     constexpr bool kMask = decltype(maskc)::value;             // the tail trips: tile j + 1 may be ragged or past the end - mask it (no branch inside a step)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the previous step's four loads: K tile j + 2 and V^T tile j have landed
-    if constexpr (!(VAR & 128)) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     FENCE();
     static_for<32>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
-      if constexpr ((s & 7) == 0 && !(VAR & 64)) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      if constexpr ((s & 7) == 0) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
       // ---- the MFMA of this slot ----
       if constexpr (s < 16) {
         constexpr int kk = s >> 2, kb = (s >> 1) & 1, x = s & 1;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
         mfma_o<2 * x + d>(vfr[c][d], pf[x][c]);
       }
       // ---- the fragment read of this slot ----
-      if constexpr (!(VAR & 64) && (s & 1) == 0) {
+      if constexpr ((s & 1) == 0) {
         constexpr int i = (s & 15) >> 1;
         if constexpr (s < 16) lds_frag<VBASE + P * SLOT>(vfr[i >> 1][i & 1], koff[i & 1][i >> 1]);
         else lds_frag<((P + 2) & 3) * SLOT>(kfr[i >> 1][i & 1], koff[i & 1][i >> 1]);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
       if constexpr (s == 11) dma_v(IC<((P + 2) & 3)>{}, j + 2, 0);
       if constexpr (s == 15) dma_v(IC<((P + 2) & 3)>{}, j + 2, 1);
       // ---- keys at / past the end: S(j + 1) is complete (its chains ended at slot 15), its first exponentials come at slot 28 ----
-      if constexpr (s == 21 && kMask && VAR == 0) mask_tail(sn, j + 1);
+      if constexpr (s == 21 && kMask) mask_tail(sn, j + 1);
       // ---- the softmax quarter of this slot ----
       if constexpr (s < 28) chunk_q(sc, IC<(((s >> 2) + 1) & 1)>{}, IC<(((s >> 2) + 1) >> 1)>{}, IC<(s & 3)>{});
       else chunk_q(sn, IC<0>{}, IC<0>{}, IC<(s & 3)>{});
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the last S MFMA -> its registers' next writer / reader: 18 wait states, by hand
   FENCE();
   static_for<8>([&](auto i_) { constexpr int i = decltype(i_)::value; lds_frag<SLOT>(kfr[i >> 1][i & 1], koff[i & 1][i >> 1]); });   // K tile 1: step 0's S half
-  if (ntiles == 1 && VAR == 0) mask_tail(sa, 0);
+  if (ntiles == 1) mask_tail(sa, 0);
   static_for<4>([&](auto q_) { chunk_q(sa, IC<0>{}, IC<0>{}, q_); });
   FENCE();
   // vmcnt bookkeeping: every step waits for "all but the last four" loads and issues four.  Nothing is in flight here, so step 0's wait is
@@ -316,19 +318,16 @@ __global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict
   });
 }
 
-extern "C" void dove_set_error(const char*, ...) {}
-template <int VAR>
-static int launch_var(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo, const float* norm2, void* stream) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)attn2p_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, a2p::LDS); once = true; }
+// Launch for the heads whose score bound (norm2: [heads][2] = max |q|^2, max |k|^2) is at most 40; the other heads' output rows are left
+// untouched (dove_attention_fwd_bf16 runs them on attn_fwd_kernel).  Same operand contract as dove_attention_fwd_bf16.
+int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
+                               const float* norm2, void* stream) {
+  static PerDeviceOnce attr_set;
+  if (auto once_ = attr_set.guard()) (void)hipFuncSetAttribute((const void*)attn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe::LDS);
   const int qblocks = (int)((Npad + 255) / 256);
-  hipLaunchKernelGGL(attn2p_kernel<VAR>, dim3((unsigned)(qblocks * heads)), dim3(256), a2p::LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh,
-                     (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-extern "C" int attn2p(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
-                      const float* norm2, void* stream, int var) {
-#define V(n) case n: return launch_var<n>(Qh, Kh, Vt, O, N, Npad, heads, ldo, norm2, stream);
-  switch (var) { V(0) V(2) V(8) V(64) V(66) V(72) V(128) V(136) V(200) default: return -1; }
-#undef V
+  DOVE_CHECK_ARG((long long)qblocks * heads < (1ll << 31), "attention_fwd: grid too large");
+  hipLaunchKernelGGL(attn_pipe_kernel, dim3((unsigned)(qblocks * heads)), dim3(256), attn_pipe::LDS, (hipStream_t)stream, (const bf16_t*)Qh,
+                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
+  DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16 (pipelined)");
+  return DOVE_OK;
 }

@@ -11,7 +11,7 @@ OBJ=.
 EXTRA=""
 if [ "$MODE" = "timing" ]; then OUT=../libdove_hip_timing.so; OBJ=.timing; EXTRA="-DDOVE_TIMING_BUILD"; mkdir -p $OBJ; fi
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $EXTRA"
-SRCS="capi igemm igemm_legacy norm attention attention_mx elementwise mxfp8 t5 graph"
+SRCS="capi igemm igemm_legacy norm attention attention_pipe attention_mx elementwise mxfp8 t5 graph"
 if [ "$MODE" = "timing" ]; then SRCS="$SRCS gemm4x_timing"; fi
 pids=()
 for f in $SRCS; do

@@ -20,7 +20,7 @@ if not os.path.exists(so):
     import subprocess
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tools", "exp", "attn2p_exp.hip"), "-o", so])
 lib = C.CDLL(so)
-lib.attn2p.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+lib.attn2p.argtypes = [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int]
 dev = torch.device("cuda", 0)
 BF = torch.bfloat16
 idx16 = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15], device=dev)
@@ -48,9 +48,9 @@ def run_prod(q, k, vt, N, npad, heads, out, norm2):
     ops.attention(q, k, vt, N, npad, heads, out, norm2=norm2)
 
 
-def run_new(q, k, vt, N, npad, heads, out, norm2):
+def run_new(q, k, vt, N, npad, heads, out, norm2, var=0):
     rc = lib.attn2p(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), N, npad, heads, heads * 64, norm2.data_ptr(),
-                    torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.current_stream().cuda_stream, var)
     assert rc == 0, rc
 
 
@@ -59,9 +59,9 @@ def rel(a, b):
 
 
 zeros = len(sys.argv) > 1 and sys.argv[1] == "zeros"
-if not zeros:
+if not zeros and not (len(sys.argv) > 1 and sys.argv[1] == "time"):
     worst = 0.0
-    for N in (50, 64, 100, 128, 129, 200, 256, 300, 321, 700):
+    for N in (50, 64, 100, 128, 129, 192, 200, 256, 300, 320, 321, 700):
         heads = 3
         npad, q, k, v, vt, n2 = make(N, heads, 0.35, 0.35, 100 + N)
         op = torch.zeros(N, heads * 64, device=dev, dtype=BF)
@@ -74,7 +74,12 @@ if not zeros:
         ep, en = rel(op.float(), ref), rel(on.float(), ref)
         worst = max(worst, en / max(ep, 1e-9))
         print(f"N = {N:5d} ({(N + 63) // 64} tiles): rms-rel vs fp32 softmax attention: product {ep:.3e}  pipelined {en:.3e}  finite {bool(torch.isfinite(on.float()).all())}", flush=True)
-        assert en < 1.5 * ep + 1e-3, (N, ep, en)
+        if not en < 1.5 * ep + 1e-3:
+            blk = [(r0, rel(on[r0:r0 + 32].float(), ref[r0:r0 + 32])) for r0 in range(0, N, 32)]
+            print("   WRONG; per 32-row block:", " ".join(f"{r0}:{e:.1e}" for r0, e in blk), flush=True)
+            for h in range(heads):
+                print(f"   head {h}: {rel(on[:, h * 64:(h + 1) * 64].float(), ref[:, h * 64:(h + 1) * 64]):.2e}", end="")
+            print()
     # a head above the cutoff is left alone (the running-maximum kernel's): the output buffer keeps its contents there
     N, heads = 300, 3
     npad, q, k, v, vt, n2 = make(N, heads, 0.35, 0.35, 7)
@@ -93,7 +98,7 @@ on = torch.zeros(N, heads * 64, device=dev, dtype=BF)
 run_prod(q, k, vt, N, npad, heads, op, n2)
 run_new(q, k, vt, N, npad, heads, on, n2)
 torch.cuda.synchronize()
-if not zeros:
+if not zeros and not (len(sys.argv) > 1 and sys.argv[1] == "time"):
     rows = torch.cat([torch.arange(0, 40, device=dev), torch.arange(N // 2, N // 2 + 24, device=dev), torch.arange(N - 50, N, device=dev)])
     w = {"product": 0.0, "pipelined": 0.0}
     for h in (0, heads // 2, heads - 1):
@@ -104,7 +109,7 @@ if not zeros:
     d = on.float() - op.float()
     print(f"sampled rows x 3 heads, rms-rel vs fp32 softmax attention: product {w['product']:.3e}  pipelined {w['pipelined']:.3e}; between the two (whole output) "
           f"rms-rel {float(d.pow(2).mean().sqrt() / op.float().pow(2).mean().sqrt()):.3e}  max |d| {float(d.abs().max()):.3e}  finite {bool(torch.isfinite(on.float()).all())}", flush=True)
-    assert w["pipelined"] < 1.5 * w["product"] + 1e-3
+    print("headline-size check:", "ok" if w["pipelined"] < 1.5 * w["product"] + 1e-3 else "WRONG")
 
 
 def timeit(fn, iters=5):
@@ -120,9 +125,18 @@ def timeit(fn, iters=5):
 
 
 fl = 4.0 * heads * N * N * 64
-res = {"p": [], "n": []}
+VARS = {0: "the kernel", 2: "no row sums", 8: "no softmax VALU", 64: "no fragment reads (MFMAs + full VALU)", 66: "no fragment reads, no row sums",
+        72: "no VALU, no fragment reads", 128: "no barrier", 136: "no barrier, no VALU", 200: "no barrier / VALU / reads (MFMAs + DMA)"}
+if len(sys.argv) > 2:
+    VARS = {int(x): VARS.get(int(x), "") for x in sys.argv[2].split(",")}
+res = {"p": []}
 for rnd in range(3):
     res["p"].append(timeit(lambda: run_prod(q, k, vt, N, npad, heads, op, n2)))
-    res["n"].append(timeit(lambda: run_new(q, k, vt, N, npad, heads, on, n2)))
-tp, tn = sorted(res["p"])[1], sorted(res["n"])[1]
-print(f"attention N = {N}, {heads} heads: product {tp:7.3f} ms ({fl / tp / 1e9:6.1f} TFLOP/s)   pipelined {tn:7.3f} ms ({fl / tn / 1e9:6.1f} TFLOP/s)   x{tn / tp:.3f}", flush=True)
+    for var in VARS:
+        res.setdefault(var, []).append(timeit(lambda: run_new(q, k, vt, N, npad, heads, on, n2, var)))
+tp = sorted(res["p"])[1]
+print(f"attention N = {N}, {heads} heads: product {tp:7.3f} ms ({fl / tp / 1e9:6.1f} TFLOP/s)")
+steps = 3848.0            # pipeline steps per SIMD at this size (72 query blocks x 48 heads x 4 waves x 285 tiles / 1024 SIMDs)
+for var, name in VARS.items():
+    tn = sorted(res[var])[1]
+    print(f"   pipelined, variant {var:3d} ({name}): {tn:7.3f} ms ({fl / tn / 1e9:6.1f} TFLOP/s)  x{tn / tp:.3f}   {tn * 1e6 / steps:6.0f} ns per step", flush=True)

@@ -1,0 +1,338 @@
+// EXPERIMENT (tools/attn2p_ab.py; never loaded by dove_amd): flash-attention forward of dove_attention_fwd_bf16, BOUNDED-SCORE path only,
+// rebuilt around what tools/coissue.py and tools/ubench.py measured on gfx950: the MFMAs of one wave and the VALU work of ANOTHER wave on the
+// same SIMD serialize, while VALU instructions that follow an MFMA in the SAME wave's stream run under it (8 MFMA + 16 v_exp: 276 ticks where
+// the MFMAs alone take 256).  The product kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) overlaps nothing: 16 MFMAs (290 ns on
+// real operands) + ~200 ns of softmax VALU = the 510 ns per 32 x 64 wave-tile it measures.  Here:
+//   * ONE wave per SIMD (256 threads, one workgroup per CU); a wave owns TWO query blocks of 32 (A, B) - every K / V^T fragment read from LDS
+//     feeds two MFMAs, half the LDS traffic per MFMA;
+//   * software pipeline over the KV tiles inside the wave: a step issues the 16 QK^T MFMAs of tile j+1 and the 16 PV MFMAs of tile j, and
+//     BEHIND EVERY MFMA a fixed handful of the softmax VALU instructions of tile j (8 chunks of {8 v_exp, 4 v_cvt_pk, 4 v_dot2} = one P^T
+//     fragment each; a chunk spans 4 MFMA slots), fenced by sched_barrier so the order survives the compiler;
+//   * no shift at all: with every score of the head bounded by b <= 40 (the caller's norm bound, as in the product) 2^s <= 2^40 and the row
+//     sums stay below 2^55 - far inside fp32 / bf16 range - and the constant 2^-b the product multiplies in cancels in O / l anyway.  The S
+//     chains start from the inline constant 0 (no accumulator zeroing, no C-operand registers);
+//   * row sums by v_dot2_f32_bf16 of the PACKED probabilities with (1, 1): 4 instructions per fragment instead of 8 adds, and the denominator
+//     sums exactly the bf16 values the numerator multiplies;
+//   * 6-stage LDS ring (K tile + V^T tile = 16 KB per stage, LDS-DMA), ONE barrier per step; tile j+2 is visible at the top of step j, so the
+//     fragment reads of a step's first MFMAs are issued in the previous step's tail.
+// Operand layout = the product's (dove_qkv_post_bf16 v_order 1).  Heads whose bound is above the cutoff (or NaN) are LEFT UNTOUCHED by this
+// kernel: the caller runs them on the product's running-maximum kernel.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "../../dove_amd/csrc/common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int V> using IC = std::integral_constant<int, V>;
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(IC<I>{}); static_for<N, I + 1>(f); }
+}
+
+__device__ __forceinline__ bf16x8 frag4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(bf16x8, v);
+}
+// acc + lo(p) + hi(p): the two packed bf16 probabilities of p against (1, 1)
+__device__ __forceinline__ float dot_ones(uint32_t p, float acc) {
+  float d;
+  asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(0x3f803f80u), "v"(acc));
+  return d;
+}
+
+// The MFMAs are inline asm so that the register FILES are ours to choose: S in VGPRs (the exponentials read it; as builtins the allocator put
+// the 128 S registers into AGPRs and moved every value through v_accvgpr_read: 64 extra VALU instructions per step), O and the Q fragments in
+// AGPRs (only MFMAs touch them).  hipcc does not model an asm MFMA's hazards (guide 5.7); the pipeline keeps every consumer far behind its
+// producer (S: >= 12 MFMA slots before the first exponential; P fragments: >= 2 slots before their PV MFMA; chains: 4 accumulators in
+// rotation), the prologue and the epilogue pad by hand.
+__device__ __forceinline__ void mfma_s_first(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_s_first_a(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&a"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mfma_s_a(f32x16& d, const bf16x8& k, const bf16x8& q) {
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ float acc_read(const float& a) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+__device__ __forceinline__ void mfma_o(f32x16& d, const bf16x8& v, const bf16x8& p) {
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(v), "v"(p));
+}
+
+__device__ __forceinline__ void add1(float& acc, float v) { asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(v)); }
+
+namespace a2p {
+constexpr int NSTAGE = 6, STAGE = 16384, VOFF = 8192, LDS = NSTAGE * STAGE;
+}
+
+// VAR (timing experiments; 0 = the kernel as described): bit 0: row sums by 8 v_add per chunk instead of 4 v_dot2; bit 1: no row sums;
+// bit 2: no exponentials (P = S); bit 3: no softmax VALU at all; bit 4: no MFMAs (VALU + reads only); bit 5: S chains accumulate in AGPRs and
+// every score moves to a VGPR by v_accvgpr_read before its exponential; bit 6: no LDS fragment reads inside the steps; bit 7: no barrier
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void attn2p_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vt,
+                                                        bf16_t* __restrict__ O, long long N, long long Npad, long long ldo, int qblocks,
+                                                        const float* __restrict__ bound) {
+  using namespace a2p;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = (int)(t / (unsigned)qblocks), qb = (int)(t - (unsigned)h * (unsigned)qblocks);
+  {
+    const float b = 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);
+    if (!(b <= 40.0f)) return;                                 // (NaN compares false) the running-maximum kernel owns this head
+  }
+  const long long q0 = (long long)qb * 256 + wave * 64;        // block A: q0 .. q0 + 31, block B: q0 + 32 .. q0 + 63
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    long long qrow = q0 + x * 32 + l31;
+    if (qrow >= Npad) qrow = Npad - 1;                         // rows past the padded end are never stored
+    const bf16_t* qp = Qh + ((long long)h * Npad + qrow) * 64 + hi * 8;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[x][kk] = *(const bf16x8*)(qp + kk * 16);
+  }
+
+  const int ntiles = (int)((N + 63) / 64);
+  const int srow = tid >> 3;
+  const int sc_ld = (tid & 7) ^ ((srow >> 1) & 7);
+  const auto srd_k = __builtin_amdgcn_make_buffer_rsrc((void*)(Kh + (long long)h * Npad * 64), (short)0, (int)(Npad * 128), 0x00020000);
+  const auto srd_v = __builtin_amdgcn_make_buffer_rsrc((void*)(Vt + (long long)h * 64 * Npad), (short)0, (int)(Npad * 128), 0x00020000);
+  unsigned vk[2], vv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    vk[j] = (unsigned)(((j * 32 + srow) * 64 + sc_ld * 8) * 2);
+    vv[j] = (unsigned)((((long long)(j * 32 + srow)) * Npad + sc_ld * 8) * 2);
+  }
+  // one of a tile's four LDS-DMA instructions (i = 0, 1: K halves; 2, 3: V^T halves) into ring slot `slot`; a tile past the end reads beyond
+  // the descriptor's range only when its offset does (Npad covers whole tiles up to 128-key granularity; later tiles return zeros)
+  auto stage1 = [&](int slot, int tile, int i) {
+    char* dst = smem + slot * STAGE + (i & 1) * 4096 + wave * 1024;
+    if (i < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_k, (lds_ptr_t)dst, 16, vk[i & 1], tile * (64 * 128), 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(srd_v, (lds_ptr_t)(dst + VOFF), 16, vv[i & 1], tile * (64 * 2), 0, 0);
+  };
+
+  int koff[2][4];                                              // fragment offsets inside a K tile; the V^T tile uses the same pattern at + VOFF
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int row = b * 32 + l31;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) koff[b][c] = row * 128 + (((c * 2 + hi) ^ sw) << 4);
+  }
+
+  f32x16 o[2][2];                                              // [block][d half]
+  f32x16 sa[2][2], sb[2][2];                                   // S^T of two consecutive tiles: [block][key half]; roles swap every step
+  float ls[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // row-sum partials [block][position in a chunk]: every add is a chunk (100+ cycles) behind the one it depends on
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][d][r] = 0.f;
+
+  // keys past N in the last tile: their scores become -inf BEFORE the exponentials (their K rows are zero: 2^0 = 1 would enter the row sums)
+  auto mask_tail = [&](f32x16 (&s)[2][2], int tile) {
+    if constexpr (VAR != 0) return;                              // timing variants do not care
+    const long long kv0 = (long long)tile * 64;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long kv = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (kv >= N) s[x][kb][r] = -1e30f;
+        }
+  };
+
+  bf16x8 pf[2][4];                                             // P^T fragments of the tile being multiplied: [block][16-key slice c]
+  bf16x8 kfr[4][2], vfr[4][2];                                 // fragments in flight: [register set][key half / d half]
+  // softmax chunk (block x, slice c) of the tile held in `s`, cut in four quarters (one per MFMA slot): 8 exps, 4 packs, 4 row-sum dots
+  float ex[8];
+  uint32_t pk[4];
+  float fake[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) fake[i] = (float)(lane + i) * 1e-3f;
+  auto chunk_q = [&](f32x16 (&s)[2][2], auto x_, auto c_, auto q_) {
+    constexpr int x = decltype(x_)::value, c = decltype(c_)::value, quarter = decltype(q_)::value;
+    constexpr int kb = c >> 1, b = 8 * (c & 1);
+    if constexpr (VAR & 8) { pf[x][c] = __builtin_bit_cast(bf16x8, f32x4{s[x][kb][b], s[x][kb][b + 2], s[x][kb][b + 4], s[x][kb][b + 6]}); return; }
+    auto E = [&](int i) {
+      float v = s[x][kb][b + i];
+      if constexpr ((VAR & 32) && !(VAR & 256)) v = acc_read(s[x][kb][b + i]);
+      if constexpr (VAR & 256) v = fake[(b + i) & 7];           // bit 8: the exponentials read registers no MFMA writes
+      if constexpr (VAR & 4) ex[i] = v; else ex[i] = __builtin_amdgcn_exp2f(v);
+    };
+    auto C = [&](int i) { pk[i] = pack_bf2(ex[2 * i], ex[2 * i + 1]); };
+    auto D = [&](int i) {
+      if constexpr (VAR & 2) return;
+      if constexpr (VAR & 512) ls[x][i & 1] = dot_ones(pk[i], ls[x][i & 1]);          // v_dot2_f32_bf16: measured 5.7 ns each - slower than two adds
+      else {        // single v_add_f32 each, as asm: plain C adds are SLP-packed into v_pk_add_f32 by -O3, an anti-lever beside MFMAs (MI355X_MICROARCH)
+        add1(ls[x][2 * i], ex[2 * i]);
+        add1(ls[x][2 * i + 1], ex[2 * i + 1]);
+      }
+    };
+    if constexpr (quarter == 0) { E(0); E(1); E(2); E(3); }
+    if constexpr (quarter == 1) { C(0); E(4); D(0); E(5); }
+    if constexpr (quarter == 2) { C(1); E(6); D(1); E(7); }
+    if constexpr (quarter == 3) { C(2); D(2); C(3); D(3); pf[x][c] = frag4(pk[0], pk[1], pk[2], pk[3]); }
+  };
+
+  // ---- one pipeline step: QK^T of tile j + 1 into `sn`, softmax + PV of tile j from `sc` ----
+  // MFMA slot s (0 .. 31):  0-15  S chains, kk-major: (kk = s >> 2, kb = (s >> 1) & 1, block = s & 1)
+  //                        16-31  O chains, slice-major: (c = (s - 16) >> 2, block = ((s - 16) >> 1) & 1, d half = s & 1)
+  // VALU: chunk n = 2 c + block of tile j runs in slots 4 n - 4 .. 4 n - 1 (chunk 0 in the PREVIOUS step's last four slots, which therefore
+  // carry chunk 0 of tile j + 1 here): PV slice c needs chunks 2 c and 2 c + 1 = done by slot 8 c + 3 < 16 + 4 c.
+  // LDS: every fragment is read four slots before its first use into the register set its (kk / c) parity names.
+  auto step = [&](int j, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], auto lastc, bool mask_next) {
+    constexpr bool kLast = decltype(lastc)::value;             // no tile j + 1: no S chains, no chunk 0 of the next tile
+    const char* kt = smem + ((j + 1) % NSTAGE) * STAGE;
+    const char* vt = smem + (j % NSTAGE) * STAGE + VOFF;
+    const char* kt2 = smem + ((j + 2) % NSTAGE) * STAGE;
+    const int slot4 = (j + 4) % NSTAGE;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the previous step's four loads: tile j + 2 has landed
+    if constexpr (!(VAR & 128)) __builtin_amdgcn_s_barrier();
+    FENCE();
+    static_for<32>([&](auto s_) {
+      constexpr int s = decltype(s_)::value;
+      // ---- the MFMA of this slot ----
+      if constexpr (s < 16) {
+        if constexpr (!kLast) {
+          constexpr int kk = s >> 2, kb = (s >> 1) & 1, x = s & 1;
+          if constexpr (VAR & 16) {}
+          else if constexpr (VAR & 32) { if constexpr (kk == 0) mfma_s_first_a(sn[x][kb], kfr[0][kb], qf[x][0]); else mfma_s_a(sn[x][kb], kfr[kk][kb], qf[x][kk]); }
+          else if constexpr (kk == 0) mfma_s_first(sn[x][kb], kfr[0][kb], qf[x][0]);
+          else mfma_s(sn[x][kb], kfr[kk][kb], qf[x][kk]);
+        }
+      } else {
+        constexpr int c = (s - 16) >> 2, x = ((s - 16) >> 1) & 1, d = s & 1;
+        if constexpr (!(VAR & 16)) mfma_o(o[x][d], vfr[c][d], pf[x][c]);
+        else asm volatile("" :: "v"(vfr[c][d]), "v"(pf[x][c]));
+      }
+      // ---- one fragment read every other slot, a whole half-step ahead of its user: the 8 V^T fragments of THIS step's PV half during the S
+      // half (slot 2 i: fragment (d = i & 1, c = i >> 1)), the 8 K fragments of the NEXT step's S half during the PV half (slot 16 + 2 i:
+      // fragment (kb = i & 1, kk = i >> 1) of tile j + 2, visible since this step's barrier) ----
+      if constexpr (!(VAR & 64) && s < 16 && (s & 1) == 0) vfr[s >> 2][(s >> 1) & 1] = *(const bf16x8*)(vt + koff[(s >> 1) & 1][s >> 2]);
+      if constexpr (!(VAR & 64) && !kLast && s >= 16 && (s & 1) == 0) kfr[(s - 16) >> 2][((s - 16) >> 1) & 1] = *(const bf16x8*)(kt2 + koff[((s - 16) >> 1) & 1][(s - 16) >> 2]);
+      // ---- this step's LDS-DMAs: tile j + 4, one instruction behind each of the slots 2, 6, 10, 14 ----
+      if constexpr ((s & 3) == 2 && s < 16) stage1(slot4, j + 4, s >> 2);
+      // ---- keys past N of a ragged last tile: S(j + 1) is complete (its chains ended at slot 15), its first exponentials come at slot 28 ----
+      if constexpr (!kLast && s == 21) { if (mask_next) mask_tail(sn, j + 1); }
+      // ---- the softmax quarter of this slot ----
+      if constexpr (s < 28) chunk_q(sc, IC<(((s >> 2) + 1) & 1)>{}, IC<(((s >> 2) + 1) >> 1)>{}, IC<(s & 3)>{});
+      else if constexpr (!kLast) chunk_q(sn, IC<0>{}, IC<0>{}, IC<(s & 3)>{});
+      FENCE();
+    });
+    // hipcc does not know that O's registers are MFMA destinations: where it copies them (v_accvgpr_read at a region boundary: found behind the
+    // loop for even tile counts) it pads nothing, and the last PV MFMAs' results were read 16 passes too early.  The hand-made pad, every step:
+    FENCE();
+  };
+  auto pad = [&]() {
+    if constexpr (!(VAR & 1024)) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+    FENCE();
+  };
+
+  // ---- prologue: tiles 0 .. 3 in flight, S(0), chunk 0 of tile 0, the first fragments ----
+#pragma unroll
+  for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage1(tl, tl, i);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // tiles 0 and 1
+  __builtin_amdgcn_s_barrier();
+  const bool ragged = (N & 63) != 0;
+  {
+    const char* kt = smem;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8 kf = *(const bf16x8*)(kt + koff[kb][kk]);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          if constexpr (VAR & 32) { if (kk == 0) mfma_s_first_a(sa[x][kb], kf, qf[x][kk]); else mfma_s_a(sa[x][kb], kf, qf[x][kk]); }
+          else if (kk == 0) mfma_s_first(sa[x][kb], kf, qf[x][kk]);
+          else mfma_s(sa[x][kb], kf, qf[x][kk]);
+        }
+      }
+    FENCE();
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");     // 16-pass MFMA result -> VALU read: 18 wait states, by hand
+    FENCE();
+    if (ragged && ntiles == 1) mask_tail(sa, 0);
+    static_for<4>([&](auto q_) { chunk_q(sa, IC<0>{}, IC<0>{}, q_); });
+    const char* k1 = smem + STAGE;                             // the K fragments of tile 1 (landed: the wait above) for step 0's S half
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { kfr[kk][0] = *(const bf16x8*)(k1 + koff[0][kk]); kfr[kk][1] = *(const bf16x8*)(k1 + koff[1][kk]); }
+  }
+  // vmcnt bookkeeping: a step waits for "all but the last four" loads.  Tiles 2 and 3 (eight loads) are in flight here, so step 0's wait
+  // covers tile 2 (= j + 2) and every later step's the tile issued two steps before it.
+  // ---- the tile loop, two steps per trip (the S buffers swap roles); S(j) is in `sa` at every even j ----
+  int j = 0;
+  for (; j + 2 < ntiles; j += 2) {
+    step(j, sa, sb, std::false_type{}, false);
+    step(j + 1, sb, sa, std::false_type{}, ragged && j + 2 == ntiles - 1);
+    if constexpr (VAR & 2048) pad();                           // (2048: the pad in every trip, to price it)
+  }
+  pad();                                                       // region boundaries: where hipcc may copy O (see `pad`)
+  if (j + 1 < ntiles) {                                        // two tiles left
+    step(j, sa, sb, std::false_type{}, ragged);
+    pad();
+    step(j + 1, sb, sa, std::true_type{}, false);
+  } else {                                                     // one tile left
+    step(j, sa, sb, std::true_type{}, false);
+  }
+
+  FENCE();
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");       // the last PV MFMAs -> v_accvgpr_read of O
+  FENCE();
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    float l = ((ls[x][0] + ls[x][1]) + (ls[x][2] + ls[x][3])) + ((ls[x][4] + ls[x][5]) + (ls[x][6] + ls[x][7]));
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const long long q = q0 + x * 32 + l31;
+    if (q < N) {
+      bf16_t* op = O + q * ldo + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * hi;
+          uint2 w;
+          w.x = pack_bf2(o[x][db][g * 4 + 0] * inv, o[x][db][g * 4 + 1] * inv);
+          w.y = pack_bf2(o[x][db][g * 4 + 2] * inv, o[x][db][g * 4 + 3] * inv);
+          *(uint2*)(op + d) = w;
+        }
+    }
+  }
+}
+
+extern "C" void dove_set_error(const char*, ...) {}
+template <int VAR>
+static int launch_var(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo, const float* norm2, void* stream) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)attn2p_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, a2p::LDS); once = true; }
+  const int qblocks = (int)((Npad + 255) / 256);
+  hipLaunchKernelGGL(attn2p_kernel<VAR>, dim3((unsigned)(qblocks * heads)), dim3(256), a2p::LDS, (hipStream_t)stream, (const bf16_t*)Qh, (const bf16_t*)Kh,
+                     (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+extern "C" int attn2p(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
+                      const float* norm2, void* stream, int var) {
+#define V(n) case n: return launch_var<n>(Qh, Kh, Vt, O, N, Npad, heads, ldo, norm2, stream);
+  switch (var) { V(0) V(1) V(2) V(4) V(6) V(8) V(16) V(32) V(24) V(72) V(88) V(128) V(136) V(200) V(64) V(320) V(256) V(288) V(66) V(258) V(512) V(1024) V(1026) V(1088) V(2048) default: return -1; }
+#undef V
+}
