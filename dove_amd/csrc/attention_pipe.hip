@@ -57,28 +57,12 @@ __device__ __forceinline__ void mfma_s_first(f32x16& d, const bf16x8& k, const b
 __device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& k, const bf16x8& q) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k), "a"(q));
 }
-// O lives in FIXED accumulator registers a[0:63] that only these asm statements name (tuple T = 2 block + d half: a[16 T : 16 T + 15]): as a
-// C++ value with "+a" constraints hipcc carried one tuple through VGPRs around the tile loop (32 v_accvgpr moves per trip) and copied all four
-// between the loops.  The clobber lists keep the allocator off these registers wherever the statements are.
-template <int T>
-__device__ __forceinline__ void mfma_o(const bf16x8& v, const bf16x8& p) {
-  if constexpr (T == 0) asm volatile("v_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" ::"a"(v), "v"(p) : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-  if constexpr (T == 1) asm volatile("v_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" ::"a"(v), "v"(p) : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-  if constexpr (T == 2) asm volatile("v_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" ::"a"(v), "v"(p) : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-  if constexpr (T == 3) asm volatile("v_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" ::"a"(v), "v"(p) : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
-}
-template <int R>
-__device__ __forceinline__ float o_read() {                    // a<R> -> VGPR (the caller has padded the last MFMA's 18 wait states)
-  float v;
-  asm volatile("v_accvgpr_read_b32 %0, a%1" : "=v"(v) : "n"(R));
-  return v;
-}
-template <int T>
-__device__ __forceinline__ void o_zero() {
-  if constexpr (T == 0) asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15");
-  if constexpr (T == 1) asm volatile("v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0" ::: "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31");
-  if constexpr (T == 2) asm volatile("v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0" ::: "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47");
-  if constexpr (T == 3) asm volatile("v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0" ::: "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63");
+// (O as C++ values behind "+a" constraints: hipcc knows their liveness.  Naming fixed registers a[0:63] in the asm text with clobber lists - the
+// "asm-owned" way - was tried and is WRONG here: between two statements that clobber a tuple the allocator is free to put a short-lived value
+// (a V^T fragment read at slot 0 and dead by slot 18) into that tuple's registers.  The price of the C++ values: hipcc carries one of the four
+// tuples through VGPRs around the main loop, 32 v_accvgpr moves per trip of four steps.)
+__device__ __forceinline__ void mfma_o(f32x16& d, const bf16x8& v, const bf16x8& p) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "a"(v), "v"(p));
 }
 // LDS -> AGPR fragment read at lane address + immediate; completion is the caller's counted lgkmcnt
 template <int OFF>
@@ -157,15 +141,18 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
     for (int c = 0; c < 4; ++c) koff[b][c] = sbase + row * 128 + (((c * 2 + hi) ^ sw) << 4);
   }
 
-  // O^T [block][d half]: the asm-owned accumulator registers a[0:63] (mfma_o / o_read / o_zero)
+  f32x16 o[2][2];                                              // O^T [block][d half]                   (AGPRs)
   f32x16 sa[2][2], sb[2][2];                                   // S^T of two consecutive tiles: [block][key half]; roles swap every step (VGPRs)
   float ls[2][8];                                              // row-sum partials [block][position in a chunk]: an add is a chunk behind the one it depends on
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ls[x][i] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[x][d][r] = 0.f;
   }
-  o_zero<0>(); o_zero<1>(); o_zero<2>(); o_zero<3>();
 
   // keys at and past N: their scores become -inf BEFORE the exponentials (their K rows are zero: 2^0 = 1 would enter the row sums)
   auto mask_tail = [&](f32x16 (&s)[2][2], int tile) {
@@ -213,6 +200,8 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   auto step = [&](int j, auto pc, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], auto maskc) {
     constexpr int P = decltype(pc)::value;
     constexpr bool kMask = decltype(maskc)::value;             // the tail trips: tile j + 1 may be ragged or past the end - mask it (no branch inside a step)
+    asm volatile("" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));   // O stays in the accumulator file across the step boundary (else
+                                                                                   // hipcc parks one tuple in VGPRs around the loop: 32 v_accvgpr moves per trip)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the previous step's four loads: K tile j + 2 and V^T tile j have landed
     __builtin_amdgcn_s_barrier();
     FENCE();
@@ -226,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
         else mfma_s(sn[x][kb], kfr[kk][kb], qf[x][kk]);
       } else {
         constexpr int c = (s - 16) >> 2, x = ((s - 16) >> 1) & 1, d = s & 1;
-        mfma_o<2 * x + d>(vfr[c][d], pf[x][c]);
+        mfma_o(o[x][d], vfr[c][d], pf[x][c]);
       }
       // ---- the fragment read of this slot ----
       if constexpr ((s & 1) == 0) {
@@ -300,8 +289,6 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const long long q = q0 + x * 32 + l31;
-    float ov[2][16];
-    static_for<32>([&](auto r_) { constexpr int r = decltype(r_)::value; ov[r >> 4][r & 15] = o_read<(2 * x) * 16 + r>(); });
     if (q < N) {
       bf16_t* op = O + q * ldo + h * 64;
 #pragma unroll
@@ -310,8 +297,8 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
         for (int g = 0; g < 4; ++g) {
           const int d = db * 32 + 8 * g + 4 * hi;
           uint2 w;
-          w.x = pack_bf2(ov[db][g * 4 + 0] * inv, ov[db][g * 4 + 1] * inv);
-          w.y = pack_bf2(ov[db][g * 4 + 2] * inv, ov[db][g * 4 + 3] * inv);
+          w.x = pack_bf2(o[x][db][g * 4 + 0] * inv, o[x][db][g * 4 + 1] * inv);
+          w.y = pack_bf2(o[x][db][g * 4 + 2] * inv, o[x][db][g * 4 + 3] * inv);
           *(uint2*)(op + d) = w;
         }
     }
