@@ -93,6 +93,33 @@ def _clip_inputs(F, H, W, seed):
     return video, noise, text, T
 
 
+def test_option_weight_sums_off_bit_exact(both):
+    """DOVE_OPT_WEIGHT_SUMS = 0 == pipe.vae.weight_sums = False: no conv is handed a pack-time weight sum (w_first / w_sub / w_pair) - the
+    reference's per-tap arithmetic for validating a checkpoint.  Decode (which holds all three forms: cache-less first frames, sub-pixel
+    upsamplers, frame pairs behind the time-doubling upsamplers) through the C graph == the Python facade with the same switch, bit for
+    bit; the switch does change the result (so it did switch), by no more than the summed weights' one extra rounding."""
+    from dove_amd import lib as L
+    pipe, ctx, _ = both
+    T, h, w = 3, 32, 48                                          # the upsampled grids reach 16 x 32 low-res: the sub-pixel and pair forms engage
+    z = torch.randn(16, T, h, w, generator=torch.Generator().manual_seed(8)).to(BF).cuda()
+    try:
+        on_py = pipe.vae.decode(z[None], _prescale=1 / 0.7).sample[0]
+        on_c = ctx.vae_decode(z, prescale=1 / 0.7)
+        pipe.vae.weight_sums = False
+        ctx.set_option(L.OPT_WEIGHT_SUMS, 0)
+        assert ctx.get_option(L.OPT_WEIGHT_SUMS) == 0
+        off_py = pipe.vae.decode(z[None], _prescale=1 / 0.7).sample[0]
+        off_c = ctx.vae_decode(z, prescale=1 / 0.7)
+        torch.cuda.synchronize()
+        assert torch.equal(on_c, on_py) and torch.equal(off_c, off_py)
+        d = float(((on_py.float() - off_py.float()) ** 2).mean().sqrt() / (off_py.float() ** 2).mean().sqrt())
+        print(f"[weight sums off] decoded clip, summed vs per-tap weights: rms-rel {d:.3e}")
+        assert 0.0 < d < 3e-2, d
+    finally:
+        pipe.vae.weight_sums = True
+        ctx.set_option(L.OPT_WEIGHT_SUMS, 1)
+
+
 def test_option_vae_tiling_bit_exact(both):
     """DOVE_OPT_VAE_TILING = pipe.vae.enable_tiling() (`--is_vae_st`, ref :643-645): encode, decode and the whole clip through the C
     graph == the Python facade with the same switch, bit for bit; 3 x 3 tiles in both directions (sample size 96 x 160 -> 48 x 80 px
