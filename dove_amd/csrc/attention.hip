@@ -19,14 +19,14 @@
 // exceeds it by THR = 2^6; then O, l, the current tile's S and the -m registers are rescaled once, BEFORE the tile's
 // P is exponentiated (the safe order of T13).  P <= 64 in bf16 keeps its 8-bit relative precision and O / l accumulate
 // in fp32, so the result matches the exact-max formulation to rounding (tests: spiked keys early / late, full tensor).
-// Measured on MI355X at N = 18226, 48 heads (tools/attn_ab.py, within-run A/B; profiles/r02_attn_ab.log, r03_*): 0.93-0.99 PF by box
+// Measured on MI355X at N = 18226, 48 heads (tools/archive/attn_ab.py, within-run A/B; profiles/r02_attn_ab.log, r03_*): 0.93-0.99 PF by box
 // (round 1: 0.88-0.91).  What did NOT pay (same harness): row sum on the matrix pipe (ones x P^T, -2 %), four partial sums / v_pk_add
 // (0 %), the shift as a fifth K slice (+1 % but 2x the rounding error), two query blocks per wave, in-wave software pipelining (+3 %),
 // 6 / 8 waves per workgroup, and - round 3 - two wave groups one barrier phase apart (tools/exp/attn2g_exp.hip: 0.94-0.98x).
-// tools/coissue.py shows what bounds all of them: on gfx950 the MFMAs of one wave and the VALU of ANOTHER wave on the same SIMD
+// tools/archive/coissue.py shows what bounds all of them: on gfx950 the MFMAs of one wave and the VALU of ANOTHER wave on the same SIMD
 // serialize completely (t = t_mfma + t_valu at any priority); only VALU instructions that follow an MFMA in the same wave's own
 // stream hide under it (about half of the softmax mix).  Per 32 x 64 wave-tile: 16 MFMAs = 290 ns on N(0,1)-like operands
-// (the pipes throttle with operand toggling: 1.9 PF sustained, tools/mfma_storm.py), softmax VALU = 311-353 ns, measured 540 ns.
+// (the pipes throttle with operand toggling: 1.9 PF sustained, tools/archive/mfma_storm.py), softmax VALU = 311-353 ns, measured 540 ns.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -284,7 +284,7 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_ARG(Npad * 128 < (1ll << 31), "attention_fwd: sequence too long for 31-bit buffer offsets");
   DOVE_CHECK_ARG(ldo >= (long long)heads * 64 && ldo % 4 == 0, "attention_fwd: bad ldo");
   constexpr int LDS = 4 * 16384;
-  constexpr int NW = 4;                          // tools/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
+  constexpr int NW = 4;                          // tools/archive/attn_nw.py: 8 waves sharing a tile = 4 within noise (0 / +1.7 % on two boxes), 6 waves -13 %
   static PerDeviceOnce attr_set;
   if (auto once_ = attr_set.guard()) {
     (void)hipFuncSetAttribute((const void*)(attn_fwd_kernel<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -315,7 +315,7 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
 }
 
 #ifdef DOVE_TIMING_BUILD
-// tools/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS) on the 2-D grid, and
+// tools/archive/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS) on the 2-D grid, and
 // nw = 14: 4 waves with the XCD-contiguous 1-D grid (the product mapping), within one run
 extern "C" int dove_attention_fwd_bf16_nw(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads,
                                           long long ldo, int nw, void* stream) {

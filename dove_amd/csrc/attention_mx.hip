@@ -14,7 +14,7 @@
 //     largest probability lands in (128, 256] and the E8M0 scale 2^e restores it inside the MFMA.  A scale per tile (not one
 //     fixed scale against the running max) matters at N = 18k keys: a flat tail of keys at 2^-12 of the max carries more
 //     mass than the max itself and would flush to zero under a fixed scale.
-// Operand register layout of the 8-bit 32x32x64 MFMA (probed, tools/mxprobe.py): lane (row = l & 31, h = l >> 5) holds K bytes
+// Operand register layout of the 8-bit 32x32x64 MFMA (probed, tools/archive/mxprobe.py): lane (row = l & 31, h = l >> 5) holds K bytes
 // [16h, 16h+16) in registers 0-3 and [32+16h, 32+16h+16) in registers 4-7; the scale of 32-block b comes from lanes with h = b.
 #include <stdlib.h>
 

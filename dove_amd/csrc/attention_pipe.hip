@@ -3,7 +3,7 @@
 // CogVideoXAttnProcessor2_0, /root/reference/inference_script.py:483-489) in the one-wave-per-SIMD software-pipelined structure of the CDNA4 guide
 // (cdna_hip_programming.md "4-wave, one-wave-per-SIMD, persistent structure"; MI355X_MICROARCH "single-issue instructions HIDDEN per
 // v_mfma_f32_32x32x16_bf16 gap: <= 5"): on gfx950 the VALU work of one wave hides under the MFMAs of the SAME wave's stream and not under
-// another wave's (tools/coissue.py) - attn_fwd_kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) adds its 16 MFMAs and its
+// another wave's (tools/archive/coissue.py) - attn_fwd_kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) adds its 16 MFMAs and its
 // ~200 ns of softmax per 32 x 64 wave-tile and reads 16 KB of LDS per 16 MFMAs.  Here:
 //   * ONE wave per SIMD (256 threads, one workgroup per CU); a wave owns TWO query blocks of 32 (A, B): every K / V^T fragment read from LDS
 //     feeds two MFMAs (half the LDS traffic per MFMA);

@@ -493,7 +493,7 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // (Round 3 tried two other placements of a step's 2-4 LDS-DMA instructions - spread by sched_group_barrier: -4 %, the compiler also
 // re-clusters the fragment reads; four sched_barrier-fenced quarters of {<= 1 DMA, 4 reads, 8 MFMAs}: +-0.3 % - profiles/r03_halo4x_dma.log.
 // Unlike gemm4x's eight DMAs per step, two to four do not back up the CU's address path; the pinned order below stays.)
-// kM16 (THE PRODUCT since the end of round 4; kM16 = false is the walk of rounds 1-4, kept in the TIMING build for tools/halo_m16_ab.py): the same
+// kM16 (THE PRODUCT since the end of round 4; kM16 = false is the walk of rounds 1-4, kept in the TIMING build for tools/archive/halo_m16_ab.py): the same
 // walk on v_mfma_f32_16x16x32_bf16 - 8 x 8 accumulator blocks of 16 couts x 16 pixels in the same 256 registers, one K-32 fragment per 16 rows
 // (the same 16 ds_read_b128 per step), 64 MFMAs per step split by COUT half: the step's 8 activation fragments and the first 4 weight fragments
 // are in registers when its barrier opens; the other 4 weight fragments are read under the first 32 MFMAs, the next step's 8 + 4 under the second
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 // tiles walked by PERSISTENT workgroups in an XCD-aware supertile order (g4_* below), operands staged by LDS-DMA, the LDS-transposed epilogue
 // with buffer-addressed stores (bias, GELU(tanh), residual and AdaLN gate applied in fp32 on the read side).
 //   gemm8p_kernel (the product): eight waves in ping-pong over two K-64 buffers of full 128-B rows - see its header.
-//   gemm4x_kernel (round 2's kernel, TIMING build only, for the within-run A/B of tools/gemm8p_ab.py): ONE wave per SIMD (512-register
+//   gemm4x_kernel (round 2's kernel, TIMING build only, for the within-run A/B of tools/archive/gemm8p_ab.py): ONE wave per SIMD (512-register
 //     budget), 4 waves = 2 x 2 wave tiles of 128 x 128, 4-stage K-32 ring staged 3 steps ahead with counted vmcnt, fragments
 //     register-pipelined across the single per-step barrier, pinned MFMA / VMEM / DS interleave.
 // (gemm4x's tile constants, the supertile walk g4_* and IgemmArgs live in igemm_args.h; gemm4x_kernel itself in gemm4x_timing.hip)
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
 // gemm8p: gemm4x's GEMM (same 256 x 256 tile, same persistent tile walk and supertile order, same arithmetic: results are bit-identical)
 // with the two changes the measurements of round 3 asked for.
 //  * FULL-LINE STAGING.  gemm4x's K-32 ring is filled by LDS-DMA instructions that fetch 16 rows x 64 B; a DMA-only kernel walking the same
-//    tiles (tools/stage_ab.py) stages at 11-14.5 TB/s that way - as long as the MFMA work itself takes - and 1.5-1.65x faster with 8 rows
+//    tiles (tools/archive/stage_ab.py) stages at 11-14.5 TB/s that way - as long as the MFMA work itself takes - and 1.5-1.65x faster with 8 rows
 //    x 128 B per instruction (64-B requests run into the L2 request rate: 11 requests per clock and XCD of 16; TA busy 78 %), while the
 //    queue depth hardly matters (nothing in flight behind a 64 KB step: -9 %).  So the ring here is TWO K-64 buffers of 128-B rows
 //    (XOR-swizzled like attention's K tile), each refilled in one go as soon as its last reader is through.
@@ -1068,7 +1068,7 @@ constexpr int XB = 0, WB = 2 * OPB;                          // x buffers at 0 /
 constexpr int EPI = 4 * OPB;                                 // epilogue staging: 8 waves x 32 rows x 128 B (XOR-swizzled)
 constexpr int LDS_BYTES = EPI + 8 * 4096;                    // 163840
 }  // namespace gemm8p
-// kM16 (THE PRODUCT since the end of round 4; kM16 = false = round 3's phases, kept in the TIMING build for tools/gemm_m16_ab.py, DOVE_GEMM_M16=0):
+// kM16 (THE PRODUCT since the end of round 4; kM16 = false = round 3's phases, kept in the TIMING build for tools/archive/gemm_m16_ab.py, DOVE_GEMM_M16=0):
 // the same phases on v_mfma_f32_16x16x32_bf16 - the MFMA shape the power-limited pipe sustains best on real operands and to which the dominant
 // conv moved.  A wave's 128 tokens x 64 channels = 8 x 4 blocks of 16 x 16 (the same 128 accumulator registers), a phase =
 // 12 K-32 fragment reads + 32 MFMAs.  Results are BIT-IDENTICAL to the 32 x 32 x 16 phases on every form the DiT uses (so the row tails on
@@ -1552,7 +1552,7 @@ static int cu_count() {
   }
 #ifdef DOVE_TIMING_BUILD
   {
-    const char* e = getenv("DOVE_CU_LIMIT");                  // tools/cumask_probe.py: persistent grids sized for a CU-masked stream
+    const char* e = getenv("DOVE_CU_LIMIT");                  // tools/archive/cumask_probe.py: persistent grids sized for a CU-masked stream
     if (e && atoi(e) > 0 && atoi(e) < n) return atoi(e);
   }
 #endif
@@ -1688,7 +1688,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       // whole clip gains 0.1-0.25 % (within-run, three A/Bs; profiles/r03_gemm8p_nt.log) - kept because it never loses, not because it matters
       a.nt_out = (long long)M * d->ldo * 2 > (256ll << 20);
 #ifdef DOVE_TIMING_BUILD
-      if (a.debug & 8) a.nt_out = 1;                             // tools/gemm8p_nt.py: force on / off
+      if (a.debug & 8) a.nt_out = 1;                             // tools/archive/gemm8p_nt.py: force on / off
       if (a.debug & 16) a.nt_out = 0;
 #endif
       const long long nt = ((M + gemm4x::BM - 1) / gemm4x::BM) * a.tiles_n;
@@ -1698,8 +1698,8 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const unsigned grid4 = nt > cus ? (unsigned)cus : (unsigned)nt;
 #ifdef DOVE_TIMING_BUILD
       {
-        // the predecessor kernel, for within-run A/Bs: DOVE_GEMM8P=0 (read per call: tools/gemm8p_ab.py toggles it), with DOVE_GEMM4X_SCHED=0
-        // its round-2 DMA order (tools/gemm4x_sched.py); a debug buffer selects the s_memtime instantiations (tools/gemm*_timing.py)
+        // the predecessor kernel, for within-run A/Bs: DOVE_GEMM8P=0 (read per call: tools/archive/gemm8p_ab.py toggles it), with DOVE_GEMM4X_SCHED=0
+        // its round-2 DMA order (tools/archive/gemm4x_sched.py); a debug buffer selects the s_memtime instantiations (tools/gemm*_timing.py)
         const char* e8 = getenv("DOVE_GEMM8P");
         if (e8 && atoi(e8) == 0) {
           const char* es = getenv("DOVE_GEMM4X_SCHED");
@@ -1711,7 +1711,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
           return launch_gemm4x_timing(a, M, grid4, variant, s);
         }
         {
-          const char* em = getenv("DOVE_GEMM_M16");               // tools/gemm_m16_ab.py: DOVE_GEMM_M16=0 = the 32 x 32 x 16 phases of round 3, read per call
+          const char* em = getenv("DOVE_GEMM_M16");               // tools/archive/gemm_m16_ab.py: DOVE_GEMM_M16=0 = the 32 x 32 x 16 phases of round 3, read per call
           if (em && atoi(em) == 0 && !DOVE_DBG_BUF) {
             static PerDeviceOnce attr8m;
             if (auto once_ = attr8m.guard()) {
@@ -1775,7 +1775,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const int cus = cu_count();
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
 #ifdef DOVE_TIMING_BUILD
-      if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
+      if (!halo_m16()) {                                         // tools/archive/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
         static PerDeviceOnce attrm;
         if (auto once_ = attrm.guard()) (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, true, false>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
@@ -1807,7 +1807,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       const int cus = cu_count();                              // persistent: one workgroup per CU walks its share of the tiles
       const unsigned grid = g4 > cus ? (unsigned)cus : (unsigned)g4;
 #ifdef DOVE_TIMING_BUILD
-      if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/halo4x_timing.py
+      if (DOVE_DBG_BUF && kern == K_HALO4X) {                   // tools/archive/halo4x_timing.py
         a.gate = (const float*)DOVE_DBG_BUF;
         static PerDeviceOnce attrt;
         if (auto once_ = attrt.guard())
@@ -1817,7 +1817,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       } else
 #endif
 #ifdef DOVE_TIMING_BUILD
-      if (!halo_m16()) {                                         // tools/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
+      if (!halo_m16()) {                                         // tools/archive/halo_m16_ab.py, DOVE_HALO_M16=0: the 32 x 32 x 16 walk of rounds 1-4
         static PerDeviceOnce attrm;
         if (auto once_ = attrm.guard()) {
           (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);

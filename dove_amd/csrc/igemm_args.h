@@ -136,7 +136,7 @@ __device__ __forceinline__ void g4_advance(G4State& s, const IgemmArgs& a, const
 // generic v1 kernel (igemm_legacy.hip): BN in {32, 64, 128}, BK = 64 if Cin % 64 == 0 else 32
 int launch_igemm_legacy(const IgemmArgs& a, unsigned grid, int BN, bool bk64, hipStream_t s);
 #ifdef DOVE_TIMING_BUILD
-// round 2's one-wave-per-SIMD GEMM (gemm4x_timing.hip), for the within-run A/Bs of tools/gemm8p_ab.py / gemm4x_sched.py / gemm4x_timing.py:
+// round 2's one-wave-per-SIMD GEMM (gemm4x_timing.hip), for the within-run A/Bs of tools/archive/gemm8p_ab.py / gemm4x_sched.py / gemm4x_timing.py:
 // variant 0 plain, 1 GELU, 2 gate, 3 s_memtime log (a.zero = debug buffer), 4 round-2 DMA order
 int launch_gemm4x_timing(const IgemmArgs& a, long long M, unsigned grid, int variant, hipStream_t s);
 #endif

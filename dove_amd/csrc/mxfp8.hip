@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_kernel(const MxArgs a) {
   };
 
   // fragment addresses: token rows wm*128 + p*32 + l31, weight rows wn*128 + i*32 + l31.  Operand layout of the 8-bit
-  // 32x32x64 MFMA (probed on the hardware, tools/mxprobe.py): lane (row = l & 31, h = l >> 5) holds in registers 0-3 the
+  // 32x32x64 MFMA (probed on the hardware, tools/archive/mxprobe.py): lane (row = l & 31, h = l >> 5) holds in registers 0-3 the
   // row's K bytes [16 h, 16 h + 16) and in registers 4-7 the bytes [32 + 16 h, 32 + 16 h + 16) - one 16-byte piece of EACH
   // 32-element scale block - while the scale of block b is taken from the lanes with h = b.  So a lane reads the 16-byte
   // chunks h and 2 + h of the 64-byte row, at swizzled positions that do not depend on p (p*32 rows leave (row>>2)&3

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libcoissue_exp.so"))
 lib.coissue.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000

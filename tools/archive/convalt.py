@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 so = os.path.join(ROOT, "tools", "exp", "libconvalt_exp.so")
 if not os.path.exists(so):
     import subprocess

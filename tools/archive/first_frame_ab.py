@@ -4,7 +4,7 @@
     python tools/first_frame_ab.py [first|sub]"""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from dove_amd import config, ops, weights
 from dove_amd.vae import AutoencoderKLCogVideoX

@@ -6,7 +6,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dove_amd import lib as _L, ops  # noqa: E402
 
 _L.use_timing_build()          # s_memtime phase logs live only in the -DDOVE_TIMING_BUILD library

@@ -2,7 +2,7 @@
 HIP kernels vs the torch restatement of the same operator graph (tests/emu_ops.py, CPU), resnet by resnet, and both against the fp32 oracle."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dove_amd.ops as real
 from dove_amd import config, weights

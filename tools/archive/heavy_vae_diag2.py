@@ -2,7 +2,7 @@
 more than the bf16-emulated reference?  Cross-feeds: HIP decoder on the fp32 oracle's latent, on its own latent, on the bf16 oracle's."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from dove_amd import config, weights
 from dove_amd.vae import AutoencoderKLCogVideoX

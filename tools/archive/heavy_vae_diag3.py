@@ -2,7 +2,7 @@
 resnet, and what the fp32 decoder makes of each latent's error."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import dove_amd.ops as real
 from dove_amd import config, weights

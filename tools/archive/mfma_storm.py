@@ -4,7 +4,7 @@ import os
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libmfma_storm_exp.so"))
 lib.mfma_storm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 g = torch.Generator(device="cuda").manual_seed(0)

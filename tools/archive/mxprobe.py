@@ -4,7 +4,7 @@ import os
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libmxprobe_exp.so"))
 lib.mxprobe.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
 g = torch.Generator().manual_seed(0)

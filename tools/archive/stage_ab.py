@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libstage_exp.so"))
 lib.stage_exp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]
 M = 18226

@@ -1,12 +1,12 @@
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from dove_amd import config
 from dove_amd.inference import process_video
 from dove_amd.pipeline import CogVideoXPipeline
 from safetensors.torch import load_file
 dev = torch.device("cuda", 0)
-text = load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "empty_prompt_embedding.safetensors"))["prompt_embedding"]
+text = load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "empty_prompt_embedding.safetensors"))["prompt_embedding"]
 v, t, s = config.default_configs()
 pipe = CogVideoXPipeline.from_config(v, t, s, seed=1234, device=dev, init_device=dev)
 video = bench.prepare_clip(bench.synth_lr_clip(33, 180, 320, seed=42, device=dev), 4).to(torch.bfloat16)

@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "libubench_exp.so"))
 lib.ubench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 NAMES = {0: "32 v_exp_f32", 1: "32 v_add_f32", 2: "16 exp + 16 add interleaved", 3: "16 MFMA 32x32x16 (4 acc; two groups of 8)", 4: "8 MFMA + 32 add (4/gap)",

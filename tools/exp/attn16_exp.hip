@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/attn16_ab.py; never loaded by dove_amd; its constant-shift path ran once on a GPU with round 4's last seconds -
+// EXPERIMENT (tools/archive/attn16_ab.py; never loaded by dove_amd; its constant-shift path ran once on a GPU with round 4's last seconds -
 // profiles/r04_attn16.log: correct - the running-maximum path has not run yet): the flash-attention forward of dove_attention_fwd_bf16 on
 // v_mfma_f32_16x16x32_bf16, the MFMA shape the power-limited matrix pipe sustains best on real operands (the conv and the
 // GEMMs moved to it, bit-identical and 3-7 % faster).  Both softmax paths of the product kernel: the constant shift from a per-head score
@@ -12,7 +12,7 @@
 //   P^T as the B operand of O^T = V^T P^T: a K-32 group is TWO key blocks (2 g, 2 g + 1); lane q4 owns keys 4 q4 .. 4 q4 + 3 of each, and its
 //     eight probabilities ARE its K slice in the order [block 2 g: 4 q4 ..+3 | block 2 g + 1: 4 q4 ..+3].  The contraction order is free as long
 //     as V^T uses the same one, so the caller stores every 32 keys of V^T as [a0-3 b0-3 | a4-7 b4-7 | a8-11 b8-11 | a12-15 b12-15] (a / b = the
-//     two 16-key blocks; tools/attn16_ab.py permutes; in the product that would be a third v_order of dove_qkv_post_bf16) and lane q4's
+//     two 16-key blocks; tools/archive/attn16_ab.py permutes; in the product that would be a third v_order of dove_qkv_post_bf16) and lane q4's
 //     fragment is ONE 16-byte chunk: no cross-lane exchange anywhere, like the product kernel.
 //   O^T[d][query] as 4 d blocks x 2 query blocks (8 quads, the same 32 registers); lane = (query l15, d 4 q4 .. 4 q4 + 3).
 //   Row sums: per lane and query block, reduced over the four q4 lane groups once at the end.

@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/attn_ab.py variants 40+; never loaded by dove_amd): flash attention forward, head_dim 64, with TWO WAVE GROUPS
+// EXPERIMENT (tools/archive/attn_ab.py variants 40+; never loaded by dove_amd): flash attention forward, head_dim 64, with TWO WAVE GROUPS
 // ONE BARRIER PHASE APART (MI355X_MICROARCH.md "Two waves per SIMD").
 //
 // Workgroup = 8 waves = 256 queries (32 per wave), two waves per SIMD: group A = waves 0-3, group B = waves 4-7.  Per 64-key tile a

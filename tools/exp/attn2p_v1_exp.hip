@@ -1,5 +1,5 @@
 // EXPERIMENT (tools/attn2p_ab.py; never loaded by dove_amd): flash-attention forward of dove_attention_fwd_bf16, BOUNDED-SCORE path only,
-// rebuilt around what tools/coissue.py and tools/ubench.py measured on gfx950: the MFMAs of one wave and the VALU work of ANOTHER wave on the
+// rebuilt around what tools/archive/coissue.py and tools/archive/ubench.py measured on gfx950: the MFMAs of one wave and the VALU work of ANOTHER wave on the
 // same SIMD serialize, while VALU instructions that follow an MFMA in the SAME wave's stream run under it (8 MFMA + 16 v_exp: 276 ticks where
 // the MFMAs alone take 256).  The product kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) overlaps nothing: 16 MFMAs (290 ns on
 // real operands) + ~200 ns of softmax VALU = the 510 ns per 32 x 64 wave-tile it measures.  Here:

@@ -1,5 +1,5 @@
 // EXPERIMENT harness (not part of the product library): templated variants of the flash-attention forward for within-run
-// A/B on the GPU box (tools/attn_ab.py).  Operand layout and numerics contract are those of dove_attention_fwd_bf16.
+// A/B on the GPU box (tools/archive/attn_ab.py).  Operand layout and numerics contract are those of dove_attention_fwd_bf16.
 //   NEGM: the running max enters the S accumulator through the MFMA C operand (S - m costs no VALU), rescale deferred
 //         until some score exceeds the running max by THR (base-2)
 //   SUM : 0 serial fp32 row sum, 1 four partial sums, 2 row sum on the matrix pipe (ones x P^T)

@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/attn_ab.py, variants 30+): software-pipelined flash attention.  Within ONE wave the QK^T MFMAs of tile j+1 are
+// EXPERIMENT (tools/archive/attn_ab.py, variants 30+): software-pipelined flash attention.  Within ONE wave the QK^T MFMAs of tile j+1 are
 // issued under the exponentials of tile j and the PV MFMAs of tile j under the row sums of tile j and the max-reduction of tile
 // j+1; the interleave is pinned with sched_barrier fences (the compiler otherwise orders the phases serially).  Operand layout and
 // numerics contract are those of dove_attention_fwd_bf16 (lazy rescale, -m through the MFMA C operand).

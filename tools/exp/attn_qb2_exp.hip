@@ -3,14 +3,14 @@
 // WRONG (max err 5.8): with both query blocks' MFMA chains and VALU in one scheduling region the compiler places a VALU reader of the
 // inline-asm MFMA's result inside its 12-wait-state window - the hazard of an asm statement it cannot see (guide 5.7 item 2; the
 // product kernel is pinned against this by tests/test_isa_checks.py).  A working version needs every MFMA in asm with explicit
-// "a" / "v" register classes and a hand-placed 1 MFMA : 5 VALU interleave; tools/coissue.py bounds what that could gain at ~13 %
+// "a" / "v" register classes and a hand-placed 1 MFMA : 5 VALU interleave; tools/archive/coissue.py bounds what that could gain at ~13 %
 // of the attention time (478 ns per 16 MFMA + softmax mix against 540 ns now).  Kept as the record of the attempt.
 //
-// EXPERIMENT (tools/attn_ab.py variants 50+; never loaded by dove_amd): flash attention forward, head_dim 64, ONE wave per SIMD,
+// EXPERIMENT (tools/archive/attn_ab.py variants 50+; never loaded by dove_amd): flash attention forward, head_dim 64, ONE wave per SIMD,
 // TWO query blocks per wave, skewed by half a tile so that every block of 16 MFMAs has the softmax VALU of the OTHER query block to
 // interleave with IN THE SAME WAVE.
 //
-// Why this shape (tools/coissue.py, profiles/r03_coissue_mfma_valu.log): on gfx950 an MFMA stream and a VALU stream issued by two
+// Why this shape (tools/archive/coissue.py, profiles/r03_coissue_mfma_valu.log): on gfx950 an MFMA stream and a VALU stream issued by two
 // DIFFERENT waves of one SIMD serialize completely (t = t_mfma + t_valu, whatever the priorities), while ONE wave that alternates
 // 1 MFMA : ~7 independent VALU hides about half of the VALU time under its own MFMAs (16 MFMA + the softmax mix: 478 ns instead of
 // 302 + 353).  Within one query block a tile is a dependency chain (QK^T -> softmax -> PV), so the independent VALU has to come from

@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/coissue.py): do the matrix pipe and the VALU of ONE SIMD run concurrently when the two instruction streams
+// EXPERIMENT (tools/archive/coissue.py): do the matrix pipe and the VALU of ONE SIMD run concurrently when the two instruction streams
 // come from two DIFFERENT waves?  Workgroup = 8 waves (two per SIMD): waves 0-3 issue only MFMAs (16 per body, two accumulators,
 // operands N(0,1) from memory), waves 4-7 only the softmax VALU mix of one attention wave-tile (33 v_exp, 34 v_add, 16 v_max3, 8 v_max,
 // 16 v_cvt_pk), no LDS, no barriers.  mode 1: only the MFMA waves work, 2: only the VALU waves, 3: both; 4 / 5: both streams in EVERY wave

@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/convalt.py): two structural alternatives for the dominant kernel (conv3x3_halo4x), measured on a model of its K walk:
+// EXPERIMENT (tools/archive/convalt.py): two structural alternatives for the dominant kernel (conv3x3_halo4x), measured on a model of its K walk:
 // one wave per SIMD (256 threads, 1 workgroup per CU, 512 registers per lane), 256 accumulator registers, every operand fragment read
 // from LDS with ds_read_b128, one barrier per 32-MFMA step, no global traffic (the LDS-DMA staging of the real kernel is not modelled: the
 // model is an UPPER bound for both variants).
@@ -14,7 +14,7 @@
 //  MODE 4  baseline tile with NO fragment reads in the loop (registers only): the matrix pipe's own rate in this harness
 //  MODE 5  the baseline walk in the OTHER MFMA shape: v_mfma_f32_16x16x32_bf16, 8 x 8 accumulator blocks of 16 x 16 (the same 128 x 128 tile,
 //          the same 256 accumulator registers, the same 16 fragment reads per step - one K-32 fragment of 16 rows each - and 64 MFMAs);
-//          tools/mfma_storm.py order: the pipe alone holds 2.0-2.1 PF in this shape on N(0,1) data against 1.8-1.9 PF for 32 x 32 x 16
+//          tools/archive/mfma_storm.py order: the pipe alone holds 2.0-2.1 PF in this shape on N(0,1) data against 1.8-1.9 PF for 32 x 32 x 16
 //  MODE 6  mode 5 with the operands held in registers (no LDS reads)
 //  MODE 7  mode 5 HAND-PIPELINED like the product kernel: fragments register-double-buffered across the step barrier (this step's x and the
 //          first half of its w are already in registers when the barrier opens; the second half of w and the NEXT step's x / first w half

@@ -1,4 +1,4 @@
-// EXPERIMENT (tools/stage_ab.py): how fast can 256 persistent workgroups stage a GEMM's operand tiles L2 -> LDS by LDS-DMA with NO compute,
+// EXPERIMENT (tools/archive/stage_ab.py): how fast can 256 persistent workgroups stage a GEMM's operand tiles L2 -> LDS by LDS-DMA with NO compute,
 // walking the tiles exactly like gemm4x (256 x 256 tiles, same supertile order, 4 waves, 128 KB ring)?
 //   MODE 0: K-32 steps, 16 rows x 64 B per instruction (gemm4x's staging shape), WAIT instructions may stay in flight per wave
 //   MODE 1: K-64 steps,  8 rows x 128 B per instruction (full cache lines)

@@ -8,13 +8,13 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 {
-echo "### convalt shape"; timeout 100 python tools/convalt.py shape 4000
-echo "### convalt shape zeros"; timeout 100 python tools/convalt.py shape 4000 zeros
-echo "### halo4x_timing 16x16x32"; timeout 100 python tools/halo4x_timing.py
-echo "### halo4x_timing 32x32x16"; DOVE_HALO_M16=0 timeout 100 python tools/halo4x_timing.py
-echo "### halo_m16_ab check time"; timeout 200 python tools/halo_m16_ab.py check time
-echo "### gemm_m16_ab"; timeout 100 python tools/gemm_m16_ab.py
-echo "### attn16_ab (first run of this kernel on a GPU)"; timeout 150 python tools/attn16_ab.py
+echo "### convalt shape"; timeout 100 python tools/archive/convalt.py shape 4000
+echo "### convalt shape zeros"; timeout 100 python tools/archive/convalt.py shape 4000 zeros
+echo "### halo4x_timing 16x16x32"; timeout 100 python tools/archive/halo4x_timing.py
+echo "### halo4x_timing 32x32x16"; DOVE_HALO_M16=0 timeout 100 python tools/archive/halo4x_timing.py
+echo "### halo_m16_ab check time"; timeout 200 python tools/archive/halo_m16_ab.py check time
+echo "### gemm_m16_ab"; timeout 100 python tools/archive/gemm_m16_ab.py
+echo "### attn16_ab (first run of this kernel on a GPU)"; timeout 150 python tools/archive/attn16_ab.py
 } 2>&1 | grep -v amdgpu > gpurun_out/next_first.log
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep -v amdgpu | tail -1 > gpurun_out/next_bench.log
 tail -60 gpurun_out/next_first.log

@@ -3,4 +3,4 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
-timeout 600 python tools/attn_ab.py 40,41,42,43,44 2>&1 | grep -v amdgpu | tee gpurun_out/r03_attn2g.log | tail -30
+timeout 600 python tools/archive/attn_ab.py 40,41,42,43,44 2>&1 | grep -v amdgpu | tee gpurun_out/r03_attn2g.log | tail -30

@@ -13,5 +13,5 @@ timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | grep -v amdgpu | tail -
 cd /tmp && rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r05 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $R/gpurun_out/r05_prof.log 2>&1
 cd $R; cp /tmp/prof/r05_kernel_stats.csv gpurun_out/r05_bench_kernel_stats.csv
 bash tools/runs/gpu_pmc_bench.sh > /dev/null 2>&1
-timeout 300 python tools/attn16_ab.py 2>&1 | grep -v amdgpu > gpurun_out/r05_attn16_fair.log
+timeout 300 python tools/archive/attn16_ab.py 2>&1 | grep -v amdgpu > gpurun_out/r05_attn16_fair.log
 cat gpurun_out/r05_a_tests.log; tail -1 gpurun_out/r05_bench_head.log | cut -c1-600; head -8 gpurun_out/r05_bench_kernel_stats.csv | cut -c1-130; tail -14 gpurun_out/pmc_traffic.txt; cat gpurun_out/r05_attn16_fair.log
