@@ -279,3 +279,111 @@ def test_process_video_sharded_real_size_8_ranks(tmp_path):
                 assert r[stage][1]["recv_blocking"] == 0 and r[stage][1]["recv_preposted"] == n_halos, (r["rank"], stage, r[stage][1])
             else:
                 assert r[stage][0]["recv_blocking"] == r[stage][1]["recv_preposted"] == 0
+
+
+# ---- the 42-layer DiT of configs[2] at its real sequence length, 8 ranks (the whole operator at real size keeps a 2-layer DiT: 8 x (11 GB of
+# 42-layer weights + 17-20 GB of VAE working set) = 240 GB of this one GPU's 288 GB leaves no margin; the DiT alone is 8 x ~14 GB) --------------
+def _dit42_worker(rank, world, port, q, ref_path):
+    import faulthandler
+    faulthandler.dump_traceback_later(560, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from dove_amd import config, dist as ddist, weights
+        from dove_amd.rope import prepare_rotary_positional_embeddings
+        from dove_amd.transformer import CogVideoXTransformer3DModel
+        v, t, s = config.default_configs()
+        assert t["num_layers"] == 42
+        tr = CogVideoXTransformer3DModel(t, weights.LazyStateDict(weights.dit_param_shapes(t), 21, dev), dev)
+        hidden, text = _dit42_inputs(t)
+        rope = prepare_rotary_positional_embeddings(height=RH, width=RW, num_frames=hidden.shape[0], transformer_config=tr.config,
+                                                    vae_scale_factor_spatial=8, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = ddist.dit_forward_ulysses(tr, hidden.to(dev), text.to(dev), 399, rope)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        ref = torch.load(ref_path).to(dev)
+        d = (out.float() - ref.float()).abs()
+        q.put(dict(rank=rank, equal=bool(torch.equal(out, ref)), max_diff=float(d.max()), n_diff=int((d > 0).sum()), seconds=dt,
+                   finite=bool(torch.isfinite(out).all()), peak_gb=torch.cuda.max_memory_allocated() / 1e9))
+    except BaseException:
+        import traceback
+        q.put(dict(rank=rank, error=traceback.format_exc()))
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dit42_inputs(t):
+    g = torch.Generator().manual_seed(9)
+    hidden = torch.randn(10, 16, RH // 8, RW // 8, generator=g).to(torch.bfloat16)      # 9 latent frames + the first-frame copy: N = 18 000 + 226
+    text = (torch.randn(226, t["text_embed_dim"], generator=g) * 0.15).to(torch.bfloat16)
+    return hidden, text
+
+
+def test_dit_sharded_42_layers_real_size_8_ranks(tmp_path):
+    """The DiT half of configs[2] at FULL depth and the real sequence length: 42 layers, N = 18 226 tokens, 8 ranks (8 processes on this box's one
+    GPU, gloo with host-staged wires) - rows of the residual stream sharded for every row-local operator, 6 heads per rank for attention, one
+    all-to-all each way per layer (`dove_amd.dist.dit_forward_ulysses`): every rank's velocity is BIT-IDENTICAL to the single-process forward
+    (which runs the bounded heads on the pipelined attention kernel and the GEMM row tails on their own kernel - per row and per head the same
+    arithmetic whatever the sharding).  Shard axis of the reference: /root/reference/inference_script.py:249-279, 690-703; the op: :483-489."""
+    import socket
+    import time
+
+    import torch.multiprocessing as mp
+    from dove_amd import config, weights
+    from dove_amd.rope import prepare_rotary_positional_embeddings
+    from dove_amd.transformer import CogVideoXTransformer3DModel
+    dev = torch.device("cuda", 0)
+    v, t, s = config.default_configs()
+    tr = CogVideoXTransformer3DModel(t, weights.LazyStateDict(weights.dit_param_shapes(t), 21, dev), dev)
+    hidden, text = _dit42_inputs(t)
+    rope = prepare_rotary_positional_embeddings(height=RH, width=RW, num_frames=hidden.shape[0], transformer_config=tr.config,
+                                                vae_scale_factor_spatial=8, device=dev)
+    ref = tr._forward_one(hidden.to(dev), text.to(dev), 399, rope)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ref).all())
+    ref_path = str(tmp_path / "ref_dit.pt")
+    torch.save(ref.cpu(), ref_path)
+    del tr, ref
+    torch.cuda.empty_cache()
+    world = 8
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dit42_worker, args=(r, world, port, q, ref_path), daemon=True) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res, t_end = [], time.time() + 580
+    try:
+        while time.time() < t_end and any(p.is_alive() for p in procs):
+            while not q.empty():
+                res.append(q.get())
+            if any("error" in r for r in res):
+                break
+            time.sleep(0.2)
+        while not q.empty():
+            res.append(q.get())
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+            p.join(5)
+    errs = [r for r in res if "error" in r]
+    assert not errs, f"rank {errs[0]['rank']} failed:\n{errs[0]['error']}"
+    assert len(res) == world and all(p.exitcode == 0 for p in procs), f"rank exit codes {[p.exitcode for p in procs]}"
+    res.sort(key=lambda r: r["rank"])
+    print(f"[dit42 x8 real size] {time.time() - t0:.0f} s; per rank: " + " | ".join(
+        f"r{r['rank']}: eq {r['equal']} {r['seconds']:.1f} s peak {r['peak_gb']:.1f} GB" for r in res))
+    assert all(r["finite"] for r in res)
+    bad = [r for r in res if not r["equal"]]
+    assert not bad, f"ranks {[r['rank'] for r in bad]} differ from the single-process forward: max |d| {bad[0]['max_diff']} ({bad[0]['n_diff']} values)"
