@@ -1,4 +1,7 @@
-// Flash-attention forward for the CogVideoX DiT joint [text ; video] self-attention (gfx950).
+// Flash-attention forward for the CogVideoX DiT joint [text ; video] self-attention (gfx950): the entry point dove_attention_fwd_bf16 and the
+// RUNNING-MAXIMUM kernel.  Since round 5 the heads whose scores the caller bounds by 40 (norm2: every head of the DiT with unit LayerNorm gains)
+// run on the software-pipelined kernel of attention_pipe.hip; this kernel keeps the others - and every head when no bound is given - and exits
+// at once for a head the other kernel owns.  Its own constant-shift loop (below) is what the timing library's DOVE_ATTN_PIPE=0 A/B runs.
 //   head_dim 64, bf16 MFMA 32x32x16, fp32 online softmax, non-causal, no mask, N not a tile multiple.
 // Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0, reached from
 // /root/reference/inference_script.py:483-489.
@@ -36,8 +39,8 @@
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
-                               const float* norm2, void* stream);   // attention_pipe.hip
+__attribute__((visibility("hidden"))) int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
+                                                                    int heads, long long ldo, const float* norm2, void* stream);   // attention_pipe.hip
 
 __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;

@@ -25,9 +25,11 @@
 //     step on a tile that does not exist adds zeros - no tail variants, no copies of O at region boundaries.
 // Operand layout: dove_qkv_post_bf16's (v_order 1), as attn_fwd_kernel.  Heads whose bound is above the cutoff (or NaN) are LEFT UNTOUCHED:
 // dove_attention_fwd_bf16 runs them on attn_fwd_kernel's running maximum.
+// The last partial round of workgroups runs the one-block-per-wave form (NB = 1): 3.298 vs 3.341 ms at N = 18 226, 48 heads (profiles/r05_attn_tail.log).
 // Measured (tools/attn2p_ab.py on the experiment twin tools/exp/attn2p_exp.hip, N = 18 226, 48 heads, within one process, profiles/r05_attn2p_*.log):
 // 3.52 ms against attn_fwd_kernel's 3.77-3.96 ms by box (x 0.89-0.93; 1.16 PF), 2.56 vs 2.95 ms on all-zero operands; by parts (ns per step of
 // 32 MFMAs on real operands): MFMAs alone 606, + fragment reads 698, + exponentials and packs 841, + row sums 916.
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -81,25 +83,32 @@ namespace attn_pipe {
 constexpr int SLOT = 8192, VBASE = 4 * SLOT, LDS = 8 * SLOT;    // K slots 0-3 at 0 .. 24 KB, V^T slots 0-3 at 32 .. 56 KB
 }
 
+// NB = query blocks of 32 per wave.  2: the kernel described above (256 queries per workgroup).  1: the same pipeline with one block per
+// wave (128 queries per workgroup, 16 MFMA slots per step, fragments not shared) - about 0.55 of the time per workgroup for half the
+// queries: dove_attention_pipe_launch runs the LAST PARTIAL ROUND of workgroups this way (48 heads x 72 query blocks = 13.5 rounds of 256:
+// the half round costs a whole one otherwise).  `item0`: index of this launch's first 256-query item in the head-major item list.
+template <int NB>
 __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long long N, long long Npad, long long ldo, int qblocks,
-                                                        const float* __restrict__ bound) {
+                                                        const float* __restrict__ bound, int item0) {
   using namespace attn_pipe;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  const unsigned t = xcd_remap(blockIdx.x, gridDim.x);
+  // NB == 2: one item per workgroup, XCD-contiguous over this launch's items; NB == 1: two workgroups per item (query halves)
+  const unsigned t = NB == 2 ? (unsigned)item0 + xcd_remap(blockIdx.x, gridDim.x) : (unsigned)item0 + (blockIdx.x >> 1);
   const int h = (int)(t / (unsigned)qblocks), qb = (int)(t - (unsigned)h * (unsigned)qblocks);
   {
     const float b = 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);
     if (!(b <= 40.0f)) return;                                 // (NaN compares false) the running-maximum kernel owns this head
   }
-  const long long q0 = (long long)qb * 256 + wave * 64;        // block A: q0 .. q0 + 31, block B: q0 + 32 .. q0 + 63
+  const long long q0 = NB == 2 ? (long long)qb * 256 + wave * 64                      // block A: q0 .. q0 + 31, block B: q0 + 32 .. q0 + 63
+                               : (long long)qb * 256 + (blockIdx.x & 1) * 128 + wave * 32;
 
-  bf16x8 qf[2][4];
+  bf16x8 qf[NB][4];
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < NB; ++x) {
     long long qrow = q0 + x * 32 + l31;
     if (qrow >= Npad) qrow = Npad - 1;                         // rows past the padded end are never stored
     const bf16_t* qp = Qh + ((long long)h * Npad + qrow) * 64 + hi * 8;
@@ -141,11 +150,11 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
     for (int c = 0; c < 4; ++c) koff[b][c] = sbase + row * 128 + (((c * 2 + hi) ^ sw) << 4);
   }
 
-  f32x16 o[2][2];                                              // O^T [block][d half]                   (AGPRs)
-  f32x16 sa[2][2], sb[2][2];                                   // S^T of two consecutive tiles: [block][key half]; roles swap every step (VGPRs)
-  float ls[2][8];                                              // row-sum partials [block][position in a chunk]: an add is a chunk behind the one it depends on
+  f32x16 o[NB][2];                                             // O^T [block][d half]                   (AGPRs)
+  f32x16 sa[NB][2], sb[NB][2];                                  // S^T of two consecutive tiles: [block][key half]; roles swap every step (VGPRs)
+  float ls[NB][8];                                             // row-sum partials [block][position in a chunk]: an add is a chunk behind the one it depends on
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < NB; ++x) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ls[x][i] = 0.f;
 #pragma unroll
@@ -155,10 +164,10 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   }
 
   // keys at and past N: their scores become -inf BEFORE the exponentials (their K rows are zero: 2^0 = 1 would enter the row sums)
-  auto mask_tail = [&](f32x16 (&s)[2][2], int tile) {
+  auto mask_tail = [&](f32x16 (&s)[NB][2], int tile) {
     const long long kv0 = (long long)tile * 64;
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < NB; ++x)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -168,12 +177,12 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
         }
   };
 
-  bf16x8 pf[2][4];                                             // P^T fragments of the tile being multiplied: [block][16-key slice c]   (VGPRs)
+  bf16x8 pf[NB][4];                                            // P^T fragments of the tile being multiplied: [block][16-key slice c]   (VGPRs)
   bf16x8 kfr[4][2], vfr[4][2];                                 // K fragments [kk][key half], V^T fragments [slice c][d half]          (AGPRs)
   // softmax chunk (block x, slice c) of the tile held in `s`, cut in four quarters of FIVE instructions (one quarter per MFMA slot):
   // 8 exps, 4 packs, 8 adds
   uint32_t pk[4];
-  auto chunk_q = [&](f32x16 (&s)[2][2], auto x_, auto c_, auto q_) {
+  auto chunk_q = [&](f32x16 (&s)[NB][2], auto x_, auto c_, auto q_) {
     constexpr int x = decltype(x_)::value, c = decltype(c_)::value, quarter = decltype(q_)::value;
     constexpr int kb = c >> 1, b = 8 * (c & 1);
     auto E = [&](int i) { float v = s[x][kb][b + i]; exp2_inplace(v); s[x][kb][b + i] = v; };
@@ -197,42 +206,54 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   // Counted waits: reads return in order; four fragments ahead of each 8-slot block -> lgkmcnt(4) at slots 0, 8, 16, 24.
   // LDS-DMA: K tile j + 4 -> K slot P (its last reader, tile j, was read in step j - 2) in slots 3, 7; V^T tile j + 2 -> V slot (P + 2) & 3 (last
   // reader: tile j - 2 in step j - 2) in slots 11, 15.
-  auto step = [&](int j, auto pc, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], auto maskc) {
+  auto step = [&](int j, auto pc, f32x16 (&sc)[NB][2], f32x16 (&sn)[NB][2], auto maskc) {
     constexpr int P = decltype(pc)::value;
     constexpr bool kMask = decltype(maskc)::value;             // the tail trips: tile j + 1 may be ragged or past the end - mask it (no branch inside a step)
-    asm volatile("" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));   // O stays in the accumulator file across the step boundary (else
-                                                                                   // hipcc parks one tuple in VGPRs around the loop: 32 v_accvgpr moves per trip)
+    if constexpr (NB == 2) asm volatile("" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[NB - 1][0]), "+a"(o[NB - 1][1]));   // O stays in the accumulator file across the step
+    else asm volatile("" : "+a"(o[0][0]), "+a"(o[0][1]));                                                           // boundary (else hipcc parks a tuple in VGPRs around the loop)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // all but the previous step's four loads: K tile j + 2 and V^T tile j have landed
     __builtin_amdgcn_s_barrier();
     FENCE();
-    static_for<32>([&](auto s_) {
+    // NB == 1 (16 slots): S chains in slots 0-7 (kk = s >> 1, kb = s & 1), O chains in 8-15 (c = (s - 8) >> 1, d half = s & 1); chunk c of tile j
+    // in slots 4 c - 4 .. 4 c - 1 (chunk 0 of tile j + 1 in slots 12-15): slice c is packed by slot 4 c - 1 < 8 + 2 c.  One fragment read per
+    // slot: V^T fragment i (d = i & 1, c = i >> 1) in slot i for the MFMA of slot 8 + i, K fragment i of tile j + 2 in slot 8 + i for the NEXT
+    // step's slot i; seven younger reads are in flight at every first use -> lgkmcnt(6) at the even slots covers the pair.
+    constexpr int NS = 16 * NB, HALF = NS / 2;
+    static_for<NS>([&](auto s_) {
       constexpr int s = decltype(s_)::value;
-      if constexpr ((s & 7) == 0) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      if constexpr (NB == 2 && (s & 7) == 0) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+      if constexpr (NB == 1 && (s & 1) == 0) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
       // ---- the MFMA of this slot ----
-      if constexpr (s < 16) {
-        constexpr int kk = s >> 2, kb = (s >> 1) & 1, x = s & 1;
+      if constexpr (s < HALF) {
+        constexpr int kk = NB == 2 ? s >> 2 : s >> 1, kb = NB == 2 ? (s >> 1) & 1 : s & 1, x = NB == 2 ? s & 1 : 0;
         if constexpr (kk == 0) mfma_s_first(sn[x][kb], kfr[0][kb], qf[x][0]);
         else mfma_s(sn[x][kb], kfr[kk][kb], qf[x][kk]);
       } else {
-        constexpr int c = (s - 16) >> 2, x = ((s - 16) >> 1) & 1, d = s & 1;
+        constexpr int u = s - HALF;
+        constexpr int c = NB == 2 ? u >> 2 : u >> 1, x = NB == 2 ? (u >> 1) & 1 : 0, d = s & 1;
         mfma_o(o[x][d], vfr[c][d], pf[x][c]);
       }
       // ---- the fragment read of this slot ----
-      if constexpr ((s & 1) == 0) {
-        constexpr int i = (s & 15) >> 1;
-        if constexpr (s < 16) lds_frag<VBASE + P * SLOT>(vfr[i >> 1][i & 1], koff[i & 1][i >> 1]);
+      if constexpr (NB == 1 || (s & 1) == 0) {
+        constexpr int i = NB == 2 ? (s & 15) >> 1 : s & 7;
+        if constexpr (s < HALF) lds_frag<VBASE + P * SLOT>(vfr[i >> 1][i & 1], koff[i & 1][i >> 1]);
         else lds_frag<((P + 2) & 3) * SLOT>(kfr[i >> 1][i & 1], koff[i & 1][i >> 1]);
       }
-      // ---- this step's LDS-DMAs ----
-      if constexpr (s == 3) dma_k(IC<P>{}, j + 4, 0);
-      if constexpr (s == 7) dma_k(IC<P>{}, j + 4, 1);
-      if constexpr (s == 11) dma_v(IC<((P + 2) & 3)>{}, j + 2, 0);
-      if constexpr (s == 15) dma_v(IC<((P + 2) & 3)>{}, j + 2, 1);
-      // ---- keys at / past the end: S(j + 1) is complete (its chains ended at slot 15), its first exponentials come at slot 28 ----
-      if constexpr (s == 21 && kMask) mask_tail(sn, j + 1);
+      // ---- this step's LDS-DMAs (in the S half) ----
+      constexpr int DS = NB == 2 ? 4 : 2;                       // slots 3, 7, 11, 15 / 1, 3, 5, 7
+      if constexpr (s == DS - 1) dma_k(IC<P>{}, j + 4, 0);
+      if constexpr (s == 2 * DS - 1) dma_k(IC<P>{}, j + 4, 1);
+      if constexpr (s == 3 * DS - 1) dma_v(IC<((P + 2) & 3)>{}, j + 2, 0);
+      if constexpr (s == 4 * DS - 1) dma_v(IC<((P + 2) & 3)>{}, j + 2, 1);
+      // ---- keys at / past the end: S(j + 1) is complete (its chains ended with the S half), its first exponentials come in the last four slots ----
+      if constexpr (s == (NB == 2 ? 21 : 10) && kMask) mask_tail(sn, j + 1);
       // ---- the softmax quarter of this slot ----
-      if constexpr (s < 28) chunk_q(sc, IC<(((s >> 2) + 1) & 1)>{}, IC<(((s >> 2) + 1) >> 1)>{}, IC<(s & 3)>{});
-      else chunk_q(sn, IC<0>{}, IC<0>{}, IC<(s & 3)>{});
+      if constexpr (s < NS - 4) {
+        constexpr int n = (s >> 2) + 1;                         // chunk of tile j
+        chunk_q(sc, IC<(NB == 2 ? (n & 1) : 0)>{}, IC<(NB == 2 ? (n >> 1) : n)>{}, IC<(s & 3)>{});
+      } else {
+        chunk_q(sn, IC<0>{}, IC<0>{}, IC<(s & 3)>{});
+      }
       FENCE();
     });
   };
@@ -246,8 +267,9 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   static_for<8>([&](auto i_) { constexpr int i = decltype(i_)::value; lds_frag<0>(kfr[i >> 1][i & 1], koff[i & 1][i >> 1]); });
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   FENCE();
-  static_for<16>([&](auto s_) {
-    constexpr int s = decltype(s_)::value, kk = s >> 2, kb = (s >> 1) & 1, x = s & 1;
+  static_for<8 * NB>([&](auto s_) {
+    constexpr int s = decltype(s_)::value;
+    constexpr int kk = NB == 2 ? s >> 2 : s >> 1, kb = NB == 2 ? (s >> 1) & 1 : s & 1, x = NB == 2 ? s & 1 : 0;
     if constexpr (kk == 0) mfma_s_first(sa[x][kb], kfr[0][kb], qf[x][0]);
     else mfma_s(sa[x][kb], kfr[kk][kb], qf[x][kk]);
   });
@@ -283,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   FENCE();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the last PV MFMAs -> v_accvgpr_read of O
   FENCE();
-  static_for<2>([&](auto x_) {
+  static_for<NB>([&](auto x_) {
     constexpr int x = decltype(x_)::value;
     float l = ((ls[x][0] + ls[x][1]) + (ls[x][2] + ls[x][3])) + ((ls[x][4] + ls[x][5]) + (ls[x][6] + ls[x][7]));
     l += __shfl_xor(l, 32);
@@ -307,14 +329,44 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
 
 // Launch for the heads whose score bound (norm2: [heads][2] = max |q|^2, max |k|^2) is at most 40; the other heads' output rows are left
 // untouched (dove_attention_fwd_bf16 runs them on attn_fwd_kernel).  Same operand contract as dove_attention_fwd_bf16.
-int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad, int heads, long long ldo,
-                               const float* norm2, void* stream) {
+// Items = (head, 256-query block) in head-major order.  Whole rounds of `cus` items run one per workgroup; a last partial round of at most
+// half the CUs runs as twice as many one-block-per-wave workgroups (NB = 1), which take about 0.55 of a round.
+static int pipe_cu_count() {
+  static std::atomic<int> cus[DOVE_MAX_DEVICES] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int n = (dev >= 0 && dev < DOVE_MAX_DEVICES) ? cus[dev].load(std::memory_order_relaxed) : 0;
+  if (!n) {
+    n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (dev >= 0 && dev < DOVE_MAX_DEVICES) cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+__attribute__((visibility("hidden"))) int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
+                                                                    int heads, long long ldo, const float* norm2, void* stream) {
   static PerDeviceOnce attr_set;
-  if (auto once_ = attr_set.guard()) (void)hipFuncSetAttribute((const void*)attn_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe::LDS);
+  if (auto once_ = attr_set.guard()) {
+    (void)hipFuncSetAttribute((const void*)attn_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe::LDS);
+    (void)hipFuncSetAttribute((const void*)attn_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe::LDS);
+  }
   const int qblocks = (int)((Npad + 255) / 256);
-  DOVE_CHECK_ARG((long long)qblocks * heads < (1ll << 31), "attention_fwd: grid too large");
-  hipLaunchKernelGGL(attn_pipe_kernel, dim3((unsigned)(qblocks * heads)), dim3(256), attn_pipe::LDS, (hipStream_t)stream, (const bf16_t*)Qh,
-                     (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2);
-  DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16 (pipelined)");
+  const long long items = (long long)qblocks * heads;
+  DOVE_CHECK_ARG(items < (1ll << 30), "attention_fwd: grid too large");
+  const int cus = pipe_cu_count();
+  long long rem = items % cus;
+  if (rem * 2 > cus) rem = 0;                                    // a mostly full last round stays on the two-block kernel (a launch of at most half a
+                                                                 // round runs entirely on the one-block form: twice the workgroups, each shorter)
+  const long long main_items = items - rem;
+  if (main_items > 0) {
+    hipLaunchKernelGGL(attn_pipe_kernel<2>, dim3((unsigned)main_items), dim3(256), attn_pipe::LDS, (hipStream_t)stream, (const bf16_t*)Qh,
+                       (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2, 0);
+    DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16 (pipelined)");
+  }
+  if (rem > 0) {
+    hipLaunchKernelGGL(attn_pipe_kernel<1>, dim3((unsigned)(2 * rem)), dim3(256), attn_pipe::LDS, (hipStream_t)stream, (const bf16_t*)Qh,
+                       (const bf16_t*)Kh, (const bf16_t*)Vt, (bf16_t*)O, N, Npad, ldo, qblocks, norm2, (int)main_items);
+    DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16 (pipelined, last round)");
+  }
   return DOVE_OK;
 }

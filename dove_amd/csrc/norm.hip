@@ -458,7 +458,7 @@ extern "C" int dove_layernorm_modulate_bf16(const void* x, void* y, long long ro
 // 8 tokens (one lane per vector touched 64 different lines per instruction and ran at 2.6 TB/s: round 3).  LayerNorm statistics are
 // reduced over the 8 lanes by three xor-shuffles; the interleaved-pair rotation stays inside a lane's 8 values.
 // ------------------------------------------------------------------------------------------------
-constexpr int QK_HB = 4;                                       // heads per thread: the token's cos / sin rows (fp32: 4x the bytes of the data they
+constexpr int QK_HB = 8;                                       // heads per thread: the token's cos / sin rows (fp32: 4x the bytes of the data they
                                                                // rotate) are fetched once per QK_HB heads, not once per head
 __global__ __launch_bounds__(256) void qk_post_kernel(const bf16_t* __restrict__ qkv, long long N, long long Npad, int heads, int text_len,
                                                       const float* __restrict__ gq, const float* __restrict__ bq,

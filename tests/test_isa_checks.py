@@ -198,10 +198,10 @@ def test_no_product_kernel_spills(igemm_asm, tmp_path):
 def test_pipelined_attention_step_is_what_was_placed(tmp_path):
     """attention_pipe.hip places every instruction of its K walk by hand (asm MFMAs / exps / adds / packs / LDS reads, sched_barrier fences) and
     owns hazards hipcc does not model for asm producers (guide 5.7).  Pinned on the ISA of a MAIN-LOOP step (between two workgroup barriers):
-    the instruction multiset that was placed (32 MFMAs, 64 exps, 64 single adds, 32 packs, 16 fragment reads into AGPRs, 4 LDS-DMAs, no
+    the instruction multiset that was placed (per query block and step 16 MFMAs, 32 exps, 32 single adds, 16 packs; 16 fragment reads into AGPRs, 4 LDS-DMAs, no
     accumulator moves, no packed-f32 VALU - an anti-lever beside MFMAs that -O3 SLP-packing produces from plain adds), and the distance the
-    pipeline promises between an S chain's last MFMA and the first VALU instruction that reads its registers (>= 60 instructions: the 18
-    wait states a 16-pass XDL result needs are covered many times over)."""
+    pipeline promises between an S chain's last MFMA and the first VALU instruction that reads its registers (>= 60 instructions, >= 30 in
+    the one-block form: the 18 wait states a 16-pass XDL result needs are covered with margin)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
@@ -209,37 +209,41 @@ def test_pipelined_attention_step_is_what_was_placed(tmp_path):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-result",
                            os.path.join(ROOT, "dove_amd", "csrc", "attention_pipe.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
     lines = [l.strip() for l in open(out).read().split("\n")]
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z16attn_pipe_kernel") and ":" in l)
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    lines = [l for l in lines[start:end + 1] if l and not l.startswith(";") and not l.startswith(".")]
-    bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
-    assert len(bars) >= 9, f"prologue + 4 main-loop steps + 4 tail steps expected, found {len(bars)} barriers"
-    # barriers: [prologue, main step 0, 1, 2, 3, tail step 0 ...]; a main-loop step = from its barrier to the next one
-    for k in (1, 2, 3):
-        st = lines[bars[k]:bars[k + 1]]
-        cnt = lambda pat: sum(1 for l in st if l.startswith(pat))
-        assert cnt("v_mfma_f32_32x32x16_bf16") == 32, (k, cnt("v_mfma_f32_32x32x16_bf16"))
-        assert cnt("v_exp_f32") == 64 and cnt("v_add_f32") == 64 and cnt("v_cvt_pk_bf16_f32") == 32, (k, cnt("v_exp_f32"), cnt("v_add_f32"), cnt("v_cvt_pk_bf16_f32"))
-        assert sum(1 for l in st if l.startswith("ds_read_b128 a[")) == 16, "16 fragment reads per step, straight into AGPRs"
-        assert sum(1 for l in st if l.startswith("buffer_load_dwordx4") and l.endswith("lds")) == 4
-        assert not any(l.startswith("v_accvgpr") for l in st), "accumulator moves inside a step"
-        assert not any(l.startswith("v_pk_") for l in st), "packed f32 VALU inside a step"
-        assert not any("scratch_" in l for l in st)
-        # S chains: an MFMA with a VGPR destination; the LAST one writing a given destination, and the first later non-MFMA reader of it
-        last = {}
-        for i, l in enumerate(st):
-            if l.startswith("v_mfma_f32_32x32x16_bf16 v["):
-                last[l.split()[1].rstrip(",")] = i
-        assert len(last) == 4, last
-        full = lines[bars[k]:bars[k + 2]]                      # the readers of the last chains sit in the next step
-        for dst, i in last.items():
-            regs = _regs(dst)
-            for m in range(i + 1, len(full)):
-                t = full[m]
-                if t.startswith("v_mfma"):
-                    continue
-                if any(_regs(x) & regs for x in re.findall(r"v\[\d+:\d+\]|v\d+", t)):
-                    assert m - i >= 60, f"step {k}: `{t}` reads {dst} only {m - i} instructions behind the chain's last MFMA"
-                    break
-            else:
-                raise AssertionError(f"no reader of {dst} found")
+    all_lines = lines
+    # NB = 2: the kernel as described (two query blocks per wave); NB = 1: the one-block form that runs the last partial round of workgroups
+    for nb, min_gap in ((2, 60), (1, 30)):
+        start = next(i for i, l in enumerate(all_lines) if l.startswith(f"_Z16attn_pipe_kernelILi{nb}E") and ":" in l)
+        end = next(i for i in range(start, len(all_lines)) if "s_endpgm" in all_lines[i])
+        lines = [l for l in all_lines[start:end + 1] if l and not l.startswith(";") and not l.startswith(".")]
+        bars = [i for i, l in enumerate(lines) if l.startswith("s_barrier")]
+        assert len(bars) >= 9, f"prologue + 4 main-loop steps + 4 tail steps expected, found {len(bars)} barriers"
+        # barriers: [prologue, main step 0, 1, 2, 3, tail step 0 ...]; a main-loop step = from its barrier to the next one
+        for k in (1, 2, 3):
+            st = lines[bars[k]:bars[k + 1]]
+            cnt = lambda pat: sum(1 for l in st if l.startswith(pat))
+            assert cnt("v_mfma_f32_32x32x16_bf16") == 16 * nb, (nb, k, cnt("v_mfma_f32_32x32x16_bf16"))
+            assert cnt("v_exp_f32") == 32 * nb and cnt("v_add_f32") == 32 * nb and cnt("v_cvt_pk_bf16_f32") == 16 * nb, \
+                (nb, k, cnt("v_exp_f32"), cnt("v_add_f32"), cnt("v_cvt_pk_bf16_f32"))
+            assert sum(1 for l in st if l.startswith("ds_read_b128 a[")) == 16, "16 fragment reads per step, straight into AGPRs"
+            assert sum(1 for l in st if l.startswith("buffer_load_dwordx4") and l.endswith("lds")) == 4
+            assert not any(l.startswith("v_accvgpr") for l in st), "accumulator moves inside a step"
+            assert not any(l.startswith("v_pk_") for l in st), "packed f32 VALU inside a step"
+            assert not any("scratch_" in l for l in st)
+            # S chains: an MFMA with a VGPR destination; the LAST one writing a given destination, and the first later non-MFMA reader of it
+            last = {}
+            for i, l in enumerate(st):
+                if l.startswith("v_mfma_f32_32x32x16_bf16 v["):
+                    last[l.split()[1].rstrip(",")] = i
+            assert len(last) == 2 * nb, last
+            full = lines[bars[k]:bars[k + 2]]                      # the readers of the last chains sit in the next step
+            for dst, i in last.items():
+                regs = _regs(dst)
+                for m in range(i + 1, len(full)):
+                    t = full[m]
+                    if t.startswith("v_mfma"):
+                        continue
+                    if any(_regs(x) & regs for x in re.findall(r"v\[\d+:\d+\]|v\d+", t)):
+                        assert m - i >= min_gap, f"NB {nb} step {k}: `{t}` reads {dst} only {m - i} instructions behind the chain's last MFMA"
+                        break
+                else:
+                    raise AssertionError(f"no reader of {dst} found")
