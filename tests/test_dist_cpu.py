@@ -214,3 +214,32 @@ def test_split_batches():
     assert split_batches(b, 2) == [b[:2], b[2:]]
     assert split_batches(b, 3) == [b[:2], [b[2]], [b[3]]]
     assert split_batches(b, 8)[4:] == [[], [], [], []]
+
+
+def test_bench_frame_checksums_name_the_frame():
+    """bench.py's single-clip self-validation sends 8 bytes per frame: equal bits give equal sums on every rank, ONE flipped bit anywhere in a frame
+    changes that frame's sum and no other, for both element sizes, and an empty share is an empty vector."""
+    import importlib.util
+    import os
+
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g = torch.Generator().manual_seed(3)
+    for dtype, itype in ((torch.bfloat16, torch.int16), (torch.float32, torch.int32)):
+        x = torch.randn(1, 3, 5, 24, 40, generator=g).to(dtype)
+        ref = bench.frame_checksums(x)
+        assert ref.dtype == torch.int64 and ref.shape == (5,)
+        assert torch.equal(ref, bench.frame_checksums(x.clone()))
+        for (c, f, h, w, bit) in ((0, 0, 0, 0, 0), (2, 3, 23, 39, 7), (1, 4, 11, 17, 14)):
+            y = x.clone()
+            y.view(itype)[0, c, f, h, w] ^= (1 << bit)
+            got = bench.frame_checksums(y)
+            assert [i for i in range(5) if got[i] != ref[i]] == [f]
+        # a frame that moved to another slot is seen as well (the weights are per position inside a frame, the comparison is per slot)
+        z = x.clone()
+        z[:, :, [1, 2]] = x[:, :, [2, 1]]
+        got = bench.frame_checksums(z)
+        assert [i for i in range(5) if got[i] != ref[i]] == [1, 2]
+    assert bench.frame_checksums(torch.zeros(1, 3, 0, 8, 8, dtype=torch.bfloat16)).numel() == 0
