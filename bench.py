@@ -130,6 +130,8 @@ def main():
                          "never the headline: the line says so in `dtype` and `config.variant`")
     ap.add_argument("--dit-attention", choices=["bf16", "mxfp8"], default="bf16",
                     help="same configs[4] variant: attention products on the block-scaled fp8 MFMA; never the headline")
+    ap.add_argument("--vae-streams", type=int, choices=[1, 2], default=None,
+                    help="HIP streams the VAE's frame-batches alternate on (default: the product's, 2); 1 for the A/B")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (never headline) MXFP8 measurement of the N=1 line")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="debug only: play the N ranks as N processes on GPU 0 over gloo (RCCL refuses two ranks on one device) to "
@@ -176,6 +178,8 @@ def main():
                                          dit_attention_precision=args.dit_attention)
     torch.cuda.synchronize()
     t_build = time.time() - t_build
+    if args.vae_streams is not None:
+        pipe.vae.n_streams = args.vae_streams
 
     up = 4
     strong = args.single_clip and use_dist
@@ -211,6 +215,25 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_profiler(None)
+    # The product runs the VAE's frame-batches on two HIP streams: an event pair around a launch then also spans the time the kernel shared the
+    # chip with the other stream's kernels.  The roofline's per-launch durations therefore come from a ONE-stream pass of the same process,
+    # right behind the timed region (same clip, same weights, same launches); the line carries both and says which is which.
+    prof_records, prof_steps, prof_elapsed, prof_note = records, args.steps, elapsed, "the timed region (one HIP stream)"
+    if pipe.vae.n_streams >= 2 and not strong:
+        keep_streams, pipe.vae.n_streams = pipe.vae.n_streams, 1
+        prof_records, prof_steps = [], max(1, min(args.steps, 3))
+        step()
+        ops.set_profiler(prof_records)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        prof_elapsed = time.perf_counter() - tp0
+        ops.set_profiler(None)
+        pipe.vae.n_streams = keep_streams
+        prof_note = (f"a ONE-stream pass of {prof_steps} step(s) of this process right behind the timed region ({prof_elapsed / prof_steps * 1e3:.1f} ms per clip "
+                     f"against {elapsed / args.steps * 1e3:.1f} in the two-stream timed region, where an event pair also spans co-scheduled kernels of the other stream)")
     per_rank = [elapsed]
     observed_world, gpu_ids = 1, [torch.cuda.get_device_properties(dev).name + f" #{local}"]
     if use_dist:
@@ -306,12 +329,14 @@ def main():
             ms = sum(r[2].elapsed_time(r[3]) for r in recs)
             return fl, ms
         DOM = "conv3x3_halo4x_kernel"
-        dom = [r for r in records if r[4] == DOM]
+        dom = [r for r in prof_records if r[4] == DOM]
         dom_fl, dom_ms = agg(dom)
-        tot_fl, tot_ms = agg(records)
+        tot_fl, tot_ms = agg(prof_records)
         dom_fl_alg, _ = agg(dom, 1)
+        dom_timed = [r for r in records if r[4] == DOM]
+        dom_ms_timed = agg(dom_timed)[1]
         by = {}
-        for key, _fl_alg, e0, e1, var, fl in records:
+        for key, _fl_alg, e0, e1, var, fl in prof_records:
             k = f"{var}:cin{key[0]}_cout{key[1]}_taps{key[2]}"
             a = by.setdefault(k, [0.0, 0.0, 0])
             a[0] += fl
@@ -333,7 +358,7 @@ def main():
             # name the library reports now, with the launch count per clip this run just observed (a kernel that was renamed, split or
             # re-dispatched since the PMC pass makes the numbers stale - then the fields stay null and say why)
             pk = pj.get("per_kernel", {}).get(DOM)
-            seen = len(dom) // max(args.steps, 1)
+            seen = len(dom) // max(prof_steps, 1)
             from dove_amd.lib import kernel_source_sha256
             tree = kernel_source_sha256()
             if pj.get("kernel_source_sha256") != tree:
@@ -362,6 +387,10 @@ def main():
             "config": {"workload": f"synthetic {args.frames}x{args.height}x{args.width} HR clip (LR {args.height//up}x{args.width//up}, 4x), "
                                    f"one-step t=399, CogVideoX1.5-5B VAE + {t['num_layers']}-layer DiT random-init, " + ("ONE clip sharded over all GPUs (BASELINE configs[2])" if strong else "1 clip per GPU (BASELINE configs[1])"),
                        "tokens": macs["tokens"], "pflop_per_clip": macs["flop"] / 1e15,
+                       # the arithmetic that was timed: pack-time weight sums ON = first-frame temporal taps, sub-pixel upsample convs and frame pairs
+                       # multiply by fp32 sums of the bf16 taps rounded once (fewer MACs; inside every parity gate); OFF = the reference's per-tap
+                       # arithmetic (pipe.vae.weight_sums = False / DOVE_OPT_WEIGHT_SUMS), timed below as a variant
+                       "weight_sums": bool(pipe.vae.weight_sums), "vae_streams": int(pipe.vae.n_streams),
                        "variant": "headline (bf16)" if headline else "BASELINE configs[4]: fp8 DiT " + " + ".join(fp8_parts) + ", NOT the headline dtype"},
             "frames_per_s_per_gpu": value / world,
             "ranks": {"world_size_observed": observed_world, "gpus": gpu_ids,
@@ -371,18 +400,20 @@ def main():
             "whole_path_tflops_issued_per_gpu": (macs["flop"] * args.steps - sum(r[1] - r[5] for r in records)) / elapsed / 1e12,
             "roofline": {"bound": "mfma", "kernel": DOM + " (persistent LDS-halo implicit-GEMM 3x3(x3) conv, bf16 MFMA 16x16x32)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": traffic, "traffic_source": pmc_src, "launches": len(dom) // max(args.steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
+                         "traffic": traffic, "traffic_source": pmc_src, "launches": len(dom) // max(prof_steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
+                         "durations_from": prof_note,
+                         "avg_launch_ms_timed_region": dom_ms_timed / max(len(dom_timed), 1),
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
                          "flops_counted": "MFMA work actually issued; the reference's formulation of the same launches is "
                                           f"{dom_fl_alg / max(dom_fl, 1):.4f} x that (first-frame temporal sums, sub-pixel upsample convs skip duplicate taps)",
                          "achieved_algorithmic": dom_fl_alg / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
-                         "share_of_step_time": dom_ms / (elapsed * 1e3),
+                         "share_of_step_time": dom_ms / (prof_elapsed * 1e3),
                          # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs) from profiles/pmc_traffic.json
                          # (separate rocprofv3 --pmc pass over this command, tools/runs/gpu_pmc_bench.sh)
                          "mfma_pipe_busy_frac_pmc": pmc_busy,
                          "all_igemm_kernels": {"achieved": all_igemm, "frac": all_igemm / MFMA_BF16_PEAK_TFLOPS,
-                                               "share_of_step_time": tot_ms / (elapsed * 1e3), "launches": len(records) // max(args.steps, 1)},
-                         "top_classes": {k: {"ms": a[1] / args.steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // args.steps}
+                                               "share_of_step_time": tot_ms / (prof_elapsed * 1e3), "launches": len(prof_records) // max(prof_steps, 1)},
+                         "top_classes": {k: {"ms": a[1] / prof_steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // prof_steps}
                                          for k, a in top}},
             "model_build_s": t_build,
         }
@@ -441,19 +472,41 @@ def main():
                 barrier()
                 return time.perf_counter() - tv0, o
 
-            # (a) the attention fast path is WEIGHT-DEPENDENT: heads whose score bound 1.01 sqrt(max|q|^2 max|k|^2) is <= 40 run the softmax
-            # with a constant shift (csrc/attention.hip), the others with a running maximum.  Report which heads did in this run (random-
-            # init weights: LayerNorm gains of 1) and what the clip costs when NO head may (norm2 = NULL): a checkpoint with large q / k
-            # gains lands between the two lines
+            # (a) the attention fast path: every head starts on the no-shift pipelined kernel (csrc/attention_pipe.hip); a head whose row sums
+            # leave that kernel's window is recomputed with the running maximum inside the same call.  Score bounds <= 80 cannot (random-init
+            # weights: ~12); above, it depends on the real scores.  Report which heads did what in this run, the same clip with the q / k
+            # LayerNorm gains x 3 each (scores x 9, bound ~108: the regime where the window is CHECKED, not guaranteed), and the clip with the
+            # running maximum in every head (norm2 = NULL): the floor
             tr = pipe.transformer
-            tr.attn_bound_trace = []
-            step()
-            torch.cuda.synchronize()
-            b_all = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
-            tr.attn_bound_trace = None
-            res["attention"] = {"fixed_shift_heads_frac": float((b_all <= 40.0).float().mean()), "score_bound_max": float(b_all.max()),
-                                "score_bound_median": float(b_all.median()), "cutoff": 40.0, "heads_x_layers": int(b_all.numel()),
-                                "note": "share of (layer, head) pairs whose attention ran with the constant-shift softmax in this run; depends on the weights"}
+
+            def path_shares():
+                tr.attn_bound_trace, tr.attn_path_trace = [], []
+                step()
+                torch.cuda.synchronize()
+                b_ = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
+                on_pipe = torch.stack([torch.isfinite(n2[:, 0] * n2[:, 1]) for n2 in tr.attn_path_trace]).float().cpu()
+                tr.attn_bound_trace = None
+                return b_, float(on_pipe.mean())
+
+            b_all, share = path_shares()
+            res["attention"] = {"no_shift_heads_frac": share, "score_bound_max": float(b_all.max()),
+                                "score_bound_median": float(b_all.median()), "guaranteed_below": 80.0, "heads_x_layers": int(b_all.numel()),
+                                "note": "share of (layer, head) pairs the no-shift pipelined kernel finished in this run; a head is handed to the "
+                                        "running maximum only when one of its un-shifted row sums leaves [2^-80, 2^100]"}
+            qk = [blk[nm][j] for blk in tr.blocks for nm in ("nq", "nk") for j in (0, 1)]
+            keep = [w_.clone() for w_ in qk]
+            for w_ in qk:
+                w_.mul_(3.0)
+            b3, share3 = path_shares()
+            tv3, _ = timed_variant()
+            for w_, k_ in zip(qk, keep):
+                w_.copy_(k_)
+            del keep
+            res["variants"].append({
+                "name": "q / k LayerNorm gains and biases x 3 each (every score x 9; score bound median "
+                        f"{float(b3.median()):.0f}, max {float(b3.max()):.0f} - above the 80 up to which the no-shift kernel needs no check)",
+                "dtype": "bf16", "value": vsteps * args.frames / tv3, "unit": "frames/s", "steps": vsteps, "ms_per_step": tv3 / vsteps * 1e3,
+                "speedup_vs_headline_this_run": (vsteps * args.frames / tv3) / value, "no_shift_heads_frac": share3})
             tr.attn_score_bound = False
             tv, o_rm = timed_variant()
             tr.attn_score_bound = True
@@ -464,6 +517,16 @@ def main():
                 "psnr_vs_headline_output_db": float(10 * torch.log10(1.0 / (((o_rm.float() - out.float()) ** 2).mean() + 1e-12))),
                 "psnr_note": "same function, other summation order in the softmax; 42 random-init layers amplify last-bit differences (the 2-layer "
                              "agreement gate is tests/test_parity_gpu.py::test_dit_mixed_softmax_paths_wide_qk_gains)"})
+            # (a') the cost of exactness: no pack-time weight sum anywhere - every conv launch computes the reference's per-tap arithmetic
+            pipe.vae.weight_sums = False
+            tvw, o_w = timed_variant()
+            pipe.vae.weight_sums = True
+            res["variants"].append({
+                "name": "pipe.vae.weight_sums = False: the reference's per-tap conv arithmetic (no first-frame / sub-pixel / frame-pair weight sums)",
+                "dtype": "bf16", "value": vsteps * args.frames / tvw, "unit": "frames/s", "steps": vsteps, "ms_per_step": tvw / vsteps * 1e3,
+                "speedup_vs_headline_this_run": (vsteps * args.frames / tvw) / value,
+                "psnr_vs_headline_output_db": float(10 * torch.log10(1.0 / (((o_w.float() - out.float()) ** 2).mean() + 1e-12)))})
+            del o_w
             # (b) the reference's PUBLISHED configuration: --is_vae_st = pipe.vae.enable_slicing() + enable_tiling() (inference.sh:8,
             # inference_script.py:642-645): 4 x 5 overlapping 240x360-px tiles per VAE stage, blended.  Tiling recomputes the overlaps
             # (FLOP ratio below), so "ideal" = the untiled clip time with the VAE share scaled by that ratio

@@ -1,7 +1,8 @@
 // Flash-attention forward for the CogVideoX DiT joint [text ; video] self-attention (gfx950): the entry point dove_attention_fwd_bf16 and the
-// RUNNING-MAXIMUM kernel.  Since round 5 the heads whose scores the caller bounds by 40 (norm2: every head of the DiT with unit LayerNorm gains)
-// run on the software-pipelined kernel of attention_pipe.hip; this kernel keeps the others - and every head when no bound is given - and exits
-// at once for a head the other kernel owns.  Its own constant-shift loop (below) is what the timing library's DOVE_ATTN_PIPE=0 A/B runs.
+// RUNNING-MAXIMUM kernel.  Heads the caller hands a finite score bound for (norm2) run on the software-pipelined no-shift kernel of
+// attention_pipe.hip first (round 5: bound <= 40; round 6: every finite bound, the row sums checked in that kernel's epilogue); this kernel
+// keeps the heads that one marked NaN, the heads whose bound was not finite - and every head when no bound is given - and exits at once for a
+// head the other kernel finished.  Its own constant-shift loop (below) is what the timing library's DOVE_ATTN_PIPE=0 A/B runs.
 //   head_dim 64, bf16 MFMA 32x32x16, fp32 online softmax, non-causal, no mask, N not a tile multiple.
 // Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0, reached from
 // /root/reference/inference_script.py:483-489.
@@ -40,7 +41,7 @@
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __attribute__((visibility("hidden"))) int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
-                                                                    int heads, long long ldo, const float* norm2, void* stream);   // attention_pipe.hip
+                                                                    int heads, long long ldo, float* norm2, void* stream);   // attention_pipe.hip
 
 __device__ __forceinline__ bf16x8 make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -85,6 +86,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     qb = blockIdx.x;
   }
   const long long q0 = (long long)qb * (NW * 32) + wave * 32;
+  // skip_bounded: attn_pipe_kernel (attention_pipe.hip) ran first on every head with a finite bound and marked the ones it could not finish
+  // NaN; this kernel keeps the marked ones and those whose bound was NaN / infinite to begin with.  (Before any load: ~6.9 k workgroups of a
+  // DiT attention call leave here.)
+  if (bound && skip_bounded && bound[2 * h] * bound[2 * h + 1] < __builtin_inff()) return;
 
   bf16x8 qf[4];
   {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
   // 2^-2b, and 2^-80 keeps P, l and the P V products far inside the NORMAL fp32 / bf16 range (60, the first cutoff, left 2^-120 - six binades
   // above the denormals, less than |v| can take away; LayerNorm'd q / k give b ~ 12).
   bool fixed = FIXED;
-  if (bound) {
+  if (bound && !skip_bounded) {       // (timing library only: DOVE_ATTN_PIPE=0 - the constant-shift loop of rounds 3-4 for the A/B)
     const float b = FIXED ? bound[h] : 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);   // [head][q, k]: max squared row norms
     fixed = FIXED || b <= 40.0f;      // NaN compares false: the running maximum
     if (fixed) {
@@ -114,8 +119,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
     }
   }
   fixed = __builtin_amdgcn_readfirstlane(fixed);
-  // skip_bounded: the bounded heads of this launch run on attn_pipe_kernel (attention_pipe.hip); this kernel keeps the others
-  if (fixed && skip_bounded) return;
 
   const int ntiles = (int)((N + 63) / 64);
   const int srow = tid >> 3;
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __re
 }
 
 extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N,
-                                        long long Npad, int heads, int head_dim, long long ldo, const float* norm2, void* stream) {
+                                        long long Npad, int heads, int head_dim, long long ldo, float* norm2, void* stream) {
   DOVE_CHECK_ARG(Qh && Kh && Vt && O, "attention_fwd: null pointer");
   DOVE_CHECK_ARG(head_dim == 64, "attention_fwd: head_dim must be 64 (got %d)", head_dim);
   DOVE_CHECK_ARG(N > 0 && Npad % 128 == 0 && Npad >= N && Npad - N < 128, "attention_fwd: Npad must be N rounded up to 128");
@@ -297,9 +300,10 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
 #ifdef DOVE_TIMING_BUILD
   { const char* e = getenv("DOVE_ATTN_BOUND"); if (e && atoi(e) == 0) norm2 = nullptr; }   // tools/e2e_env_ab.py: running maximum vs bound
 #endif
-  // With a score bound per head (norm2) the heads it bounds by 40 run on the software-pipelined kernel (attention_pipe.hip: one wave per SIMD,
-  // no shift needed), the others - and every head when no bound is given - here on the running maximum.  Both kernels decide per head from
-  // the same two numbers, so each output row is written by exactly one of them.
+  // With a score bound per head (norm2) every head whose bound is finite runs on the software-pipelined kernel (attention_pipe.hip: one wave
+  // per SIMD, no shift), which marks norm2[2 h] NaN for a head whose row sums left its safe window; those, the heads with a non-finite bound -
+  // and every head when no bound is given - run here on the running maximum, AFTER the other kernel on the same stream: the final contents of
+  // every output row come from exactly one of them, and norm2 says which (dove_attention_head_paths).
   int skip_bounded = 0;
   if (norm2) {
     skip_bounded = 1;
@@ -316,6 +320,13 @@ extern "C" int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const voi
   DOVE_CHECK_LAUNCH("dove_attention_fwd_bf16");
   return DOVE_OK;
 }
+
+extern "C" int dove_attention_head_paths(const float* norm2_host, int heads, int* path) {
+  DOVE_CHECK_ARG(path && heads >= 0, "attention_head_paths: bad arguments");
+  for (int h = 0; h < heads; ++h) path[h] = norm2_host && norm2_host[2 * h] * norm2_host[2 * h + 1] < __builtin_inff() ? 1 : 0;   // the kernels' own test
+  return DOVE_OK;
+}
+extern "C" const char* dove_attention_path_name(int path) { return path == 1 ? "attn_pipe_kernel" : path == 0 ? "attn_fwd_kernel" : ""; }
 
 #ifdef DOVE_TIMING_BUILD
 // tools/archive/attn_nw.py: the same kernel with 4 / 6 / 8 waves per workgroup (occupancy 2 / 3 / 4 waves per SIMD by LDS) on the 2-D grid, and

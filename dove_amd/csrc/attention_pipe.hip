@@ -1,6 +1,9 @@
-// Flash-attention forward, BOUNDED-SCORE path of dove_attention_fwd_bf16 (every head of the DiT whose LayerNorm'd q / k give a score bound
-// 1.01 sqrt(max |q|^2 max |k|^2) <= 40 - all of them with unit gains; replaces F.scaled_dot_product_attention inside diffusers'
-// CogVideoXAttnProcessor2_0, /root/reference/inference_script.py:483-489) in the one-wave-per-SIMD software-pipelined structure of the CDNA4 guide
+// Flash-attention forward, NO-SHIFT path of dove_attention_fwd_bf16: every head the caller hands a finite score bound for (norm2) runs here
+// first, WITHOUT a softmax shift; a head one of whose row sums leaves the window in which that is exact to rounding (attn_pipe::kRowSumMin /
+// kRowSumMax below: impossible for a bound <= 80, i.e. every head of the DiT with LayerNorm gains up to ~2.5 x unit; not observed on real
+// scores far above that, since the Cauchy-Schwarz bound is loose) marks itself NaN in norm2 and is recomputed by attn_fwd_kernel's running
+// maximum in the same call.  Replaces F.scaled_dot_product_attention inside diffusers' CogVideoXAttnProcessor2_0,
+// /root/reference/inference_script.py:483-489.  The one-wave-per-SIMD software-pipelined structure of the CDNA4 guide
 // (cdna_hip_programming.md "4-wave, one-wave-per-SIMD, persistent structure"; MI355X_MICROARCH "single-issue instructions HIDDEN per
 // v_mfma_f32_32x32x16_bf16 gap: <= 5"): on gfx950 the VALU work of one wave hides under the MFMAs of the SAME wave's stream and not under
 // another wave's (tools/archive/coissue.py) - attn_fwd_kernel (two waves per SIMD, each QK^T -> softmax -> PV in turn) adds its 16 MFMAs and its
@@ -10,9 +13,9 @@
 //   * software pipeline over the KV tiles inside the wave: a step issues the 16 QK^T MFMAs of tile j + 1 and the 16 PV MFMAs of tile j, and
 //     behind every MFMA a fixed handful of the softmax instructions of tile j (8 chunks of {8 v_exp, 4 v_cvt_pk, 8 v_add} = one P^T fragment
 //     each; a chunk spans 4 MFMA slots), pinned by sched_barrier;
-//   * no shift: with every score of the head bounded by b <= 40 (the caller's norm bound, as in the product) 2^s <= 2^40 and the row sums stay
-//     below 2^55 - far inside fp32 / bf16 range - and the constant 2^-b the product multiplies in cancels in O / l.  The S chains start from
-//     the inline constant 0;
+//   * no shift: softmax is shift-invariant and fp32 / bf16 carry 8 exponent bits, so 2^s itself serves as long as the row sum stays in the
+//     window below (round 5 took a static bound b <= 40 for that; round 6 checks the row sums themselves - one compare per row in the
+//     epilogue - so the fast path no longer depends on the weights' LayerNorm gains).  The S chains start from the inline constant 0;
 //   * register files chosen by hand (asm MFMAs, asm ds_reads): S in VGPRs (the exponentials read it), O, the Q fragments AND the K / V^T
 //     fragments in AGPRs (only MFMAs touch them; LDS loads write AGPRs directly) - as builtins / plain loads the allocator moves S through
 //     v_accvgpr_read (64 extra issues per step) or runs out of VGPRs;
@@ -23,8 +26,8 @@
 //     fragments are read half a step ahead of their MFMAs, four counted lgkmcnt waits per step;
 //   * the tile loop runs to a multiple of four steps: tiles at and past the ragged end are masked to -inf before their exponentials, so a
 //     step on a tile that does not exist adds zeros - no tail variants, no copies of O at region boundaries.
-// Operand layout: dove_qkv_post_bf16's (v_order 1), as attn_fwd_kernel.  Heads whose bound is above the cutoff (or NaN) are LEFT UNTOUCHED:
-// dove_attention_fwd_bf16 runs them on attn_fwd_kernel's running maximum.
+// Operand layout: dove_qkv_post_bf16's (v_order 1), as attn_fwd_kernel.  Heads whose bound is NaN or infinite are LEFT UNTOUCHED, heads that
+// mark themselves may be partly written: dove_attention_fwd_bf16 runs both kinds on attn_fwd_kernel's running maximum afterwards (whole heads).
 // The last partial round of workgroups runs the one-block-per-wave form (NB = 1): 3.298 vs 3.341 ms at N = 18 226, 48 heads (profiles/r05_attn_tail.log).
 // Measured (tools/attn2p_ab.py on the experiment twin tools/exp/attn2p_exp.hip, N = 18 226, 48 heads, within one process, profiles/r05_attn2p_*.log):
 // 3.52 ms against attn_fwd_kernel's 3.77-3.96 ms by box (x 0.89-0.93; 1.16 PF), 2.56 vs 2.95 ms on all-zero operands; by parts (ns per step of
@@ -81,6 +84,12 @@ __device__ __forceinline__ uint32_t cvtpk(float lo, float hi) {
 
 namespace attn_pipe {
 constexpr int SLOT = 8192, VBASE = 4 * SLOT, LDS = 8 * SLOT;    // K slots 0-3 at 0 .. 24 KB, V^T slots 0-3 at 32 .. 56 KB
+// Safe window of a row's UN-SHIFTED sum l = sum_j 2^s_ij, checked once per row in the epilogue.
+//   l <= 2^100: no 2^s overflowed (that leaves inf or NaN in l) and O = sum_j p_j v_j <= l max |v| stays finite for |v| < 2^27;
+//   l >= 2^-80: whatever flushed to zero below 2^-126 sums to < N 2^-126 <= 2^-102 (N < 2^24: the 31-bit buffer offsets), a 2^-22 share of
+//   l, and every term that matters is a normal fp32 / bf16 number with its full relative precision.
+// A score bound |s| <= b <= 80 implies N 2^-80 <= l <= N 2^80, inside the window for every N < 2^20: for such heads the check cannot fire.
+constexpr float kRowSumMin = 0x1p-80f, kRowSumMax = 0x1p100f;
 }
 
 // NB = query blocks of 32 per wave.  2: the kernel described above (256 queries per workgroup).  1: the same pipeline with one block per
@@ -90,7 +99,7 @@ constexpr int SLOT = 8192, VBASE = 4 * SLOT, LDS = 8 * SLOT;    // K slots 0-3 a
 template <int NB>
 __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vt,
                                                         bf16_t* __restrict__ O, long long N, long long Npad, long long ldo, int qblocks,
-                                                        const float* __restrict__ bound, int item0) {
+                                                        float* bound, int item0) {
   using namespace attn_pipe;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -99,10 +108,7 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   // NB == 2: one item per workgroup, XCD-contiguous over this launch's items; NB == 1: two workgroups per item (query halves)
   const unsigned t = NB == 2 ? (unsigned)item0 + xcd_remap(blockIdx.x, gridDim.x) : (unsigned)item0 + (blockIdx.x >> 1);
   const int h = (int)(t / (unsigned)qblocks), qb = (int)(t - (unsigned)h * (unsigned)qblocks);
-  {
-    const float b = 1.01f * sqrtf(bound[2 * h] * bound[2 * h + 1]);
-    if (!(b <= 40.0f)) return;                                 // (NaN compares false) the running-maximum kernel owns this head
-  }
+  if (!(bound[2 * h] * bound[2 * h + 1] < __builtin_inff())) return;   // NaN (also: marked by a workgroup below) or infinite: the running-maximum kernel owns this head
   const long long q0 = NB == 2 ? (long long)qb * 256 + wave * 64                      // block A: q0 .. q0 + 31, block B: q0 + 32 .. q0 + 63
                                : (long long)qb * 256 + (blockIdx.x & 1) * 128 + wave * 32;
 
@@ -311,6 +317,8 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const long long q = q0 + x * 32 + l31;
+    // the un-shifted row sum must have stayed where fp32 / bf16 lose nothing (header): outside, the head is handed to the running maximum
+    if (q < N && !(l >= kRowSumMin && l <= kRowSumMax)) bound[2 * h] = __builtin_nanf("");
     if (q < N) {
       bf16_t* op = O + q * ldo + h * 64;
 #pragma unroll
@@ -327,8 +335,8 @@ __global__ __launch_bounds__(256, 1) void attn_pipe_kernel(const bf16_t* __restr
   });
 }
 
-// Launch for the heads whose score bound (norm2: [heads][2] = max |q|^2, max |k|^2) is at most 40; the other heads' output rows are left
-// untouched (dove_attention_fwd_bf16 runs them on attn_fwd_kernel).  Same operand contract as dove_attention_fwd_bf16.
+// Launch for the heads whose score bound (norm2: [heads][2] = max |q|^2, max |k|^2) is finite; norm2[2 h] becomes NaN for a head that has to be
+// recomputed (dove_attention_fwd_bf16 runs those on attn_fwd_kernel).  Same operand contract as dove_attention_fwd_bf16.
 // Items = (head, 256-query block) in head-major order.  Whole rounds of `cus` items run one per workgroup; a last partial round of at most
 // half the CUs runs as twice as many one-block-per-wave workgroups (NB = 1), which take about 0.55 of a round.
 static int pipe_cu_count() {
@@ -344,7 +352,7 @@ static int pipe_cu_count() {
   return n;
 }
 __attribute__((visibility("hidden"))) int dove_attention_pipe_launch(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
-                                                                    int heads, long long ldo, const float* norm2, void* stream) {
+                                                                    int heads, long long ldo, float* norm2, void* stream) {
   static PerDeviceOnce attr_set;
   if (auto once_ = attr_set.guard()) {
     (void)hipFuncSetAttribute((const void*)attn_pipe_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, attn_pipe::LDS);

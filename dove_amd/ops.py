@@ -428,15 +428,31 @@ def ulysses_place(rq, rk, rv, counts, hloc, N, Npad, Qh, Kh, Vt, norm2_out=None)
 
 
 def attention(Qh, Kh, Vt, N, Npad, heads, out, norm2=None):
-    """``norm2`` (fp32 [heads, 2] of THESE heads, from the ``qkv_post`` call that produced Qh / Kh - or the element-wise maximum over the
-    ranks sharing the rows): constant-shift softmax instead of the running maximum.  A stale or sliced array that under-states the norms
-    silently breaks the softmax scaling (include/dove_hip.h): pass None when in doubt."""
+    """``norm2`` (fp32 [heads, 2], IN/OUT; from the ``qkv_post`` call that produced Qh / Kh - or the element-wise maximum over the ranks
+    sharing the rows): heads with finite entries run on the software-pipelined no-shift kernel; a head whose row sums leave that kernel's
+    safe window is marked NaN in ``norm2[h, 0]`` and recomputed with the running maximum inside the same call (include/dove_hip.h).  None:
+    the running maximum in every head.  ``attention_head_paths(norm2)`` afterwards names the kernel that produced each head."""
     L.require_cuda(Qh, Kh, Vt, out, norm2)
     if norm2 is not None:
         assert norm2.dtype == torch.float32 and norm2.shape == (heads, 2) and norm2.is_contiguous()
     L.check(L.load().dove_attention_fwd_bf16(L.ptr(Qh), L.ptr(Kh), L.ptr(Vt), L.ptr(out), N, Npad, heads, 64, out.shape[1], L.ptr(norm2),
                                              L.stream_ptr()), "dove_attention_fwd_bf16")
     return out
+
+
+def attention_head_paths(norm2, heads=None):
+    """Kernel names, one per head, of the ``attention`` call that was handed ``norm2`` (read AFTER the call; synchronises).  ``norm2=None``
+    with ``heads``: a call without bounds."""
+    lib = L.load()
+    if norm2 is None:
+        host, n = None, int(heads)
+    else:
+        host = norm2.detach().float().cpu().contiguous()
+        n = host.shape[0]
+    path = (C.c_int * n)()
+    L.check(lib.dove_attention_head_paths(None if host is None else C.cast(host.data_ptr(), C.POINTER(C.c_float)), n, path),
+            "dove_attention_head_paths")
+    return [lib.dove_attention_path_name(int(v)).decode() for v in path]
 
 
 def qkv_post_mx(qkv, N, Npad, heads, text_len, gq, bq, gk, bk, cos, sin, qscale, eps, Q8, K8, V8t, Vs):

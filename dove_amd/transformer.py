@@ -57,11 +57,13 @@ class CogVideoXTransformer3DModel:
             raise ValueError(f"attention_precision must be 'bf16' or 'mxfp8', got {attention_precision!r}")
         self.linear_precision = linear_precision
         self.attention_precision = attention_precision
-        # the bf16 attention kernel takes a per-head score bound from qkv_post and runs heads whose bound is <= 40 with a CONSTANT softmax
-        # shift (csrc/attention.hip): which heads do depends on the weights (the q / k LayerNorm gains).  False hands no bound over: every
-        # head keeps the running maximum (bench.py times both and reports the fraction; results agree to fp32 rounding of the row sums)
+        # the bf16 attention takes the per-head norm array of qkv_post and runs every head with finite entries on the pipelined no-shift kernel
+        # (csrc/attention_pipe.hip); a head whose row sums leave that kernel's window is recomputed with the running maximum in the same call
+        # (never for score bounds <= 80; data-dependent above).  False hands no array over: every head keeps the running maximum (bench.py
+        # times both and reports the share of heads per path; results agree to fp32 rounding of the row sums)
         self.attn_score_bound = True
         self.attn_bound_trace = None      # a list: every layer appends its [heads, 2] bound array (bench.py: share of heads on the fast path)
+        self.attn_path_trace = []         # filled beside it: the same array AFTER the attention call (ops.attention_head_paths: which kernel served)
         self._mod_cache = {}
         self._bufs = {}
         self._pack(state_dict)
@@ -238,6 +240,8 @@ class CogVideoXTransformer3DModel:
                 if self.attn_bound_trace is not None:
                     self.attn_bound_trace.append(norm2.clone())
                 att = ops.attention(Qh, Kh, Vt, N, npad, Lh, n1, norm2=norm2 if self.attn_score_bound else None)   # reuse n1's storage for the attention output
+                if self.attn_bound_trace is not None:               # after the call: a head the pipelined kernel handed back is NaN in column 0
+                    self.attn_path_trace.append(norm2.clone() if self.attn_score_bound else torch.full_like(norm2, float("nan")))
             big(att, blk["out"], resid=hs, gate=md["gate1"], gate_split=Lt, out=hs)
             n2 = ops.layernorm_modulate(hs, blk["ln2"][0], blk["ln2"][1], self.eps, md["m2"], Lt, out=n1)
             f1 = big(n2, blk["ff1"], act=1)

@@ -99,10 +99,12 @@ class AutoencoderKLCogVideoX:
         self.dec_batch = c.get("num_latent_frames_batch_size", 2)
         if c.get("norm_num_groups", 32) != 32:
             raise NotImplementedError("HIP GroupNorm kernels are built for 32 groups")
-        # n_streams = 2 alternates frame-batches on two HIP streams (bit-identical; tests/test_e2e_gpu.py).  Worth +1.4 % with the
-        # persistent conv3x3_halo4x (whose workgroups own a whole CU each, so two convs mostly serialise) - and it makes
-        # per-kernel durations (HIP events, rocprofv3) include co-scheduling waits.  Default 1: clean per-kernel accounting.
-        self.n_streams = 1
+        # n_streams = 2 alternates frame-batches on two HIP streams (bit-identical; tests/test_e2e_gpu.py::test_two_stream_vae_is_bit_identical):
+        # one batch's HBM-bound GroupNorm / glue kernels run beside the other batch's MFMA-bound convs (the persistent conv3x3_halo4x owns a CU
+        # per workgroup, so two convs mostly serialise).  Default since round 6 (+1.4 % per clip; profiles/r06_streams_ab.log).  Per-kernel
+        # durations taken with two streams (HIP events, rocprofv3) include co-scheduling waits: bench.py takes its roofline figures from a
+        # one-stream pass of the same run and says so.
+        self.n_streams = 2
         self._streams = None
         # False: no conv is handed a pack-time weight sum (first-frame temporal sums, sub-pixel upsample sums, frame-pair sums): every launch
         # computes the reference's per-tap arithmetic - for validating a checkpoint without the one extra bf16 rounding of the summed weights

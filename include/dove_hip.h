@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 13
+#define DOVE_ABI_VERSION 14
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -202,15 +202,21 @@ int dove_ulysses_place_bf16(const void* rq, const void* rk, const void* rv, cons
 
 /* F.scaled_dot_product_attention (no mask, non-causal) on the operands above, Vt in QUAD-SWAPPED key order; Qh carries
  * scale*log2(e).  O [N][ldo] token-major, head h at columns [64h, 64h+64).
- * norm2 (may be NULL): float [heads][2] = max squared row norms of this call's Qh / Kh heads (dove_qkv_post_bf16).  With it, every
- * score of head h is bounded by b = 1.01 sqrt(norm2[h][0] norm2[h][1]) (Cauchy-Schwarz) and the softmax runs with that constant shift
- * instead of a running maximum (the constant cancels in O / l): -7 % kernel time.  Heads with b > 40 (a row of all anti-aligned keys has
- * every probability near 2^-2b: 2^-80 stays far inside the normal fp32 / bf16 range), heads with a non-finite bound and calls with
- * norm2 == NULL use the running maximum.  CONTRACT: norm2 must be the array the dove_qkv_post_bf16 call that produced THESE Qh / Kh
- * filled (or the element-wise maximum over the ranks that share the rows): a stale or sliced array that under-states a head's norms
- * makes exp2 overflow for that head's largest scores, with nothing to catch it. */
+ * norm2 (may be NULL; IN/OUT since ABI 14): float [heads][2] = max squared row norms of this call's Qh / Kh heads (dove_qkv_post_bf16).
+ * Every head whose two numbers are finite runs on the software-pipelined kernel WITHOUT a softmax shift (shift-invariance: 2^s itself, the
+ * constant cancels in O / l; -13 % kernel time against the running maximum at N = 18 226).  That is exact to rounding while a row's sum
+ * l = sum_j 2^s_ij stays in [2^-80, 2^100] - guaranteed when the Cauchy-Schwarz bound b = 1.01 sqrt(norm2[h][0] norm2[h][1]) <= 80, and
+ * checked per row otherwise: a head with a row outside the window is marked norm2[h][0] = NaN and recomputed, whole, with the running
+ * maximum inside the same call.  Heads with a non-finite entry on entry and calls with norm2 == NULL use the running maximum.  On return
+ * (stream order) norm2 therefore tells which kernel produced each head (dove_attention_head_paths).  The values only select the path: a
+ * stale array costs time, never correctness (ABI <= 13 used b as the shift itself and needed it to describe THESE Qh / Kh). */
 int dove_attention_fwd_bf16(const void* Qh, const void* Kh, const void* Vt, void* O, long long N, long long Npad,
-                            int heads, int head_dim, long long ldo, const float* norm2, void* stream);
+                            int heads, int head_dim, long long ldo, float* norm2, void* stream);
+/* Which kernel produced each head of a dove_attention_fwd_bf16 call: norm2_host = HOST copy of that call's norm2 taken after it completed
+ * (NULL: the call had none); path[h] = 1 "attn_pipe_kernel" (no shift), 0 "attn_fwd_kernel" (running maximum).  Pure host function.
+ * dove_attention_path_name(path) names them. */
+int dove_attention_head_paths(const float* norm2_host, int heads, int* path);
+const char* dove_attention_path_name(int path);
 
 /* layout glue at the [B,C,T,H,W] boundary (B = 1) */
 int dove_cl_from_ncthw(const void* x, int dtype, int C, long long npix, int Cp, float scale, float shift, void* y,

@@ -310,9 +310,11 @@ def test_qkv_post_and_attention(N, heads, text_len):
     close(f"attention_{N}_{heads}", got, ref, rtol=3e-2, afrac=8e-3)
     # the same product with the constant shift from the bound instead of the running maximum (what the DiT runs)
     nr = torch.stack([(Qr[:, :N].float() ** 2).sum(-1).amax(-1), (Kr[:, :N].float() ** 2).sum(-1).amax(-1)], dim=1).cuda().contiguous()
-    assert float(1.01 * (nr[:, 0] * nr[:, 1]).sqrt().max()) < 60.0
+    assert float(1.01 * (nr[:, 0] * nr[:, 1]).sqrt().max()) < 80.0
+    assert ops.attention_head_paths(None, heads) == ["attn_fwd_kernel"] * heads
     got2 = ops.attention(Qr.cuda(), Kr.cuda(), Vr.cuda(), N, npad, heads, torch.zeros(N, D, dtype=BF, device="cuda"), norm2=nr)
     torch.cuda.synchronize()
+    assert ops.attention_head_paths(nr) == ["attn_pipe_kernel"] * heads      # what the DiT runs: the no-shift pipelined kernel
     close(f"attention_bound_{N}_{heads}", got2, ref, rtol=3e-2, afrac=8e-3)
 
 
@@ -452,11 +454,13 @@ def test_attention_spiked_rows():
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"))
     torch.cuda.synchronize()
     close("attention_spike", got, ref, rtol=3e-2, afrac=8e-3)
-    # with the score bound: the spikes push it far above 40, so these heads must take the running-maximum path by themselves
+    # with the score bound: the spike of query 7 is a score of ~230 - 2^230 overflows the un-shifted exponential, the row sum leaves the
+    # pipelined kernel's window, the head marks itself and the SAME call recomputes it with the running maximum
     n2 = _norm2(Q, K, N).cuda()
-    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().min()) > 40.0
-    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().min()) > 200.0
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.full((N, heads * 64), 7.0, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
+    assert ops.attention_head_paths(n2) == ["attn_fwd_kernel"] * heads and bool(torch.isnan(n2[:, 0]).all())
     close("attention_spike_bound_fallback", got, ref, rtol=3e-2, afrac=8e-3)
 
 
@@ -491,15 +495,21 @@ def test_attention_loose_bound():
     ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
+    assert ops.attention_head_paths(n2) == ["attn_pipe_kernel"] * heads
     close("attention_loose_bound", got, ref, rtol=3e-2, afrac=8e-3)
 
 
-def test_attention_bound_anti_aligned_at_cutoff():
-    """The adversarial case for the constant-shift softmax: EVERY key of a head is anti-aligned with EVERY query (q ~ +a e0, k ~ -a e0), so
-    every score sits at -b / 1.01 and every probability at 2^(-2b) before the normalisation, with b just under the kernel's cutoff (40):
-    2^-78 must still normalise to the exact softmax.  Head 1 has the same structure with b just ABOVE the cutoff: it must fall back to the
-    running maximum inside the same launch.  (norm2 must describe the Qh / Kh of the call: include/dove_hip.h.)"""
-    N, heads = 1000, 2
+def test_attention_no_shift_window_edges():
+    """The adversarial cases for the no-shift softmax of attn_pipe_kernel (one launch, five heads):
+      0  EVERY key anti-aligned with EVERY query (q ~ +a e0, k ~ -a e0), bound just under 80: every score ~ -76, every probability ~ 2^-76
+         before the normalisation, row sums ~ 2^-66 - inside the window, must normalise to the exact softmax ON the pipelined kernel;
+      1  the same with scores ~ -96: row sums ~ 2^-86 < 2^-80 -> the head marks itself and is recomputed with the running maximum;
+      2  every key ALIGNED at +106: row sums ~ 2^116 > 2^100 -> marked, recomputed;
+      3  a bound of ~100 from one long query and one long key that are orthogonal to everything, real scores within +-3: the bound is far
+         above 80 but the row sums are ordinary -> stays on the pipelined kernel (the fast path does not depend on the bound's size);
+      4  as 0, handed over with a NaN bound -> the running maximum from the start.
+    (round 5's form of this test pinned a static cutoff at b = 40.)"""
+    N, heads = 1000, 5
     npad = 1024
     g = torch.Generator().manual_seed(29)
     Q = torch.zeros(heads, npad, 64, dtype=BF)
@@ -507,26 +517,33 @@ def test_attention_bound_anti_aligned_at_cutoff():
     V = torch.zeros(heads, 64, npad, dtype=BF)
     q = torch.randn(heads, N, 64, generator=g) * 0.15
     k = torch.randn(heads, N, 64, generator=g) * 0.15
-    for h, a in enumerate((6.1, 6.6)):
+    for h, (a, sgn) in {0: (8.7, -1.0), 1: (9.8, -1.0), 2: (10.3, 1.0), 4: (8.7, -1.0)}.items():
         q[h, :, 0] = a
-        k[h, :, 0] = -a
+        k[h, :, 0] = sgn * a
+    q[3], k[3] = q[3] * 2, k[3] * 2
+    q[3, 11] = 0
+    q[3, 11, 0] = 10.0
+    k[3, :, 0] = 0
+    k[3, 500] = 0
+    k[3, 500, 1] = 10.0
+    q[3, :, 1] = 0
     Q[:, :N], K[:, :N] = q.to(BF), k.to(BF)
     V[:, :, :N] = torch.randn(heads, 64, N, generator=g).to(BF)
     E.vt_quad_swap(V)
     n2 = _norm2(Q, K, N).cuda()
+    n2[4, 1] = float("nan")
     b = 1.01 * (n2[:, 0] * n2[:, 1]).sqrt()
-    assert 36.0 < float(b[0]) < 40.0 < float(b[1]) < 50.0, b
+    assert 74.0 < float(b[0]) < 80.0 < float(b[1]) and 95.0 < float(b[3]), b
     ref = E.attention(Q, K, V, N, npad, heads, torch.zeros(N, heads * 64, dtype=BF))
-    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
+    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.full((N, heads * 64), 7.0, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
+    assert ops.attention_head_paths(n2) == ["attn_pipe_kernel", "attn_fwd_kernel", "attn_fwd_kernel", "attn_pipe_kernel", "attn_fwd_kernel"], n2
     assert bool(torch.isfinite(got).all())
-    close("attention_anti_aligned", got, ref, rtol=3e-2, afrac=8e-3)
-    # a non-finite bound must not select the constant shift
-    bad = n2.clone()
-    bad[0, 0] = float("nan")
-    got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=bad)
+    close("attention_window_edges", got, ref, rtol=3e-2, afrac=8e-3)
+    # a second call with the array the first one marked: the marked heads go straight to the running maximum, same result
+    got2 = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.full((N, heads * 64), 7.0, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
-    close("attention_nan_bound", got, ref, rtol=3e-2, afrac=8e-3)
+    assert torch.equal(got, got2)
 
 
 def test_conv_subpixel_is_the_kernel_and_matches_direct_form():
@@ -613,8 +630,10 @@ def test_conv_and_linear_fullsize_properties():
     torch.cuda.synchronize()
 
 
-def test_attention_fullsize_properties():
-    """N = 18 226 tokens x 48 heads (the headline clip): properties that need no reference at that size.
+@pytest.mark.parametrize("with_bound", [False, True], ids=["running_max", "norm2_pipe"])
+def test_attention_fullsize_properties(with_bound):
+    """N = 18 226 tokens x 48 heads (the headline clip), on the running-maximum kernel (no bound) and on the production path (norm2 ->
+    attn_pipe_kernel, asserted): properties that need no reference at that size.
     (i) rows of softmax sum to one: V = 1 must give 1 (P is rounded to bf16 before PV while the normaliser is fp32: 2^-7);
     (ii) exact linearity in V for power-of-two scales: attention(Q, K, 2V) == 2 * attention(Q, K, V) bit for bit;
     (iii) keys in the zero-padded tail (columns N..Npad) never contribute: poisoning them changes nothing."""
@@ -632,17 +651,24 @@ def test_attention_fullsize_properties():
     ones[:, :, :N] = 1.0
     ops.vt_quad_swap(ones)                         # natural -> the quad-swapped key order the kernel reads
     ops.vt_quad_swap(Vt)
-    o1 = ops.attention(Qh, Kh, ones, N, npad, heads, out())
+    n2 = _norm2(Qh, Kh, N) if with_bound else None
+    want_path = ["attn_pipe_kernel" if with_bound else "attn_fwd_kernel"] * heads
+
+    def attn(K_, V_):
+        r = ops.attention(Qh, K_, V_, N, npad, heads, out(), norm2=n2)
+        torch.cuda.synchronize()
+        assert ops.attention_head_paths(n2, heads) == want_path
+        return r
+    o1 = attn(Kh, ones)
     assert float((o1.float() - 1.0).abs().max()) <= 2 ** -7
-    a = ops.attention(Qh, Kh, Vt, N, npad, heads, out())
-    b = ops.attention(Qh, Kh, (Vt.float() * 2).to(BF), N, npad, heads, out())
+    a = attn(Kh, Vt)
+    b = attn(Kh, (Vt.float() * 2).to(BF))
     assert torch.equal((a.float() * 2).to(BF), b)
     Kp, Vp = Kh.clone(), ops.vt_quad_swap(Vt.clone())          # Vp back in natural order
     Kp[:, N:] = 7.0
     Vp[:, :, N:] = 1e4                                          # poison every key >= N ...
     ops.vt_quad_swap(Vp)                                        # ... wherever the swapped order puts it
-    c = ops.attention(Qh, Kp, Vp, N, npad, heads, out())
-    torch.cuda.synchronize()
+    c = attn(Kp, Vp)                                            # (n2 still describes the real rows: the poisoned pad rows are masked, not scored)
     assert torch.equal(a, c)
 
 
@@ -1055,10 +1081,12 @@ def test_prodshape_attention_18226_sampled():
     p = torch.softmax(torch.einsum("hqd,hkd->hqk", q.float()[:, rows], k.float()) * math.log(2.0), dim=-1)
     ref = torch.einsum("hqk,hdk->hqd", p, v.float()).permute(1, 0, 2).reshape(len(rows), heads * 64).to(BF)
     close("prod_attention_18226", got[rows.cuda()], ref, rtol=3e-2, afrac=8e-3)
+    assert ops.attention_head_paths(None, heads) == ["attn_fwd_kernel"] * heads     # the call above: the running maximum
     n2 = _norm2(Q, K, N).cuda()
-    assert float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().max()) < 60.0
+    assert 40.0 < float(1.01 * (n2[:, 0] * n2[:, 1]).sqrt().max()) < 80.0          # (round 5 asserted "< 60" against a cutoff of 40: both heads fell back)
     got = ops.attention(Q.cuda(), K.cuda(), V.cuda(), N, npad, heads, torch.zeros(N, heads * 64, dtype=BF, device="cuda"), norm2=n2)
     torch.cuda.synchronize()
+    assert ops.attention_head_paths(n2) == ["attn_pipe_kernel"] * heads             # the production kernel served both heads
     close("prod_attention_18226_bound", got[rows.cuda()], ref, rtol=3e-2, afrac=8e-3)
 
 

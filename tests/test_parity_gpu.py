@@ -305,12 +305,13 @@ def test_heavy_tailed_weights_stagewise(heavy):
     reference's own error + 1e-3; every residual stream <= 1.5 x + 2e-3; PSNR >= reference - 0.05 dB), on weights with seeded outliers:
     massive-activation channels (x50) on the residual stream from patch_embed.proj and every ff.net.2, outlier channels in the VAE
     mid-block convs, LayerNorm gains spread over a decade, q / k gains up to 4 (peaky attention rows; heads on either side of the
-    constant-shift cutoff), one text row x30.  Random-init N(0, 0.02^2)-style weights never show the kernels such tensors."""
+    static guarantee b <= 80 of the no-shift attention kernel), one text row x30.  Random-init N(0, 0.02^2)-style weights never show the kernels such tensors."""
     pipe, text, video, noise, ref, refbf, tr32, trbf = (heavy[k] for k in ("pipe", "text", "video", "noise", "ref", "refbf", "tr32", "trbf"))
     tr = pipe.transformer
-    tr.attn_bound_trace = []
+    tr.attn_bound_trace, tr.attn_path_trace = [], []
     st = hip_stages(pipe, video.cuda(), text, noise.cuda())
     bt = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
+    pipe_share = float(torch.stack([torch.isfinite(n2[:, 0] * n2[:, 1]) for n2 in tr.attn_path_trace]).float().mean())
     tr.attn_bound_trace = None
     got = process_video(pipe, video.cuda(), empty_prompt_embedding=text, posterior_noise=noise.cuda())
     torch.cuda.synchronize()
@@ -323,7 +324,7 @@ def test_heavy_tailed_weights_stagewise(heavy):
     eb = {k: rms_rel(trbf[k], tr32[k]) for k in keys}
     p_hip, p_bf = psnr(got.float().cpu(), ref), psnr(refbf.float(), ref)
     print(f"[heavy] outlier channels carry {ratio:.1f} x the mean |residual|; attention score bound min / median / max "
-          f"{float(bt.min()):.1f} / {float(bt.median()):.1f} / {float(bt.max()):.1f}, constant-shift share {float((bt <= 40).float().mean()):.2f}; "
+          f"{float(bt.min()):.1f} / {float(bt.median()):.1f} / {float(bt.max()):.1f}, share of heads finished by the no-shift pipelined kernel {pipe_share:.2f}; "
           f"saturated pixels {100 * sat:.1f} %")
     print(f"[heavy] PSNR vs fp32 oracle: hip {p_hip:.3f} dB, bf16 reference {p_bf:.3f} dB ({p_hip - p_bf:+.3f} dB)")
     print("[heavy] rms-rel vs fp32 oracle (hip | bf16 reference): " + "  ".join(f"{k}:{eh[k]:.2e}|{eb[k]:.2e}" for k in keys))
@@ -415,11 +416,12 @@ def test_heavy_tailed_weights_mxfp8_velocity(heavy):
 
 
 def test_dit_mixed_softmax_paths_wide_qk_gains(golden_dir):
-    """The bf16 attention kernel picks its softmax PER HEAD from the weights: constant shift when the score bound 1.01 |q|max |k|max is
-    <= 40, running maximum otherwise.  Random-init LayerNorm gains of 1 put every head on the fast path, so here norm_q / norm_k get
-    gains log-uniform in [0.5, 4] and norm_k is then rescaled so that the MEDIAN head of each layer sits at the cutoff: both paths and
-    their per-head mix run inside one launch (asserted from the bound arrays), at N = 4458 tokens, 2 layers of the full-width DiT,
-    against the fp32 oracle with the bf16-emulated reference as the yardstick (<= 1.5 x + 2e-3 per residual stream)."""
+    """The bf16 attention picks its softmax PER HEAD from the data: every head starts on the no-shift pipelined kernel, and a head one of
+    whose row sums leaves [2^-80, 2^100] is recomputed with the running maximum in the same call.  Random-init LayerNorm gains of 1 (score
+    bound ~12) never leave the window, so here norm_q / norm_k get gains log-uniform in [0.5, 4] and norm_k is then rescaled, layer by
+    layer, until some heads of the layer DO overflow the un-shifted exponential and others do not: both kernels and their per-head mix run
+    inside one call (asserted from the norm arrays after the call), at N = 4458 tokens, 2 layers of the full-width DiT, against the fp32
+    oracle with the bf16-emulated reference as the yardstick (<= 1.5 x + 2e-3 per residual stream)."""
     from safetensors.torch import load_file
     v, t, s = config.default_configs()
     t["num_layers"] = 2
@@ -447,27 +449,37 @@ def test_dit_mixed_softmax_paths_wide_qk_gains(golden_dir):
         return wt, CogVideoXTransformer3DModel(t, wt, "cuda")
 
     def bounds(tr):
-        tr.attn_bound_trace = []
+        tr.attn_bound_trace, tr.attn_path_trace = [], []
         blocks = {}
         vh = tr(**kw, _trace=blocks)[0]
         torch.cuda.synchronize()
         b = torch.stack([1.01 * (n2[:, 0] * n2[:, 1]).sqrt() for n2 in tr.attn_bound_trace]).float().cpu()
+        on_pipe = torch.stack([torch.isfinite(n2[:, 0] * n2[:, 1]) for n2 in tr.attn_path_trace]).float().cpu()
         tr.attn_bound_trace = None
-        return vh, blocks, b
+        return vh, blocks, b, on_pipe
 
     # calibration, layer by layer (layer 1's input depends on layer 0's attention): scale k's LayerNorm (weight AND bias: k -> f k exactly)
+    # to raise the layer's median score bound until between 15 % and 85 % of its heads are handed to the running maximum
+    keys = lambda i: [f"transformer_blocks.{i}.attn1.{nm}" for nm in ("norm_k.weight", "norm_k.bias")]   # noqa: E731
     for i in range(2):
+        base = {k_: sc.get(k_, 1.0) for k_ in keys(i)}
         _, tr = build(sc)
-        _, _, b = bounds(tr)
-        f = 40.0 / float(b[i].median())
-        for nm in ("norm_k.weight", "norm_k.bias"):
-            key = f"transformer_blocks.{i}.attn1.{nm}"
-            sc[key] = sc.get(key, 1.0) * f
+        _, _, b, _ = bounds(tr)
+        med = float(b[i].median())
         del tr
+        for target in (110.0, 140.0, 170.0, 200.0, 240.0, 300.0, 400.0):
+            for k_ in keys(i):
+                sc[k_] = base[k_] * (target / med)
+            _, tr = build(sc)
+            _, _, _, on_pipe = bounds(tr)
+            del tr
+            if 0.15 < float(on_pipe[i].mean()) < 0.85:
+                break
     wt, tr = build(sc)
-    vh, blocks, b = bounds(tr)
-    frac = (b <= 40.0).float().mean(dim=1)
-    print(f"[mixed softmax] score bounds per layer: min {b.min(dim=1).values.tolist()} max {b.max(dim=1).values.tolist()}; constant-shift share {frac.tolist()}")
+    vh, blocks, b, on_pipe = bounds(tr)
+    frac = on_pipe.mean(dim=1)
+    print(f"[mixed softmax] score bounds per layer: min {b.min(dim=1).values.tolist()} median {b.median(dim=1).values.tolist()} "
+          f"max {b.max(dim=1).values.tolist()}; share of heads finished by the no-shift kernel {frac.tolist()}")
     assert all(0.15 < float(x) < 0.85 for x in frac), f"no per-head mix of the two softmax paths: {frac.tolist()}"
     torch.set_num_threads(min(os.cpu_count() or 1, 64))
     tr32, trbf = {}, {}
