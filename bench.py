@@ -130,7 +130,7 @@ def main():
                          "never the headline: the line says so in `dtype` and `config.variant`")
     ap.add_argument("--dit-attention", choices=["bf16", "mxfp8"], default="bf16",
                     help="same configs[4] variant: attention products on the block-scaled fp8 MFMA; never the headline")
-    ap.add_argument("--vae-streams", type=int, choices=[1, 2], default=None,
+    ap.add_argument("--vae-streams", type=int, choices=[1, 2, 3, 4], default=None,
                     help="HIP streams the VAE's frame-batches alternate on (default: the product's, 2); 1 for the A/B")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra (never headline) MXFP8 measurement of the N=1 line")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -309,6 +309,10 @@ def main():
             "one_gpu_ms_per_clip_this_run": elapsed / args.steps * 1e3,
             "efficiency_vs_n1": (elapsed / args.steps) / (observed_world * (el1 / args.steps)),
             "transport": "gloo through host memory (--oversubscribe debug run)" if args.oversubscribe else "RCCL (backend nccl) over xGMI",
+            # which process groups carried this rank's halos (dove_amd.dist._comm_label): a rank's receives (from rank-1) and sends (to
+            # rank+1) never share a communicator - the neighbour pair (r-1, r) talks on link r % 2 - so pre-posted receives cannot hold sends back
+            "halo_communicators_rank0": {"encode": getattr(pipe.vae, "last_halo_stats_encode", {}).get("communicators"),
+                                         "decode": getattr(pipe.vae, "last_halo_stats_decode", {}).get("communicators")},
             "bit_identical": bit_identical, "mismatched_frames": mismatched,
             "validation": "per-frame checksums of every rank's decoded frames in THIS run against the frames of rank 0's one-GPU result of the same "
                           "clip (`bit_identical`); the mode's bit-identity with the one-GPU operator is a tested property of the kernels "
@@ -423,7 +427,8 @@ def main():
             res["invalid"] = "debug run: all ranks share GPU 0 over gloo (--oversubscribe)"
         if strong:
             res["halo_exchange"] = {"vae_halo_bytes_sent_rank0_last_stage": int(getattr(pipe.vae, "last_halo_bytes", 0)),
-                                    "mode": "isend + pre-posted irecv per causal conv, GroupNorm pair sums on a side communicator"}
+                                    "mode": "isend + pre-posted irecv per causal conv, GroupNorm pair sums on a side communicator",
+                                    "communicators": getattr(pipe.vae, "last_halo_stats_decode", {}).get("communicators")}
         if args.layers is not None:
             res["invalid"] = "debug run with a truncated DiT"
         if world == 1 and not args.no_cpu_baseline:

@@ -265,6 +265,21 @@ struct dove_ctx {
   dove_xfer_fn send_fn = nullptr, recv_fn = nullptr; void* xfer_user = nullptr;
   void* rccl_lib = nullptr; void* rccl_comm = nullptr;
   bool halo_recv = false, halo_send = false;            // set by the batch loop around the rank's first / last batch
+  // Halo transport (round 6): the COMPUTE stream never runs a transfer.  Receives go to `recv_stream` (pre-posted at the start of the rank's
+  // first work item once the (stage, shape) has been seen - the list of halos is recorded on the first pass, like dove_amd/dist.py HaloCache),
+  // sends to `send_stream` behind an event recorded after the producing launch; the consuming conv waits on the receive's event.  The halo
+  // callbacks may differ from send_fn / recv_fn: the RCCL binding gives each direction its own communicator (rccl_halo_send / _recv).
+  hipStream_t recv_stream = nullptr, send_stream = nullptr;
+  dove_xfer_fn halo_send_fn = nullptr, halo_recv_fn = nullptr;
+  bool halo_can_prepost = true;                         // false: one communicator for both directions (RCCL without ncclCommSplit) - receives are posted where consumed
+  std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;  // events of the running stage (reused from stage to stage)
+  struct HaloSlot { void* p; size_t bytes; hipEvent_t ev; };
+  std::unordered_map<std::string, HaloSlot> halo_posted;
+  std::map<std::string, std::vector<std::pair<std::string, size_t>>> halo_plans;   // (stage, shape, ranks) -> halos of the first work item, in conv order
+  std::vector<std::pair<std::string, size_t>> halo_record;
+  std::string halo_key;
+  bool halo_sent = false;
+  long long stat_halo_preposted = 0, stat_halo_blocking = 0, stat_halo_sent = 0;   // of the last VAE stage (dove_get_option DOVE_STAT_*)
   // a PIECE of a frame-batch split over a rank pair (more ranks than frame-batches: BASELINE configs[2], 8 ranks on 4 batches): GroupNorm
   // sums are combined with `piece_partner`, Upsample3D is told which piece starts an odd batch (dove_amd/dist.py plan_pieces)
   int piece_role = 0;                                   // 0: whole batch, 1: head (keeps the first frame single), 2: tail
@@ -468,6 +483,100 @@ int linear(dove_ctx* c, const bf16_t* x, long long N, const Packed& pc, ConvOpt 
   return 0;
 }
 
+// ---- halo transport on the context's own streams (see dove_ctx) ----
+int next_event(dove_ctx* c, hipEvent_t* out) {
+  if (c->ev_next == c->ev_pool.size()) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_pool.push_back(e);
+  }
+  *out = c->ev_pool[c->ev_next++];
+  return 0;
+}
+// `to` waits for everything enqueued on `from` so far
+int stream_after(dove_ctx* c, hipStream_t to, hipStream_t from) {
+  hipEvent_t e; CHK(next_event(c, &e));
+  HIPCHK(hipEventRecord(e, from));
+  HIPCHK(hipStreamWaitEvent(to, e, 0));
+  return 0;
+}
+int ensure_comm_streams(dove_ctx* c) {
+  if (!c->recv_stream) HIPCHK(hipStreamCreateWithFlags(&c->recv_stream, hipStreamNonBlocking));
+  if (!c->send_stream) HIPCHK(hipStreamCreateWithFlags(&c->send_stream, hipStreamNonBlocking));
+  return 0;
+}
+// Start of the rank's FIRST work item of a stage (it receives halos from rank - 1): with a recorded plan, every receive is posted now, in conv
+// order, into buffers taken from the back of the arena; without one this pass records it.  An arena too small for the whole list falls back to
+// posting each receive where it is consumed (the recording path), which is always correct.
+int halo_begin(dove_ctx* c, const std::string& key, void* stream) {
+  c->halo_key = key;
+  c->halo_record.clear();
+  c->halo_posted.clear();
+  CHK(ensure_comm_streams(c));
+  auto it = c->halo_plans.find(key);
+  if (it == c->halo_plans.end() || !c->halo_can_prepost) return 0;
+  std::vector<void*> got;
+  for (auto& nb : it->second) {
+    void* p = c->arena.alloc(nb.second, true);
+    if (!p) { for (void* q : got) c->arena.release(q); return 0; }
+    got.push_back(p);
+  }
+  CHK(stream_after(c, c->recv_stream, (hipStream_t)stream));   // the buffers' previous users (this stream, earlier) are done before anything lands
+  size_t i = 0;
+  for (auto& nb : it->second) {
+    dove_ctx::HaloSlot sl; sl.p = got[i++]; sl.bytes = nb.second;
+    CHK(c->halo_recv_fn(c->xfer_user, c->rank - 1, sl.p, sl.bytes, (void*)c->recv_stream));
+    CHK(next_event(c, &sl.ev));
+    HIPCHK(hipEventRecord(sl.ev, c->recv_stream));
+    c->halo_posted[nb.first] = sl;
+  }
+  return 0;
+}
+// the halo of conv `name` for the rank's first work item: *out owns an arena block
+int halo_fetch(dove_ctx* c, const std::string& name, size_t bytes, void** out, void* stream) {
+  auto it = c->halo_posted.find(name);
+  if (it != c->halo_posted.end()) {
+    if (it->second.bytes != bytes) { dove_set_error("halo of %s: pre-posted %zu bytes, the conv wants %zu", name.c_str(), it->second.bytes, bytes); return DOVE_EINVAL; }
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, it->second.ev, 0));
+    *out = it->second.p;
+    c->halo_posted.erase(it);
+    ++c->stat_halo_preposted;
+    return 0;
+  }
+  if (!c->halo_posted.empty()) { dove_set_error("halo of %s was not in the pre-posted plan (%zu others still posted)", name.c_str(), c->halo_posted.size()); return DOVE_EINVAL; }
+  void* p = c->arena.alloc(bytes, true);
+  if (!p) { dove_set_error("workspace exhausted (halo of %s: %zu bytes)", name.c_str(), bytes); return DOVE_EINVAL; }
+  CHK(ensure_comm_streams(c));
+  CHK(stream_after(c, c->recv_stream, (hipStream_t)stream));   // the block's previous users
+  CHK(c->halo_recv_fn(c->xfer_user, c->rank - 1, p, bytes, (void*)c->recv_stream));
+  CHK(stream_after(c, (hipStream_t)stream, c->recv_stream));
+  c->halo_record.emplace_back(name, bytes);
+  ++c->stat_halo_blocking;
+  *out = p;
+  return 0;
+}
+int halo_end_first_item(dove_ctx* c) {
+  if (!c->halo_posted.empty()) { dove_set_error("%zu pre-posted halos were never consumed", c->halo_posted.size()); c->halo_posted.clear(); c->halo_plans.erase(c->halo_key); return DOVE_EINVAL; }
+  if (!c->halo_record.empty() && !c->halo_plans.count(c->halo_key)) c->halo_plans[c->halo_key] = c->halo_record;
+  c->halo_record.clear();
+  return 0;
+}
+// a conv of the rank's LAST work item hands its cache (the last kt - 1 input frames) to rank + 1: behind an event, on the send stream
+int halo_publish(dove_ctx* c, void* p, size_t bytes, void* stream) {
+  CHK(ensure_comm_streams(c));
+  CHK(stream_after(c, c->send_stream, (hipStream_t)stream));
+  CHK(c->halo_send_fn(c->xfer_user, c->rank + 1, p, bytes, (void*)c->send_stream));
+  c->halo_sent = true;
+  ++c->stat_halo_sent;
+  return 0;
+}
+// end of a stage: the memory the sends read is recycled by the next stage - the caller's stream continues behind the last of them
+int halo_stage_end(dove_ctx* c, void* stream) {
+  if (c->halo_sent) CHK(stream_after(c, (hipStream_t)stream, c->send_stream));
+  c->halo_sent = false;
+  return 0;
+}
+
 // ---- exchanges between ranks, built on the context's send / recv callbacks (dove_comm_init*: RCCL or any transport).  A transport
 // whose sends rendezvous with the matching receive (RCCL) brackets every exchange with group_begin / group_end; a buffering transport
 // (the tests' mailbox) needs no bracket: all sends of an exchange are issued before its receives. ----
@@ -576,9 +685,9 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   if (c->halo_recv && it == c->cache.end()) {
     // first batch of a rank > 0: the conv_cache the previous batch would have left arrives from rank - 1 (same layer order there)
     Tensor h; h.T = k; h.H = x.H; h.W = x.W; h.C = x.C;
-    h.p = (bf16_t*)c->arena.alloc(h.bytes(), true);
-    if (!h.p) { dove_set_error("workspace exhausted (halo of %s: %zu bytes)", name.c_str(), h.bytes()); return DOVE_EINVAL; }
-    CHK(c->recv_fn(c->xfer_user, c->rank - 1, h.p, h.bytes(), stream));
+    void* hp = nullptr;
+    CHK(halo_fetch(c, name, h.bytes(), &hp, stream));          // lands on the context's receive stream; this stream only waits on its event
+    h.p = (bf16_t*)hp;
     c->cache[name] = h; c->cache_owner[name] = h.p;
     it = c->cache.find(name);
   }
@@ -596,7 +705,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     c->cache[name] = nc; c->cache_owner[name] = x.p;
     c->arena.release(old_owner);                              // the conv that read the old entry is already enqueued
     x.p = nullptr;
-    if (c->halo_send) CHK(c->send_fn(c->xfer_user, c->rank + 1, nc.p, nc.bytes(), stream));
+    if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
     return 0;
   }
   nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
@@ -613,7 +722,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   c->cache[name] = nc; c->cache_owner[name] = nc.p;
   c->arena.release(old_owner);
   if (x_owned) free_t(c, x);
-  if (c->halo_send) CHK(c->send_fn(c->xfer_user, c->rank + 1, nc.p, nc.bytes(), stream));
+  if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
   return 0;
 }
 // frames one frame-batch of t input frames leaves behind the encoder's / decoder's temporal stages (diffusers' Downsample3D
@@ -778,7 +887,10 @@ void clear_caches(dove_ctx* c);
 struct StageGuard {
   dove_ctx* c;
   explicit StageGuard(dove_ctx* ctx) : c(ctx) {
-    if (c && c->depth++ == 0) { clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; set_piece(c, nullptr); }
+    if (c && c->depth++ == 0) {
+      clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; set_piece(c, nullptr);
+      c->ev_next = 0; c->halo_posted.clear(); c->halo_record.clear(); c->halo_sent = false;
+    }
   }
   ~StageGuard() { if (c) --c->depth; }
 };
@@ -965,12 +1077,19 @@ extern "C" void dove_destroy(dove_ctx* c) {
   delete c;
 }
 // ---- multi-GPU: halo exchange between the ranks of one clip (SURVEY.md 8(b) dove_comm_init, 8(e)) ---------------------------------
-// The transport is two function pointers; dove_comm_init binds them to RCCL (ncclSend / ncclRecv on the caller's stream, library
-// opened with dlopen so that libdove_hip.so itself does not depend on it), dove_comm_init_custom to anything else (tests: an
-// in-process mailbox between contexts on one GPU).
+// The transport is two function pointers; dove_comm_init binds them to RCCL (library opened with dlopen so that libdove_hip.so itself does
+// not depend on it), dove_comm_init_custom to anything else (tests: an in-process mailbox between contexts on one GPU).  The symmetric
+// exchanges (GroupNorm pair sums, the DiT's all-to-alls, the moments gather) run on the caller's stream - their results are needed at once -
+// as one ncclGroup each; the VAE's halos run on the context's OWN receive / send streams and, under RCCL, on two more communicators, so that
+// the caller's stream never executes a transfer and a rank's pre-posted receives cannot hold its sends back (dove_ctx, struct Rccl).
 namespace {
 struct Rccl {
   void* lib; void* comm;
+  // link[i]: communicator of the neighbour pairs (r - 1, r) with r % 2 == i - a rank receives its halos (from rank - 1) on link[rank % 2] and
+  // sends (to rank + 1) on link[(rank + 1) % 2]: never both on one communicator, whose point-to-point operations RCCL runs in issue order
+  // (pre-posted receives would hold every send back until the rank's LAST halo had arrived).  Made with ncclCommSplit; without that symbol
+  // both entries are `comm` and nothing is pre-posted.
+  void* link[2]; int rank;
   int (*Send)(const void*, size_t, int, int, void*, hipStream_t);
   int (*Recv)(void*, size_t, int, int, void*, hipStream_t);
   int (*CommDestroy)(void*);
@@ -1000,6 +1119,18 @@ int rccl_recv(void* user, int peer, void* p, size_t bytes, void* stream) {
   if (rc) { dove_set_error("ncclRecv from rank %d failed (%d)", peer, rc); return DOVE_ELAUNCH; }
   return 0;
 }
+int rccl_halo_send(void* user, int peer, void* p, size_t bytes, void* stream) {
+  Rccl* r = (Rccl*)user;
+  const int rc = r->Send(p, bytes, /*ncclChar*/ 0, peer, r->link[(r->rank + 1) & 1], (hipStream_t)stream);
+  if (rc) { dove_set_error("ncclSend (halo) to rank %d failed (%d)", peer, rc); return DOVE_ELAUNCH; }
+  return 0;
+}
+int rccl_halo_recv(void* user, int peer, void* p, size_t bytes, void* stream) {
+  Rccl* r = (Rccl*)user;
+  const int rc = r->Recv(p, bytes, /*ncclChar*/ 0, peer, r->link[r->rank & 1], (hipStream_t)stream);
+  if (rc) { dove_set_error("ncclRecv (halo) from rank %d failed (%d)", peer, rc); return DOVE_ELAUNCH; }
+  return 0;
+}
 void* open_rccl() {
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -1021,10 +1152,15 @@ extern "C" void dove_comm_destroy(dove_ctx* c) {
   if (!c) return;
   if (c->rccl_comm) {
     Rccl* r = (Rccl*)c->rccl_comm;
+    for (int i = 0; i < 2; ++i) if (r->link[i] && r->link[i] != r->comm) (void)r->CommDestroy(r->link[i]);
     if (r->comm) (void)r->CommDestroy(r->comm);
     delete r;
     c->rccl_comm = nullptr;
   }
+  if (c->recv_stream) { (void)hipStreamSynchronize(c->recv_stream); (void)hipStreamDestroy(c->recv_stream); c->recv_stream = nullptr; }
+  if (c->send_stream) { (void)hipStreamSynchronize(c->send_stream); (void)hipStreamDestroy(c->send_stream); c->send_stream = nullptr; }
+  c->halo_plans.clear(); c->halo_posted.clear(); c->halo_record.clear(); c->halo_can_prepost = true;
+  c->halo_send_fn = c->halo_recv_fn = nullptr;
   c->rank = 0; c->nranks = 1; c->send_fn = c->recv_fn = nullptr; c->xfer_user = nullptr; c->group_begin = c->group_end = nullptr;
 }
 extern "C" int dove_comm_set_group(dove_ctx* c, dove_group_fn begin, dove_group_fn end) {
@@ -1037,6 +1173,7 @@ extern "C" int dove_comm_init_custom(dove_ctx* c, int rank, int nranks, dove_xfe
   DOVE_CHECK_ARG(nranks == 1 || (send && recv), "dove_comm_init_custom: send / recv callbacks are required");
   dove_comm_destroy(c);
   c->rank = rank; c->nranks = nranks; c->send_fn = send; c->recv_fn = recv; c->xfer_user = user;
+  c->halo_send_fn = send; c->halo_recv_fn = recv;             // halos: the same callbacks, handed the context's send / receive stream
   return DOVE_OK;
 }
 extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank, int nranks) {
@@ -1057,9 +1194,25 @@ extern "C" int dove_comm_init(dove_ctx* c, const void* nccl_unique_id, int rank,
   memcpy(&id, nccl_unique_id, sizeof id);
   const int rc = init(&r->comm, nranks, id, rank);
   if (rc) { delete r; dove_set_error("ncclCommInitRank failed (%d)", rc); return DOVE_ELAUNCH; }
+  // two more communicators over the same ranks for the halo wavefront (struct Rccl): ncclCommSplit with one colour = a duplicate, collective
+  r->rank = rank; r->link[0] = r->link[1] = r->comm;
+  bool split_ok = false;
+  auto split = (int (*)(void*, int, int, void**, void*))dlsym(h, "ncclCommSplit");
+  if (split && nranks > 1) {
+    void *a = nullptr, *b = nullptr;
+    const int ra = split(r->comm, 0, rank, &a, nullptr);
+    const int rb = ra ? ra : split(r->comm, 0, rank, &b, nullptr);
+    if (!ra && !rb && a && b) { r->link[0] = a; r->link[1] = b; split_ok = true; }
+    else {
+      if (a) (void)r->CommDestroy(a);
+      if (b) (void)r->CommDestroy(b);
+    }
+  }
   dove_comm_destroy(c);
   c->rccl_comm = r;
   c->rank = rank; c->nranks = nranks; c->send_fn = rccl_send; c->recv_fn = rccl_recv; c->xfer_user = r;
+  c->halo_send_fn = rccl_halo_send; c->halo_recv_fn = rccl_halo_recv;
+  c->halo_can_prepost = split_ok || nranks == 1;
   c->group_begin = rccl_group_begin; c->group_end = rccl_group_end;      // every exchange (pair swap, all-to-all) is one ncclGroup
   return DOVE_OK;
 }
@@ -1114,6 +1267,10 @@ extern "C" long long dove_get_option(dove_ctx* c, int option) {
     case DOVE_OPT_DIT_LINEAR_MXFP8: return c->opt_linear_mx;
     case DOVE_OPT_DIT_ATTN_MXFP8: return c->opt_attn_mx;
     case DOVE_OPT_WEIGHT_SUMS: return c->opt_weight_sums;
+    case DOVE_STAT_HALO_PREPOSTED: return c->stat_halo_preposted;
+    case DOVE_STAT_HALO_BLOCKING: return c->stat_halo_blocking;
+    case DOVE_STAT_HALO_SENT: return c->stat_halo_sent;
+    case DOVE_STAT_HALO_COMMUNICATORS: return c->nranks > 1 ? (c->halo_can_prepost && c->rccl_comm ? 3 : (c->rccl_comm ? 1 : 0)) : 0;
     default: return -1;
   }
 }
@@ -1454,6 +1611,7 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   RankPlan rp;
   rank_plan(c, true, F, &rp);
   if (rp.total_out != T) { dove_set_error("dove_vae_encode: the rank plan yields %d latent frames, expected %d", rp.total_out, T); return DOVE_EINVAL; }
+  c->stat_halo_preposted = c->stat_halo_blocking = c->stat_halo_sent = 0;
   for (size_t i = 0; i < rp.mine.size(); ++i) {
     const Piece& pc = rp.mine[i];
     c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
@@ -1461,7 +1619,10 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
     set_piece(c, &pc);
     Tensor xb = xcl; xb.p = xcl.p + (long long)pc.s * H * W * xcl.C; xb.T = pc.e - pc.s;
     Tensor o;
-    const int rc = encoder(c, xb, &o, stream);
+    const bool first_recv = c->halo_recv;
+    if (first_recv) CHK(halo_begin(c, "enc:" + std::to_string(F) + "x" + std::to_string(H) + "x" + std::to_string(W) + ":" + std::to_string(c->nranks) + ":" + std::to_string(c->rank), stream));
+    int rc = encoder(c, xb, &o, stream);
+    if (!rc && first_recv) rc = halo_end_first_item(c);
     c->halo_recv = c->halo_send = false;
     set_piece(c, nullptr);
     CHK(rc);
@@ -1470,6 +1631,7 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   }
   free_t(c, xcl);
   clear_caches(c);
+  CHK(halo_stage_end(c, stream));
   return 0;
 }
 extern "C" int dove_vae_encode(dove_ctx* c, const void* x, int dtype, int F, int H, int W, void* moments_out, int out_dtype, void* stream) {
@@ -1553,6 +1715,7 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   RankPlan rp;
   rank_plan(c, false, T, &rp);
   if (rp.total_out != F) { dove_set_error("dove_vae_decode: the rank plan yields %d frames, expected %d", rp.total_out, F); return DOVE_EINVAL; }
+  c->stat_halo_preposted = c->stat_halo_blocking = c->stat_halo_sent = 0;
   for (size_t i = 0; i < rp.mine.size(); ++i) {
     const Piece& pc = rp.mine[i];
     c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
@@ -1560,7 +1723,10 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
     set_piece(c, &pc);
     Tensor zb = zcl; zb.p = zcl.p + (long long)pc.s * h * w * zcl.C; zb.T = pc.e - pc.s;
     Tensor o;
-    const int rc = decoder(c, zb, &o, stream);
+    const bool first_recv = c->halo_recv;
+    if (first_recv) CHK(halo_begin(c, "dec:" + std::to_string(T) + "x" + std::to_string(h) + "x" + std::to_string(w) + ":" + std::to_string(c->nranks) + ":" + std::to_string(c->rank), stream));
+    int rc = decoder(c, zb, &o, stream);
+    if (!rc && first_recv) rc = halo_end_first_item(c);
     c->halo_recv = c->halo_send = false;
     set_piece(c, nullptr);
     CHK(rc);
@@ -1582,6 +1748,7 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   }
   free_t(c, zcl);
   clear_caches(c);
+  CHK(halo_stage_end(c, stream));
   return DOVE_OK;
 }
 

@@ -60,8 +60,29 @@ class _StagedRecv:
         self._buf.copy_(self._host)
 
 
+_wire_log = None     # tests: a list -> every point-to-point call appends (communicator label, "send" | "recv" | "swap", global peer rank)
+
+
+def _comm_label(group):
+    """Name of a communicator that means the same on every rank: "link0" / "link1" (``_links``), "side" (``_side_group``), else "stage"
+    (the group the sharded call was given).  The serials of ``_group_key`` are per process."""
+    for ls in _link_groups.values():
+        for i, g in enumerate(ls):
+            if g is group:
+                return f"link{i}"
+    if any(g is group for g in _side_groups.values()):
+        return "side"
+    return "stage"
+
+
+def _log_wire(group, op, peer):
+    if _wire_log is not None:
+        _wire_log.append((_comm_label(group), op, int(peer)))
+
+
 def _isend(t, dst, group):
     """-> (tensor to keep alive, work).  ``dst`` is a global rank."""
+    _log_wire(group, "send", dst)
     if _direct(group):
         return t, dist.isend(t, dst=dst, group=group)
     h = t.cpu() if t.is_cuda else t                    # .cpu() waits for the producing stream
@@ -69,6 +90,7 @@ def _isend(t, dst, group):
 
 
 def _irecv(buf, src, group):
+    _log_wire(group, "recv", src)
     if _direct(group):
         return dist.irecv(buf, src=src, group=group)
     if buf.is_cuda:
@@ -84,11 +106,17 @@ def _exchange(mine, theirs, peer, group):
     """Symmetric swap with one peer, both directions in flight at once.  On RCCL the pair must be ONE grouped call: two ranks that
     each enqueue recv-then-send separately wait on each other's send forever."""
     if _direct(group):
+        _log_wire(group, "swap", peer)
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, peer, group), dist.P2POp(dist.irecv, theirs, peer, group)]):
             w.wait()
         return
-    rw = _irecv(theirs, peer, group)
-    keep, sw = _isend(mine, peer, group)
+    _log_wire(group, "swap", peer)
+    saved, globals()["_wire_log"] = _wire_log, None            # the pair of calls below is this ONE swap
+    try:
+        rw = _irecv(theirs, peer, group)
+        keep, sw = _isend(mine, peer, group)
+    finally:
+        globals()["_wire_log"] = saved
     rw.wait()
     sw.wait()
 
@@ -217,13 +245,26 @@ class HaloCache(dict):
         only, so the first run with a given shape records the plan (blocking receives) and every later run posts all of
         its ``irecv``s up front, in conv order, into preallocated buffers - conv k's halo streams in while convs < k run,
         and ``fetch`` merely waits on its handle (a stream-side wait on RCCL).
-    Order and bytes on the wire are those of the blocking version; results are bit-identical (gloo tests)."""
+    Order and bytes on the wire are those of the blocking version; results are bit-identical (gloo tests).
+
+    COMMUNICATORS.  A rank's receives (from rank-1) and its sends (to rank+1) must never share a communicator: RCCL executes the
+    point-to-point operations of one communicator in issue order on one stream (torch with eager init - ``device_id=`` - says so itself:
+    "unbatched P2P ops are ... serialized with all other ops on this ProcessGroup"), so a stage's pre-posted receives, queued first, would
+    hold every send of the rank back until its LAST halo had arrived - rank r+1 would start when rank r-1 had finished the stage and the
+    one-layer-skewed wavefront would degrade to ~R/2 stage times.  ``links`` = two extra world-spanning groups (``_link_groups``); the
+    neighbour pair (r-1, r) talks on ``links[r % 2]``: rank r receives on ``links[r % 2]`` and sends on ``links[(r+1) % 2]`` - on either
+    communicator a rank only ever receives or only ever sends (tests/test_dist_cpu.py::test_halo_wavefront_communicators).  Without
+    links (a sub-group: ``new_group`` is collective over the WORLD, its non-members never get here) nothing is pre-posted: each halo is
+    received right where it is consumed, so receives and sends interleave in layer order on the one communicator."""
 
     _plans: dict = {}                                   # (stage key) -> [(name, shape)] of the first local batch
 
-    def __init__(self, group, rank, world, plan_key=None):
+    def __init__(self, group, rank, world, plan_key=None, links=None):
         super().__init__()
         self.group, self.rank, self.world = group, rank, world
+        self.recv_group = links[rank % 2] if links else group
+        self.send_group = links[(rank + 1) % 2] if links else group
+        self.can_prepost = bool(links)
         self.phase = "mid"
         self.bytes_sent = 0
         self.plan_key = plan_key
@@ -242,11 +283,11 @@ class HaloCache(dict):
         """Post every receive of the first local batch when this (stage, shape) has been seen before."""
         self._dev = device
         plan = HaloCache._plans.get(self.plan_key)
-        if plan is None or self.rank == 0:
+        if plan is None or self.rank == 0 or not self.can_prepost:
             return
         for name, shape in plan:
             buf = torch.empty(shape, dtype=torch.bfloat16, device=device)
-            self._posted[name] = (buf, _irecv(buf, self._peer(self.rank - 1), self.group))
+            self._posted[name] = (buf, _irecv(buf, self._peer(self.rank - 1), self.recv_group))
 
     def fetch(self, name, like_shape, device):
         """Halo for conv ``name`` of the first local batch (None on rank 0: replicate-first-frame padding)."""
@@ -258,7 +299,7 @@ class HaloCache(dict):
                 self.recv_preposted += 1
                 return buf
             buf = torch.empty(like_shape, dtype=torch.bfloat16, device=device)
-            _recv(buf, self._peer(self.rank - 1), self.group)
+            _recv(buf, self._peer(self.rank - 1), self.recv_group)
             self._record.append((name, tuple(like_shape)))
             self.recv_blocking += 1
             return buf
@@ -267,12 +308,13 @@ class HaloCache(dict):
     def publish(self, name, new):
         self[name] = new
         if self.phase in ("last", "both") and self.rank < self.world - 1:
-            self._sends.append(_isend(new.contiguous(), self._peer(self.rank + 1), self.group))
+            self._sends.append(_isend(new.contiguous(), self._peer(self.rank + 1), self.send_group))
             self.bytes_sent += new.numel() * 2
             self.msg_bytes.append(new.numel() * 2)
 
     def stats(self):
-        return dict(bytes_sent=self.bytes_sent, messages=list(self.msg_bytes), recv_blocking=self.recv_blocking, recv_preposted=self.recv_preposted)
+        return dict(bytes_sent=self.bytes_sent, messages=list(self.msg_bytes), recv_blocking=self.recv_blocking, recv_preposted=self.recv_preposted,
+                    communicators=dict(recv=_comm_label(self.recv_group), send=_comm_label(self.send_group), stage=_comm_label(self.group)))
 
     def finish(self):
         """End of the stage: every send has left, every posted receive was consumed, the plan is remembered."""
@@ -329,6 +371,20 @@ def plan_pieces(batches, world, kind):
 
 
 _side_groups: dict = {}
+_link_groups: dict = {}
+
+
+def _links(group):
+    """Two more communicators over the world for the halo wavefront (HaloCache, COMMUNICATORS): created collectively on first use for the
+    default group - every rank reaches ``_run_sharded`` with the same arguments - and None for a sub-group."""
+    if group is not None and group is not dist.group.WORLD:
+        return None
+    key = _group_key(None)
+    if key not in _link_groups:
+        _link_groups.clear()                            # groups of a destroyed world are gone with it
+        be = dist.get_backend()
+        _link_groups[key] = (dist.new_group(backend=be), dist.new_group(backend=be))
+    return _link_groups[key]
 
 
 def _side_group(group):
@@ -338,9 +394,11 @@ def _side_group(group):
     for the default group; for a sub-group (whose non-members never get here) there is none and receives stay un-posted."""
     if group is not None and group is not dist.group.WORLD:
         return None
-    if "world" not in _side_groups:
-        _side_groups["world"] = dist.new_group(backend=dist.get_backend())
-    return _side_groups["world"]
+    key = _group_key(None)
+    if key not in _side_groups:
+        _side_groups.clear()
+        _side_groups[key] = dist.new_group(backend=dist.get_backend())
+    return _side_groups[key]
 
 
 def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
@@ -350,11 +408,12 @@ def _run_sharded(vae, x_cl, batches, world, rank, group, fn, kind="enc"):
     mine = plan[rank]
     paired = any(pc["partner"] is not None for r in plan for pc in r)
     gn_group = _side_group(group) if paired else group
+    links = _links(group)                               # both collective on first use: before anything that can differ between ranks
     gkey = _group_key(group)
     if gkey in _poisoned:
         raise RuntimeError("dove_amd.dist: an earlier sharded call on this process group failed part-way (its peers may hold unmatched halo messages); "
                            "destroy and re-create the process group before the next sharded call")
-    cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, gkey))
+    cache = HaloCache(group, rank, active, plan_key=(kind, tuple(x_cl.shape), world, rank, gkey), links=links)
     if not paired or gn_group is not None:
         cache.prepost(x_cl.device)
     if gn_group is None:

@@ -96,6 +96,11 @@ class GraphContext:
         L.check(L.load().dove_comm_init_custom(self._h, rank, nranks, self._xfer[0], self._xfer[1], None), "dove_comm_init_custom")
         self._rank, self._nranks = rank, nranks
 
+    def halo_stats(self) -> dict:
+        """Counters of the last vae_encode / vae_decode of a multi-rank context (include/dove_hip.h DOVE_STAT_*)."""
+        return dict(preposted=self.get_option(L.STAT_HALO_PREPOSTED), blocking=self.get_option(L.STAT_HALO_BLOCKING),
+                    sent=self.get_option(L.STAT_HALO_SENT), communicators=self.get_option(L.STAT_HALO_COMMUNICATORS))
+
     def comm_destroy(self):
         L.load().dove_comm_destroy(self._h)
 

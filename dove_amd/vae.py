@@ -400,8 +400,8 @@ class AutoencoderKLCogVideoX:
 
     # ---- two-stream execution of the frame-batches ------------------------------------------------------------
     def _run_batches(self, x_cl, batch, fn, post=None):
-        """Run ``fn`` (encoder or decoder) over the frame-batches.  With ``n_streams == 2`` alternate batches go to two HIP
-        streams ordered only by per-conv events, so one batch's HBM-bound GroupNorm kernels overlap the other batch's
+        """Run ``fn`` (encoder or decoder) over the frame-batches.  With ``n_streams >= 2`` the batches go round-robin to that many HIP
+        streams ordered only by per-conv events, so one batch's HBM-bound GroupNorm kernels overlap another batch's
         MFMA-bound convolutions; results are bit-identical to the single-stream order."""
         batches = frame_batches(x_cl.shape[0], batch)
         if self.n_streams < 2 or len(batches) < 2 or not x_cl.is_cuda:
@@ -410,14 +410,14 @@ class AutoencoderKLCogVideoX:
                 o = fn(x_cl[s:e], cache)
                 outs.append(post(o) if post else o)
             return outs
-        if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        if self._streams is None or len(self._streams) != self.n_streams:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)]
         main = torch.cuda.current_stream(self.device)
         cache, outs = StreamCache(), []
         for st in self._streams:
             st.wait_stream(main)                   # x_cl was produced on the caller's stream
         for i, (s, e) in enumerate(batches):
-            st = self._streams[i % 2]
+            st = self._streams[i % len(self._streams)]
             cache.stream = st
             with torch.cuda.stream(st):
                 xb = x_cl[s:e]

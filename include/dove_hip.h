@@ -329,7 +329,8 @@ int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
  *  - dove_vae_encode / dove_vae_decode run only THIS rank's share of the frame-batches (diffusers' num_sample_frames_batch_size /
  *    num_latent_frames_batch_size batching): every CogVideoXCausalConv3d of the rank's first work item receives its conv_cache (the last
  *    kt-1 input frames the previous item would have left) from rank-1, and sends its own to rank+1 after the rank's last - point-to-point, in
- *    layer order, on the caller's stream.  With at most as many ranks as frame-batches the items are whole batches; with MORE ranks (ABI 12)
+ *    layer order, on the context's own receive / send streams (ABI 14): the transport callbacks are handed THOSE streams for halos, the
+ *    caller's stream only waits on events (receives are pre-posted from the second call with a given stage and shape on).  With at most as many ranks as frame-batches the items are whole batches; with MORE ranks (ABI 12)
  *    batches are split into PAIRED PIECES on consecutive ranks - 8 ranks on a 33-frame clip decode 5,4,4,4,4,4,4,4 frames, BASELINE's
  *    "frame-chunk = 4" - and every GroupNorm of a piece swaps 65 doubles (per-group sum, sum of squares, element count) with its partner, so the
  *    statistics are the whole batch's.  Only the frames dove_shard_frames reports are written to the output buffer;
@@ -340,8 +341,10 @@ int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
  *    noise and text and gets ITS frames of video_out (dove_shard_frames(ctx, 1, T, ...)); gathering them is the caller's.
  * Every result is bit-identical to the single-GPU call (tests/test_graph_gpu.py plays 2 - 8 ranks as threads on one GPU).
  * dove_comm_init: RCCL transport (librccl opened at run time; the 128-byte id from dove_comm_unique_id on rank 0, distributed by the host;
- * every exchange is one ncclGroup).  dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`,
- * ordered on `stream`, matched in order per (source, destination) pair. */
+ * every symmetric exchange is one ncclGroup; the halos of the two directions travel on two further communicators made with ncclCommSplit).
+ * dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`, ordered on `stream`, matched in order per
+ * (source, destination) pair.  `stream` is the caller's for the symmetric exchanges and one of the context's two internal streams for
+ * halos: a transport that hands data from the sender's stream to the receiver's must order the two itself (an event per message). */
 typedef int (*dove_xfer_fn)(void* user, int peer, void* dev_ptr, size_t bytes, void* stream);
 /* Bracket of ONE exchange (ABI 12).  The paired-piece VAE swaps 65 doubles with a partner per GroupNorm and the sharded DiT runs all-to-alls:
  * symmetric patterns in which every rank sends and receives.  A transport whose send rendezvous with the peer's receive (RCCL) must see the
@@ -381,6 +384,14 @@ void dove_destroy(dove_ctx* ctx);
  * w_pair) to its convolutions - every launch computes the reference's per-tap arithmetic (+7.6 % conv MACs), for a caller who wants a
  * checkpoint validated without the one extra bf16 rounding of the summed weights.  The Python facade's switch: pipe.vae.weight_sums. */
 #define DOVE_OPT_WEIGHT_SUMS 6
+/* read-only counters of the LAST dove_vae_encode / dove_vae_decode of a multi-rank context (dove_get_option; ABI 14): halos this rank received
+ * from receives posted before the stage's first kernel / posted where they were consumed (the first pass over a (stage, shape) records the
+ * list, later passes pre-post it), halos sent; DOVE_STAT_HALO_COMMUNICATORS: 3 = RCCL with one communicator per halo direction + the main
+ * one, 1 = RCCL without ncclCommSplit (one communicator, nothing pre-posted), 0 = custom transport / single rank. */
+#define DOVE_STAT_HALO_PREPOSTED 100
+#define DOVE_STAT_HALO_BLOCKING 101
+#define DOVE_STAT_HALO_SENT 102
+#define DOVE_STAT_HALO_COMMUNICATORS 103
 int dove_set_option(dove_ctx* ctx, int option, long long value);
 long long dove_get_option(dove_ctx* ctx, int option); /* -1: unknown option */
 int dove_set_weight(dove_ctx* ctx, const char* name, const void* dev_ptr, const long long* shape, int ndim, int dtype);

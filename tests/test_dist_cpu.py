@@ -65,6 +65,22 @@ def _worker(rank, world, port, mode, q):
                 other = process_video(pipe, video, empty_prompt_embedding=text, noise_step=100)
                 q.put(("rng", all(bool(torch.equal(o, outs[0])) for o in outs), float((out.float() - ref.float()).abs().max()),
                        float((out.float() - other.float()).abs().max())))
+        elif mode == "wires":
+            # every point-to-point call of the sharded VAE, recorded as (communicator, op, peer): recording pass, then the pre-posted pass
+            video = (torch.rand(1, 3, 33, 16, 32, generator=g) * 2 - 1).to(torch.bfloat16)
+            z = torch.randn(1, 16, 9, 2, 4, generator=g).to(torch.bfloat16)
+            logs = []
+            for _ in range(2):
+                ddist._wire_log = []
+                p_sh = ddist.encode_sharded(pipe.vae, video).parameters
+                d_sh = ddist.decode_sharded(pipe.vae, z, _range01=True, gather="none")
+                logs.append(list(ddist._wire_log))
+                ddist._wire_log = None
+            st = pipe.vae.last_halo_stats_decode
+            ok = None
+            if rank == 0:
+                ok = bool(torch.equal(p_sh, pipe.vae.encode(video).latent_dist.parameters))
+            q.put(("wires", rank, logs, st["recv_preposted"], st["recv_blocking"], st["communicators"], ok))
         elif mode.startswith("ulysses"):
             F = 17
             video = (torch.rand(1, 3, F, 16, 32, generator=g) * 2 - 1).to(torch.bfloat16)
@@ -193,6 +209,53 @@ def test_paired_pieces_vae(world):
     assert shape == (1, 3, 33, 16, 32)
     assert enc_err <= 2 ** -6 and dec_err <= 2 ** -7, (enc_equal, dec_equal, enc_err, dec_err)
     print(f"[pieces x{world}] bit-identical enc {enc_equal} dec {dec_equal}; max |diff| enc {enc_err:.3g} dec {dec_err:.3g}")
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_halo_wavefront_communicators(world):
+    """RCCL runs the point-to-point operations of ONE communicator in issue order, so a rank whose pre-posted receives
+    (from rank-1) and sends (to rank+1) share a communicator sends its first halo only after its last one has arrived - the wavefront
+    serialises.  Since two ranks cannot share a GPU under RCCL the property is proved on the call log: every halo receive / send of the
+    sharded VAE (world 4: whole batches; world 8: paired pieces) is recorded as (communicator, op, peer) on real gloo ranks, and
+      * no rank has a "recv" and a "send" on the same communicator, in the recording pass and in the pre-posted pass;
+      * both ends of a link agree on its communicator (rank r sends to r+1 on the communicator r+1 receives from r on);
+      * the second pass really pre-posted (no blocking receive left) and the result is still bit-identical to one process;
+      * the GroupNorm pair swaps (world 8) ride a third communicator, as one grouped send+recv each."""
+    res = [r for r in _run(world, "wires", 0) if r[0] == "wires"]
+    assert len(res) == world
+    by_rank = {r[1]: r for r in res}
+    assert by_rank[0][6] is True, "sharded encode differs from the single-process one"
+    for p in (0, 1):
+        comm_of = {}                                             # (src, dst) -> communicator, as seen by either end
+        for rank, (_, _, logs, pre, blocking, comms, _) in by_rank.items():
+            log = logs[p]
+            recv_comms = {c for c, op, _ in log if op == "recv"}
+            send_comms = {c for c, op, _ in log if op == "send"}
+            swap_comms = {c for c, op, _ in log if op == "swap"}
+            assert not (recv_comms & send_comms), f"pass {p} rank {rank}: receives and sends share communicator(s) {recv_comms & send_comms}"
+            assert not (swap_comms & (recv_comms | send_comms)), f"pass {p} rank {rank}: GroupNorm swaps share a halo communicator"
+            assert len(recv_comms) <= 1 and len(send_comms) <= 1
+            assert (rank == 0) == (not recv_comms) and (rank == world - 1) == (not send_comms), (rank, recv_comms, send_comms)
+            assert (world > 4) == bool(swap_comms)
+            for c, op, peer in log:
+                if op == "recv":
+                    assert peer == rank - 1
+                    assert comm_of.setdefault((peer, rank), c) == c
+                elif op == "send":
+                    assert peer == rank + 1
+                    assert comm_of.setdefault((rank, peer), c) == c
+            # halos in conv order: pass 0 interleaves (blocking receive where the halo is consumed), pass 1 posts every receive first
+            ops_ = [op for _, op, _ in log if op in ("recv", "send")]
+            if p == 1 and 0 < rank < world - 1:
+                first_send = ops_.index("send")
+                n_recv_enc = ops_[:first_send].count("recv")
+                assert n_recv_enc > 1, "second pass: the receives of a stage must all be posted before its first send"
+        assert len(comm_of) == world - 1
+        assert all(comm_of[(r - 1, r)] != comm_of[(r, r + 1)] for r in range(1, world - 1)), comm_of
+    for rank, (_, _, _, pre, blocking, comms, _) in by_rank.items():
+        if rank > 0:
+            assert pre > 0 and blocking == 0, (rank, pre, blocking)
+        assert comms["recv"] != comms["send"] and comms["stage"] not in (comms["recv"], comms["send"])
 
 
 def test_plan_pieces():

@@ -203,7 +203,7 @@ def test_prodshape_conv_out_tap_split_720x1280():
 def test_prodshape_layernorm_modulate_and_qkv_post_18226():
     """CogVideoXLayerNormZero's normalise + modulate (text rows 0..225 with one (shift, scale) pair, video rows with the other) and the
     attention pre-processing (per-head LayerNorm-64 of q / k with affine, interleaved RoPE on the video rows only, scale * log2 e folded
-    into q, head-major stores, V^T quad-swapped, pad rows zero, per-head max squared norms) at N = 18 226 rows x 48 heads, against plain
+    into q, head-major stores, V^T quad-swapped, pad rows left zero, per-head max squared norms) at N = 18 226 rows x 48 heads, against plain
     F.layer_norm / the rotation formula in fp32 on sampled rows: the first / last rows, the text | video boundary, 256-row block seams."""
     N, D, heads, Lt = 18226, 3072, 48, 226
     npad = (N + 127) // 128 * 128
@@ -227,9 +227,9 @@ def test_prodshape_layernorm_modulate_and_qkv_post_18226():
     ang = torch.rand(N - Lt, 32, generator=gw) * 6.28
     cos, sin = ang.cos().repeat_interleave(2, 1).contiguous(), ang.sin().repeat_interleave(2, 1).contiguous()
     qscale = 0.125 * math.log2(math.e)
-    Qg = torch.full((heads, npad, 64), 5.0, dtype=BF, device="cuda")            # stale contents: the pad rows must come back zero
-    Kg = torch.full((heads, npad, 64), 5.0, dtype=BF, device="cuda")
-    Vg = torch.full((heads, 64, npad), 5.0, dtype=BF, device="cuda")
+    Qg = torch.zeros(heads, npad, 64, dtype=BF, device="cuda")                   # the contract: pad rows pre-zeroed by the caller (include/dove_hip.h)
+    Kg = torch.zeros(heads, npad, 64, dtype=BF, device="cuda")
+    Vg = torch.zeros(heads, 64, npad, dtype=BF, device="cuda")
     n2 = torch.full((heads, 2), -1.0, device="cuda")
     ops.qkv_post(qkv, N, npad, heads, Lt, gq.cuda(), bq.cuda(), gk.cuda(), bk.cuda(), cos.cuda(), sin.cuda(), qscale, 1e-6, Qg, Kg, Vg, norm2=n2)
     torch.cuda.synchronize()
@@ -311,3 +311,38 @@ def test_prodshape_attention_18226_48_heads_sampled():
     for h in (0, 47):
         ref = _attention_ref(Q[h:h + 1, :N].cpu(), K[h:h + 1, :N].cpu(), V[h:h + 1, :, :N].cpu(), rows)[0]
         close(f"prod_attention_48h_running_max head {h}", out3[rows.cuda(), h * 64:(h + 1) * 64], ref.to(BF), rtol=3e-2, afrac=8e-3)
+
+
+def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280():
+    """The first oracle comparison of a whole stage at the headline size: `pipe.vae.encode` on a 9 x 720 x 1280 clip (= the first
+    frame-batch of the 33-frame clip: diffusers' 9, 8, 8, 8 rule; /root/reference/inference_script.py:408) through the product path
+    (im2col'ed conv_in, w_first temporal sums, fused GroupNorm statistics over 33 M-element groups, three stride-2 downsamples, two
+    temporal pools) against oracle/vae.py in fp32 on the host cores, with the oracle's bf16 emulation (a rounding at every module output =
+    what the reference's bf16 run does) as the yardstick: err_hip <= 1.25 x err_bf16 + 1e-3 on the posterior moments, the gate of the
+    256 x 256 stage tests.  ~73 TFLOP per oracle pass."""
+    import os
+    import time
+
+    from dove_amd import config, weights
+    from dove_amd.vae import AutoencoderKLCogVideoX
+    from oracle.vae import OracleVAE
+    from test_parity_gpu import rms_rel, synth_clip
+    v, _t, _s = config.default_configs()
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), 77)
+    vae = AutoencoderKLCogVideoX(v, wv, "cuda")
+    F_, H, W = 9, 720, 1280
+    video = synth_clip(F_, H, W, seed=5)
+    got = vae.encode(video.cuda().to(BF)).latent_dist.parameters
+    torch.cuda.synchronize()
+    assert got.shape == (1, 32, 3, H // 8, W // 8)
+    torch.set_num_threads(min(os.cpu_count() or 1, 128))
+    vb = video.to(BF)                                           # both oracles see the clip the HIP path sees (bf16 boundary tensor)
+    t0 = time.time()
+    ref32 = OracleVAE(v, wv).encode(vb.float())
+    t1 = time.time()
+    refbf = OracleVAE(v, wv, torch.bfloat16).encode(vb)
+    t2 = time.time()
+    e_hip, e_bf = rms_rel(got, ref32), rms_rel(refbf, ref32)
+    print(f"[encoder 9x720x1280] fp32 oracle {t1 - t0:.0f} s, bf16-emulated oracle {t2 - t1:.0f} s on {torch.get_num_threads()} threads; "
+          f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
+    assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
