@@ -420,6 +420,8 @@ def main():
                          "top_classes": {k: {"ms": a[1] / prof_steps, "tflops": a[0] / (a[1] * 1e-3) / 1e12, "launches": a[2] // prof_steps}
                                          for k, a in top}},
             "model_build_s": t_build,
+            # peak of torch's allocator over the run so far (weights 11.6 GB + the clip's activations; two VAE streams = two pools)
+            "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(dev) / 1e9, "hbm_peak_reserved_gb": torch.cuda.max_memory_reserved(dev) / 1e9,
         }
         if (args.frames, args.height, args.width) != (33, 720, 1280):
             res["note"] = "not BASELINE.json's headline clip size (33x720x1280): a side measurement"
