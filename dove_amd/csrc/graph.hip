@@ -515,6 +515,10 @@ int halo_begin(dove_ctx* c, const std::string& key, void* stream) {
   CHK(ensure_comm_streams(c));
   auto it = c->halo_plans.find(key);
   if (it == c->halo_plans.end() || !c->halo_can_prepost) return 0;
+  // A custom transport matches messages in order per (source, destination) pair and has no channels: when this work item is the UPPER piece of
+  // a split frame-batch, its partner's GroupNorm sums and its halos both come from rank - 1, interleaved in layer order - receives posted ahead
+  // would pair with the wrong messages.  (RCCL: the halos have their own communicators; dove_amd/dist.py: the side group.)
+  if (!c->rccl_comm && c->piece_partner == c->rank - 1) return 0;
   std::vector<void*> got;
   for (auto& nb : it->second) {
     void* p = c->arena.alloc(nb.second, true);

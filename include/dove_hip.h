@@ -344,7 +344,9 @@ int dove_create(int hip_device, const dove_model_config* cfg, dove_ctx** out);
  * every symmetric exchange is one ncclGroup; the halos of the two directions travel on two further communicators made with ncclCommSplit).
  * dove_comm_init_custom: any transport - send / recv of `bytes` device bytes to / from rank `peer`, ordered on `stream`, matched in order per
  * (source, destination) pair.  `stream` is the caller's for the symmetric exchanges and one of the context's two internal streams for
- * halos: a transport that hands data from the sender's stream to the receiver's must order the two itself (an event per message). */
+ * halos: a transport that hands data from the sender's stream to the receiver's must order the two itself (an event per message).  Because
+ * a custom transport has no channels, halo receives are posted ahead only for work items whose GroupNorm partner is not rank - 1 (the pair
+ * sums would share the halos' message order); under RCCL the halos have communicators of their own and are always posted ahead. */
 typedef int (*dove_xfer_fn)(void* user, int peer, void* dev_ptr, size_t bytes, void* stream);
 /* Bracket of ONE exchange (ABI 12).  The paired-piece VAE swaps 65 doubles with a partner per GroupNorm and the sharded DiT runs all-to-alls:
  * symmetric patterns in which every rank sends and receives.  A transport whose send rendezvous with the peer's receive (RCCL) must see the

@@ -491,16 +491,19 @@ def test_one_clip_sharded_c_level(both, R):
         outs = _run_ranks(ctxs, lambda r, c: (c.shard_frames(0, F), c.vae_encode(video, out=torch.full_like(m_ref, float("nan"))), c.halo_stats()))
         torch.cuda.synchronize()
         m = torch.full_like(m_ref, float("nan"))
+        # (a rank whose first work item is the UPPER piece of a split frame-batch - the odd ranks at R = 8 - gets its partner's GroupNorm sums and its
+        # halos from the same peer in one message order: a transport without channels cannot post those receives ahead, include/dove_hip.h)
+        ahead = lambda r: r > 0 and not (R == 8 and r % 2 == 1)   # noqa: E731
         for r, ((first, count), o, st) in enumerate(outs):
             m[:, first:first + count] = o[:, first:first + count]
-            assert st["blocking"] == 0 and (st["preposted"] > 0) == (r > 0), (r, st)
+            assert (st["blocking"] == 0) == (r == 0 or ahead(r)) and (st["preposted"] > 0) == ahead(r), (r, st)
         assert torch.equal(m, m_ref), "sharded encode with pre-posted halos differs"
         outs = _run_ranks(ctxs, lambda r, c: (c.shard_frames(1, T), c.vae_decode(z, prescale=1 / 0.7, range01=True, out=torch.full_like(d_ref, float("nan"))), c.halo_stats()))
         torch.cuda.synchronize()
         d = torch.full_like(d_ref, float("nan"))
         for r, ((first, count), o, st) in enumerate(outs):
             d[:, first:first + count] = o[:, first:first + count]
-            assert st["blocking"] == 0 and (st["preposted"] > 0) == (r > 0), (r, st)
+            assert (st["blocking"] == 0) == (r == 0 or ahead(r)) and (st["preposted"] > 0) == ahead(r), (r, st)
         assert torch.equal(d, d_ref), "sharded decode with pre-posted halos differs"
         box.keep.clear()
         # ---- DiT: rows / heads sharded, the velocity complete on every rank ----
