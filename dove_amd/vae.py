@@ -207,6 +207,12 @@ class AutoencoderKLCogVideoX:
             if ev_prev is not None:
                 cache.stream.wait_event(ev_prev)
                 prev.record_stream(cache.stream)   # keep the other stream's tensor alive for this stream's read
+        tdup = kw.get("tdup", 0)
+        if tdup == 1 and prev is not None and not fetch and not cache.get(name + "#pair", False):
+            # ``tdup = 1`` also declares the CACHE a bit-identical pair.  It is one exactly when the previous batch's input was doubled and at
+            # least as long as the halo (its last two frames are then a pair); a shorter batch leaves a slid window (prev[1], x0), which is
+            # not.  frame_batches cannot produce that sequence today, but the declaration is checked here, not assumed
+            kw["tdup"] = 0
         if x.shape[0] >= k:
             new = x[-k:]      # a view: conv inputs are never written again, the batch tensor simply stays alive
         else:  # fewer frames than the halo: slide the padded window
@@ -216,6 +222,7 @@ class AutoencoderKLCogVideoX:
             cache.publish(name, new)
         else:
             cache[name] = new
+            cache[name + "#pair"] = bool(tdup) and x.shape[0] >= k      # doubled input (tmode 1: pairs from frame 0; 2: from frame 1, odd length)
         return ops.conv(x, pc, cache=prev, **kw)
 
     # set by dove_amd.dist while a rank runs a PIECE of a frame-batch (the batch is split over a rank pair):

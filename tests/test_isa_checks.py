@@ -247,3 +247,36 @@ def test_pipelined_attention_step_is_what_was_placed(tmp_path):
                         break
                 else:
                     raise AssertionError(f"no reader of {dst} found")
+        # ---- the ragged-tail steps: `mask_tail` WRITES the S tuples of tile j + 1 with v_cndmask right behind their chains - a WAW on
+        # registers an asm MFMA is still producing, which hipcc does not model.  A 32x32x16 MFMA occupies the pipe for 16 passes, so two other
+        # MFMAs (or 19 instructions) between the chain's last MFMA and the first VALU write cover the 18 wait states.  And everywhere: the
+        # instruction right behind an asm v_exp_f32 must not read its destination (the trans-use wait state) ----
+        n_tail_checked = 0
+        for k in range(5, len(bars) - 1):
+            st = lines[bars[k]:bars[k + 1]]
+            last = {}
+            for i, l in enumerate(st):
+                if l.startswith("v_mfma_f32_32x32x16_bf16 v["):
+                    last[l.split()[1].rstrip(",")] = i
+            for dst, i in last.items():
+                regs = _regs(dst)
+                for m in range(i + 1, len(st)):
+                    t = st[m]
+                    if t.startswith("v_mfma") or not t.startswith("v_"):
+                        continue
+                    ops_ = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+                    if ops_ and (_regs(ops_[0]) & regs):                 # first operand = destination
+                        between = sum(1 for x in st[i + 1:m] if x.startswith("v_mfma"))
+                        assert between >= 2 or m - i >= 19, f"NB {nb} tail step {k}: `{t}` overwrites {dst} {m - i} instructions / {between} MFMAs behind its chain"
+                        n_tail_checked += 1
+                        break
+        assert n_tail_checked >= 2 * nb, f"NB {nb}: the masked tail steps were not found ({n_tail_checked} chain -> VALU-write pairs)"
+        for k in range(1, len(bars) - 1):
+            st = lines[bars[k]:bars[k + 1]]
+            for i, l in enumerate(st[:-1]):
+                if l.startswith("v_exp_f32"):
+                    d = _regs(l.split()[1].rstrip(","))
+                    nxt = st[i + 1]
+                    srcs = re.findall(r"v\[\d+:\d+\]|v\d+", nxt)
+                    reads = srcs[1:] if nxt.startswith("v_") and not nxt.startswith("v_mfma") else srcs
+                    assert not any(_regs(x) & d for x in reads), f"NB {nb} step {k}: `{nxt}` reads the result of `{l}` in the very next slot"
