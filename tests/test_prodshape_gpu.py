@@ -346,3 +346,57 @@ def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280():
     print(f"[encoder 9x720x1280] fp32 oracle {t1 - t0:.0f} s, bf16-emulated oracle {t2 - t1:.0f} s on {torch.get_num_threads()} threads; "
           f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
+
+
+def test_prodshape_dit_2_layers_18226_vs_oracle(golden_dir):
+    """The DiT at the HEADLINE sequence length against the oracle: full-width CogVideoXTransformer3DModel, 2 of its 42 blocks, on the latent of
+    a 33 x 720 x 1280 clip (10 x 16 x 90 x 160 -> 18 000 video tokens + 226 text rows = 18 226; /root/reference/inference_script.py:483-489) -
+    patch embedding, LayerNormZero, the QKV / out / FF linears with their row tails (864 / 2 592 / 3 456 tiles on 256 CUs), QK-LayerNorm + RoPE,
+    the 48-head attention on `attn_pipe_kernel` (13.5 rounds; asserted), gated residuals, norm_out / proj_out / un-patchify - every residual
+    stream and the velocity against oracle/dit.py in fp32 with its bf16 emulation as the yardstick (err_hip <= 1.5 x err_bf16 + 2e-3, the
+    rule of test_dit_42_layers_per_block; 16 TFLOP per oracle pass)."""
+    import os
+    import time
+
+    from safetensors.torch import load_file
+
+    from dove_amd import config, weights
+    from dove_amd.transformer import CogVideoXTransformer3DModel
+    from oracle import dit as odit
+    from test_parity_gpu import rms_rel
+    _v, t, _s = config.default_configs()
+    t["num_layers"] = 2
+    wt = weights.LazyStateDict(weights.dit_param_shapes(t), 93, device="cuda")
+    tr = CogVideoXTransformer3DModel(t, wt, "cuda")
+    text = load_file(os.path.join(golden_dir, "empty_prompt_embedding.safetensors"))["prompt_embedding"]
+    g = torch.Generator().manual_seed(8)
+    latent = torch.randn(1, 10, 16, 90, 160, generator=g)
+    rope = odit.rope_3d(64, 5, 45, 80)
+    ts = torch.tensor([399])
+    tr.attn_bound_trace, tr.attn_path_trace = [], []
+    blocks = {}
+    vh = tr(hidden_states=latent.cuda().to(BF), encoder_hidden_states=text[None].cuda(), timestep=ts.cuda(),
+            image_rotary_emb=tuple(r.cuda() for r in rope), return_dict=False, _trace=blocks)[0]
+    torch.cuda.synchronize()
+    for n2 in tr.attn_path_trace:
+        assert ops.attention_head_paths(n2) == ["attn_pipe_kernel"] * 48
+    tr.attn_bound_trace = None
+    assert blocks["embed"].shape == (18226, 3072)
+    torch.set_num_threads(min(os.cpu_count() or 1, 128))
+    lb = latent.to(BF)                                          # both oracles see the bf16 boundary tensor the HIP path sees
+    tr32, trbf = {}, {}
+    t0 = time.time()
+    v32 = odit.OracleDiT(t, wt.moved("cpu")).forward(lb.float(), text.float()[None], ts, rope, tr32)
+    t1 = time.time()
+    vbf = odit.OracleDiT(t, wt.moved("cpu"), torch.bfloat16).forward(lb, text[None], ts, rope, trbf)
+    t2 = time.time()
+    rows = []
+    for name in ("embed", "block0", "block1"):
+        r32 = tr32[name][0]
+        rows.append((name, rms_rel(blocks[name], r32), rms_rel(trbf[name][0], r32)))
+    ev, evb = rms_rel(vh, v32), rms_rel(vbf, v32)
+    print(f"[dit 2 layers, N = 18226] fp32 oracle {t1 - t0:.0f} s, bf16-emulated {t2 - t1:.0f} s; rms-rel vs fp32 (hip | bf16-emulated reference): "
+          + "  ".join(f"{n}:{a:.2e}|{b:.2e}" for n, a, b in rows) + f"  velocity:{ev:.2e}|{evb:.2e}")
+    for name, eh, eb in rows:
+        assert eh <= 1.5 * eb + 2e-3, (name, eh, eb)
+    assert ev <= 1.5 * evb + 2e-3, (ev, evb)
