@@ -37,7 +37,7 @@ mfma_busy = {k: v["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (v["GRBM_GUI_ACTIVE"][0] / 8 
 top = {"kernel_source_sha256": kernel_source_sha256(),
        "whole_step_mfma_busy_frac": (mb / (ga / 8 * 1024)) if ga else None,
        "mfma_busy_frac_per_kernel": {k: round(x, 4) for k, x in sorted(mfma_busy.items(), key=lambda kv: -kv[1])[:12]},
-       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-variants --vae-streams 1 (ONE stream: the TCC counters of a dispatch count whatever the chip moves while it runs)",
        "fetch_correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncorrected", "per_kernel": res}
 for dk in ("conv3x3_halo4x_kernel", "conv3x3_halo8_kernel"):
     if dk in res:
