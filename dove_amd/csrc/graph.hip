@@ -255,6 +255,7 @@ struct dove_ctx {
   std::unordered_map<std::string, Tensor> cache;        // conv_cache of the running clip (views or copies)
   std::unordered_map<std::string, void*> cache_owner;   // arena block a cache entry keeps alive (a retained conv input) or the copy itself
   std::unordered_map<std::string, long long> cache_stride;   // nb > 1: elements between two instances' cache frames (dove_conv_desc.cache_stride)
+  std::unordered_map<std::string, bool> cache_pair;     // the cache entry is a known bit-identical frame pair (what dove_conv_desc.tdup == 1 declares of it)
   int nb = 1;                                           // > 1 while tiled() runs nb same-shaped tiles as one batch (Tensor.T = nb x frames)
   float* gn_ws = nullptr; int gn_ws_rows = 0;
   float* conv_out_bias = nullptr;                       // != NULL: decoder.conv_out runs tap-split ("decoder.conv_out.taps" + gather)
@@ -654,7 +655,10 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     Tensor prev;
     const bool have = it != c->cache.end();
     if (have) { prev = it->second; o.cache = &prev; o.cache_stride = c->cache_stride[name]; }
+    const int tdup_in = o.tdup;
+    if (o.tdup == 1 && have && !c->cache_pair[name]) o.tdup = 0;   // the declaration covers the cache: only a doubled input of >= k frames leaves a pair
     CHK(conv(c, x, pc, o, out, stream));
+    c->cache_pair[name] = tdup_in != 0 && Ti >= k;
     void* old_owner = have ? c->cache_owner[name] : nullptr;
     Tensor nc; nc.T = nb * k; nc.H = x.H; nc.W = x.W; nc.C = x.C;
     if (x_owned && Ti >= k && c->arena.cap - c->arena.used > 8 * x.bytes()) {
@@ -693,13 +697,17 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     CHK(halo_fetch(c, name, h.bytes(), &hp, stream));          // lands on the context's receive stream; this stream only waits on its event
     h.p = (bf16_t*)hp;
     c->cache[name] = h; c->cache_owner[name] = h.p;
+    c->cache_pair[name] = true;                                // the previous rank's last frames: the same declaration holds there
     it = c->cache.find(name);
   }
   Tensor prev;
   const bool have = it != c->cache.end();
   if (have) prev = it->second;
   o.cache = have ? &prev : nullptr;
+  const int tdup_in = o.tdup;
+  if (o.tdup == 1 && have && !c->cache_pair[name]) o.tdup = 0;   //  a slid window of a short batch is not a pair: three taps, not two
   CHK(conv(c, x, pc, o, out, stream));
+  c->cache_pair[name] = tdup_in != 0 && x.T >= k;
   const long long frame = (long long)x.H * x.W * x.C;
   hipStream_t s = (hipStream_t)stream;
   void* old_owner = have ? c->cache_owner[name] : nullptr;
@@ -979,6 +987,7 @@ void clear_caches(dove_ctx* c) {
   c->cache.clear();
   c->cache_owner.clear();
   c->cache_stride.clear();
+  c->cache_pair.clear();
 }
 
 // ---- DiT (dove_amd/transformer.py) ------------------------------------------------------------------------------------------------

@@ -112,6 +112,8 @@ class AutoencoderKLCogVideoX:
         # enable_tiling(): run all tiles of one shape as one batch (False: one tile at a time, the round-3 loop - kept for the A/B)
         self.tile_batching = True
         self.tile_streams = 2
+        self.tile_batch_streams = 2       # inside a tile class: frame-batches alternate between two streams (1: one after the other)
+        self._tile_helpers = []
         self._tile_stream = None
         self.tile_batch_max = 16
         self._pack(state_dict)
@@ -189,6 +191,15 @@ class AutoencoderKLCogVideoX:
             nb = self._nb
             x5 = x.view(nb, x.shape[0] // nb, *x.shape[1:])
             prev = cache.get(name)
+            events = getattr(cache, "events", None)    # StreamCache: the class's frame-batches alternate between two HIP streams (_tiled)
+            if events is not None:
+                ev_prev = events.get(name)
+                ev = torch.cuda.Event()
+                ev.record(cache.stream)
+                events[name] = ev
+                if ev_prev is not None:
+                    cache.stream.wait_event(ev_prev)
+                    prev.record_stream(cache.stream)
             if x5.shape[1] >= k:
                 new = x5[:, -k:]
             else:
@@ -345,24 +356,47 @@ class AutoencoderKLCogVideoX:
             # on a second HIP stream - their launches fill the CUs the big class leaves idle in its partly filled last rounds and at
             # the deep levels (a 30x45 latent tile is 2 x 2 conv tiles), and vice versa
             side = None
+            main = torch.cuda.current_stream(self.device) if x_cl.is_cuda else None
             if self.tile_streams > 1 and len(order) > 1 and x_cl.is_cuda:
                 if self._tile_stream is None:
                     self._tile_stream = torch.cuda.Stream(device=self.device)
-                side, main = self._tile_stream, torch.cuda.current_stream(self.device)
+                side = self._tile_stream
                 side.wait_stream(main)                          # x_cl was produced on the caller's stream
             try:
                 for k, ((th, tw, _), members) in enumerate(order):
                     nb = len(members)
-                    cache, parts = {}, []
+                    base = side if (side is not None and k > 0) else main
+                    fbs = frame_batches(T, batch)
+                    # tile_batch_streams = 2: the class's frame-batches alternate between its own stream and a helper, ordered only by the
+                    # per-conv events of StreamCache (what _run_batches does for the untiled clip): the small launches of a 240x360 tile leave
+                    # more of the chip idle at their ends than a 720x1280 frame's, and the other batch's kernels fill it
+                    helper = None
+                    if self.tile_batch_streams > 1 and len(fbs) > 1 and base is not None:
+                        slot = 0 if base is main else 1
+                        while len(self._tile_helpers) <= slot:
+                            self._tile_helpers.append(torch.cuda.Stream(device=self.device))
+                        helper = self._tile_helpers[slot]
+                        helper.wait_stream(base)
+                        x_cl.record_stream(helper)
+                    cache, parts = (StreamCache() if helper is not None else {}), []
                     self._nb = nb
-                    with torch.cuda.stream(side if (side is not None and k > 0) else None):
+                    with torch.cuda.stream(base):
                         try:
-                            for s, e in frame_batches(T, batch):
-                                xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
-                                o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
-                                parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
+                            for bi, (s, e) in enumerate(fbs):
+                                st = helper if (helper is not None and bi % 2 == 1) else base
+                                if helper is not None:
+                                    cache.stream = st
+                                with torch.cuda.stream(st):
+                                    xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
+                                    o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
+                                    parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
                         finally:
                             self._nb = 1
+                            if helper is not None:
+                                base.wait_stream(helper)
+                        if helper is not None:
+                            for o_ in parts:
+                                o_.record_stream(base)
                         out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]
                     if side is not None and k > 0:
                         out.record_stream(main)                     # blended / cropped on the caller's stream below
