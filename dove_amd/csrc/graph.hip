@@ -168,12 +168,33 @@ struct Packed { bf16_t* w = nullptr; float* bias = nullptr; bf16_t* w_first = nu
 struct Tensor { bf16_t* p = nullptr; int T = 0, H = 0, W = 0, C = 0; long long elems() const { return (long long)T * H * W * C; } size_t bytes() const { return (size_t)elems() * 2; } };
 struct Stats { float* stats = nullptr; };
 
-// first-fit arena over one device allocation; offsets 256-byte aligned
+// first-fit arena over one device allocation; offsets 256-byte aligned.
+// STREAM TRACKING (round 6; off unless a VAE stage alternates its frame-batches between two streams): allocation and release are host-side
+// and assume that whoever gets a block next runs BEHIND its last user.  On one stream that is stream order.  With two, `release` records an
+// event on the stream that is current at the release (every use of the block is ordered before that point: an item's activations live and
+// die on the item's stream, a conv cache produced on the other stream is released only after the conv that read it has been enqueued here),
+// the free range keeps the latest event per stream, and `alloc` makes the current stream wait for the events of the OTHER stream on the range
+// it carves from.  Conservative (a split range hands its events to both parts), never wrong.
 struct Arena {
   char* base = nullptr; size_t cap = 0; bool owned = false; size_t used = 0, high = 0;   // high = peak of bytes in use
   std::map<size_t, size_t> free_;                       // offset -> size
   std::unordered_map<void*, size_t> live;
-  void reset() { free_.clear(); live.clear(); used = 0; if (cap) free_[0] = cap; }
+  struct Ev { long long e[2] = {-1, -1}; };             // per free range: pool index of the LAST release event of each stream (-1: none)
+  std::map<size_t, Ev> free_ev;                         // offset -> events (only while `track`)
+  bool track = false; int cur = 0; hipStream_t streams[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> pool; size_t pool_next = 0;
+  void reset() { free_.clear(); live.clear(); free_ev.clear(); used = 0; pool_next = 0; track = false; cur = 0; if (cap) free_[0] = cap; }
+  long long next_event() {                              // events are handed out in record order: a larger index on one stream = a later point of it
+    if (pool_next == pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); pool.push_back(e); }
+    return (long long)pool_next++;
+  }
+  static void merge_ev(Ev& into, const Ev& other) { for (int i = 0; i < 2; ++i) if (other.e[i] > into.e[i]) into.e[i] = other.e[i]; }
+  void on_alloc(size_t off) {                           // the range at `off` is about to be carved: order the current stream behind the other stream's releases
+    if (!track) return;
+    auto it = free_ev.find(off);
+    if (it == free_ev.end()) return;
+    if (it->second.e[cur ^ 1] >= 0) (void)hipStreamWaitEvent(streams[cur], pool[(size_t)it->second.e[cur ^ 1]], 0);
+  }
   // transient activations are carved first-fit from the FRONT; long-lived blocks (conv caches, which persist for a whole stage)
   // from the BACK, so they do not fragment the space the big per-layer tensors cycle through
   void* alloc(size_t n, bool from_back = false) {
@@ -182,8 +203,10 @@ struct Arena {
       for (auto it = free_.rbegin(); it != free_.rend(); ++it) {
         if (it->second >= n) {
           const size_t off = it->first, sz = it->second;
+          on_alloc(off);
           free_.erase(std::next(it).base());
-          if (sz > n) free_[off] = sz - n;
+          if (sz > n) free_[off] = sz - n;                        // the front remainder keeps the range's events (same key)
+          else if (track) free_ev.erase(off);
           void* p = base + off + (sz - n);
           live[p] = n;
           used += n;
@@ -196,7 +219,12 @@ struct Arena {
     for (auto it = free_.begin(); it != free_.end(); ++it) {
       if (it->second >= n) {
         const size_t off = it->first, rest = it->second - n;
+        on_alloc(off);
         free_.erase(it);
+        if (track) {
+          auto ie = free_ev.find(off);
+          if (ie != free_ev.end()) { const Ev ev = ie->second; free_ev.erase(ie); if (rest) free_ev[off + n] = ev; }
+        }
         if (rest) free_[off + n] = rest;
         void* p = base + off;
         live[p] = n;
@@ -214,10 +242,22 @@ struct Arena {
     size_t off = (char*)p - base, n = it->second;
     live.erase(it);
     used -= n;
+    Ev ev;
+    if (track) { const long long e = next_event(); (void)hipEventRecord(pool[(size_t)e], streams[cur]); ev.e[cur] = e; }
     auto nx = free_.lower_bound(off);
-    if (nx != free_.end() && off + n == nx->first) { n += nx->second; nx = free_.erase(nx); }
-    if (nx != free_.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; n += pv->second; free_.erase(pv); } }
+    if (nx != free_.end() && off + n == nx->first) {
+      if (track) { auto ie = free_ev.find(nx->first); if (ie != free_ev.end()) { Ev old = ie->second; free_ev.erase(ie); merge_ev(old, ev); ev = old; } }
+      n += nx->second; nx = free_.erase(nx);
+    }
+    if (nx != free_.begin()) {
+      auto pv = std::prev(nx);
+      if (pv->first + pv->second == off) {
+        if (track) { auto ie = free_ev.find(pv->first); if (ie != free_ev.end()) { Ev old = ie->second; free_ev.erase(ie); merge_ev(old, ev); ev = old; } }
+        off = pv->first; n += pv->second; free_.erase(pv);
+      }
+    }
     free_[off] = n;
+    if (track) free_ev[off] = ev;
   }
 };
 
@@ -258,6 +298,15 @@ struct dove_ctx {
   std::unordered_map<std::string, bool> cache_pair;     // the cache entry is a known bit-identical frame pair (what dove_conv_desc.tdup == 1 declares of it)
   int nb = 1;                                           // > 1 while tiled() runs nb same-shaped tiles as one batch (Tensor.T = nb x frames)
   float* gn_ws = nullptr; int gn_ws_rows = 0;
+  float* gn_ws2 = nullptr;                              // the second VAE stream's statistics scratch (allocated with the stream)
+  // Two-stream VAE (DOVE_OPT_VAE_STREAMS, default 2; dove_amd/vae.py n_streams): the frame-batches of an un-tiled single-rank stage alternate
+  // between the caller's stream and `vae_stream2`, ordered only by one event per causal conv (`cache_ev`: recorded behind the conv and its cache
+  // copy, waited for by the next batch's conv of the same name) - one batch's HBM-bound GroupNorm kernels run beside the tail of the other's convs.
+  // Same kernels on the same inputs: bit-identical.  The arena tracks the streams (struct Arena).
+  int opt_vae_streams = 2;
+  hipStream_t vae_stream2 = nullptr;
+  bool vae_multi = false;
+  std::unordered_map<std::string, long long> cache_ev;   // conv name -> arena event index of the batch that wrote the cache entry
   float* conv_out_bias = nullptr;                       // != NULL: decoder.conv_out runs tap-split ("decoder.conv_out.taps" + gather)
   Arena arena;
   std::string err;
@@ -406,6 +455,7 @@ int to_mx(dove_ctx* c, Packed* pc, PackedMx* out) {
 bool ends_with(const std::string& s, const char* suf) { const size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 
 // ---- operator wrappers (allocation from the arena + argument marshalling; mirrors dove_amd/ops.py) -----------------------------
+inline float* gn_scratch(dove_ctx* c) { return (c->vae_multi && c->arena.cur == 1) ? c->gn_ws2 : c->gn_ws; }   // one statistics scratch per VAE stream
 int alloc_t(dove_ctx* c, int T, int H, int W, int C, Tensor* t) {
   t->T = T; t->H = H; t->W = W; t->C = C;
   t->p = (bf16_t*)c->arena.alloc(t->bytes());
@@ -463,13 +513,13 @@ int conv(dove_ctx* c, const Tensor& x, const Packed& pc, const ConvOpt& o, Tenso
     // a piece of a split frame-batch: the statistics are the PAIR's - hand the raw fp64 sums of this piece on (norm_silu adds the partner's)
     double* sums = (double*)c->arena.alloc(64 * sizeof(double));
     if (!sums) { dove_set_error("workspace exhausted (GroupNorm sums)"); return DOVE_EINVAL; }
-    CHK(dove_groupnorm_sums_from_partials(partial, rows, c->gn_ws, sums, stream));
+    CHK(dove_groupnorm_sums_from_partials(partial, rows, gn_scratch(c), sums, stream));
     c->arena.release(partial);
     *o.gn_stats = (float*)sums;
   } else if (partial) {
     float* st = (float*)c->arena.alloc((size_t)nb * 64 * 4);
     const double count = (double)t_out * ho * wo * (pc.cout_store() / 32);
-    CHK(dove_groupnorm_finalize_partials_nb(partial, rows / nb, nb, count, o.gn_eps, c->gn_ws, (size_t)c->gn_ws_rows * 64 * 4, st, stream));
+    CHK(dove_groupnorm_finalize_partials_nb(partial, rows / nb, nb, count, o.gn_eps, gn_scratch(c), (size_t)c->gn_ws_rows * 64 * 4, st, stream));
     c->arena.release(partial);
     *o.gn_stats = st;
   }
@@ -704,6 +754,17 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   const bool have = it != c->cache.end();
   if (have) prev = it->second;
   o.cache = have ? &prev : nullptr;
+  if (c->vae_multi) {                                         // the entry was written on the OTHER stream: behind its conv and its cache copy
+    auto ie = c->cache_ev.find(name);
+    if (ie != c->cache_ev.end()) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->arena.pool[(size_t)ie->second], 0));
+  }
+  auto mark = [&]() -> int {                                  // ... and this batch's entry is complete from here on
+    if (!c->vae_multi) return 0;
+    const long long e = c->arena.next_event();
+    HIPCHK(hipEventRecord(c->arena.pool[(size_t)e], (hipStream_t)stream));
+    c->cache_ev[name] = e;
+    return 0;
+  };
   const int tdup_in = o.tdup;
   if (o.tdup == 1 && have && !c->cache_pair[name]) o.tdup = 0;   //  a slid window of a short batch is not a pair: three taps, not two
   CHK(conv(c, x, pc, o, out, stream));
@@ -718,6 +779,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     c->arena.release(old_owner);                              // the conv that read the old entry is already enqueued
     x.p = nullptr;
     if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
+    CHK(mark());
     return 0;
   }
   nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
@@ -735,6 +797,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   c->arena.release(old_owner);
   if (x_owned) free_t(c, x);
   if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
+  CHK(mark());
   return 0;
 }
 // frames one frame-batch of t input frames leaves behind the encoder's / decoder's temporal stages (diffusers' Downsample3D
@@ -834,7 +897,7 @@ int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::strin
     if (!sums) {
       sums = (double*)c->arena.alloc(64 * sizeof(double));
       DOVE_CHECK_ARG(sums, "workspace exhausted (GroupNorm sums)");
-      CHK(dove_groupnorm_sums_bf16(x.p, x.elems() / x.C, (long long)x.H * x.W, x.C, c->gn_ws, c->gn_ws_rows, sums, stream));
+      CHK(dove_groupnorm_sums_bf16(x.p, x.elems() / x.C, (long long)x.H * x.W, x.C, gn_scratch(c), c->gn_ws_rows, sums, stream));
     }
     double* msg = (double*)c->arena.alloc(3 * 72 * sizeof(double));
     DOVE_CHECK_ARG(msg, "workspace exhausted (GroupNorm pair message)");
@@ -848,7 +911,7 @@ int norm_silu(dove_ctx* c, const Tensor& x, float* fused_stats, const std::strin
     c->arena.release(msg);
   } else if (!stats) {
     stats = (float*)c->arena.alloc((size_t)nb * 64 * 4);
-    CHK(dove_groupnorm_stats_nb_bf16(x.p, nb, x.elems() / x.C / nb, (long long)x.H * x.W, x.C, eps, c->gn_ws, c->gn_ws_rows, stats, stream));
+    CHK(dove_groupnorm_stats_nb_bf16(x.p, nb, x.elems() / x.C / nb, (long long)x.H * x.W, x.C, eps, gn_scratch(c), c->gn_ws_rows, stats, stream));
   }
   const auto& gb = c->aff.at(name);
   CHK(alloc_t(c, x.T, x.H, x.W, x.C, out));
@@ -902,6 +965,7 @@ struct StageGuard {
     if (c && c->depth++ == 0) {
       clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; set_piece(c, nullptr);
       c->ev_next = 0; c->halo_posted.clear(); c->halo_record.clear(); c->halo_sent = false;
+      c->vae_multi = false; c->cache_ev.clear();
     }
   }
   ~StageGuard() { if (c) --c->depth; }
@@ -1082,6 +1146,9 @@ extern "C" void dove_destroy(dove_ctx* c) {
   if (!c) return;
   dove_comm_destroy(c);
   clear_caches(c);
+  if (c->vae_stream2) { (void)hipStreamSynchronize(c->vae_stream2); (void)hipStreamDestroy(c->vae_stream2); }
+  for (hipEvent_t e : c->arena.pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   for (void* p : c->owned) (void)hipFree(p);
   if (c->rope_dev) (void)hipFree(c->rope_dev);
   if (c->Qh) { (void)hipFree(c->Qh); (void)hipFree(c->Kh); (void)hipFree(c->Vt); }
@@ -1266,6 +1333,9 @@ extern "C" int dove_set_option(dove_ctx* c, int option, long long value) {
       c->opt_linear_mx = value != 0; return DOVE_OK;
     case DOVE_OPT_DIT_ATTN_MXFP8: c->opt_attn_mx = value != 0; return DOVE_OK;
     case DOVE_OPT_WEIGHT_SUMS: c->opt_weight_sums = value != 0; return DOVE_OK;
+    case DOVE_OPT_VAE_STREAMS:
+      DOVE_CHECK_ARG(value == 1 || value == 2, "dove_set_option: DOVE_OPT_VAE_STREAMS is 1 or 2");
+      c->opt_vae_streams = (int)value; return DOVE_OK;
     default: break;
   }
   dove_set_error("dove_set_option: unknown option %d", option);
@@ -1280,6 +1350,7 @@ extern "C" long long dove_get_option(dove_ctx* c, int option) {
     case DOVE_OPT_DIT_LINEAR_MXFP8: return c->opt_linear_mx;
     case DOVE_OPT_DIT_ATTN_MXFP8: return c->opt_attn_mx;
     case DOVE_OPT_WEIGHT_SUMS: return c->opt_weight_sums;
+    case DOVE_OPT_VAE_STREAMS: return c->opt_vae_streams;
     case DOVE_STAT_HALO_PREPOSTED: return c->stat_halo_preposted;
     case DOVE_STAT_HALO_BLOCKING: return c->stat_halo_blocking;
     case DOVE_STAT_HALO_SENT: return c->stat_halo_sent;
@@ -1417,6 +1488,7 @@ extern "C" size_t dove_workspace_bytes(dove_ctx* c, int F, int H, int W) {
   long long vae = 22 * top;                                                       // measured high water at 33x720x1280: 17.4 x top
   // enable_tiling(): the tiles of one shape run as one batch; overlapping tiles cover up to 6/5 x 5/4 = 1.5 x the frame
   if (c->opt_tiling) vae = vae * 3 / 2;
+  else if (c->opt_vae_streams >= 2 && c->nranks == 1) vae = vae * 17 / 10;          // two frame-batches in flight (measured high water at 33x720x1280: see test_sr_clip_full_size_timing)
   const int D = cf.dit_heads * cf.dit_head_dim;
   const long long Td = T + (T % cf.dit_patch_t);
   const long long N = cf.dit_max_text + (Td / cf.dit_patch_t) * (H / 8 / cf.dit_patch) * (W / 8 / cf.dit_patch);
@@ -1427,7 +1499,11 @@ extern "C" size_t dove_workspace_bytes(dove_ctx* c, int F, int H, int W) {
 extern "C" int dove_set_workspace(dove_ctx* c, void* dev_ptr, size_t bytes) {
   DOVE_CHECK_ARG(c, "dove_set_workspace: null context");
   if (c->arena.owned && c->arena.base) (void)hipFree(c->arena.base);
-  c->arena = Arena();
+  {
+    std::vector<hipEvent_t> pool = std::move(c->arena.pool);    // the event pool outlives the workspace
+    c->arena = Arena();
+    c->arena.pool = std::move(pool);
+  }
   if (dev_ptr) { c->arena.base = (char*)dev_ptr; c->arena.cap = bytes; c->arena.owned = false; }
   else { void* p; HIPCHK(hipMalloc(&p, bytes)); c->arena.base = (char*)p; c->arena.cap = bytes; c->arena.owned = true; }
   c->arena.reset();
@@ -1592,6 +1668,42 @@ static int ensure_ws(dove_ctx* c, int F, int H, int W) {
   return 0;
 }
 
+// ---- two-stream frame-batch loop (dove_ctx::opt_vae_streams) ----
+struct VaeStreams {
+  dove_ctx* c; hipStream_t caller;
+  VaeStreams(dove_ctx* ctx, void* stream) : c(ctx), caller((hipStream_t)stream) {}
+  int begin(size_t nitems) {
+    c->vae_multi = false;
+    if (c->opt_vae_streams < 2 || c->nranks > 1 || nitems < 2 || c->nb > 1) return 0;
+    if (!c->vae_stream2) HIPCHK(hipStreamCreateWithFlags(&c->vae_stream2, hipStreamNonBlocking));
+    if (!c->gn_ws2) { void* m; CHK(dev_alloc(c, (size_t)c->gn_ws_rows * 64 * 4, &m)); c->gn_ws2 = (float*)m; }
+    Arena& a = c->arena;
+    a.track = true; a.cur = 0; a.streams[0] = caller; a.streams[1] = c->vae_stream2;
+    c->cache_ev.clear();
+    const long long e = a.next_event();                       // the second stream starts behind what the caller's stream holds so far (the converted clip)
+    HIPCHK(hipEventRecord(a.pool[(size_t)e], caller));
+    HIPCHK(hipStreamWaitEvent(c->vae_stream2, a.pool[(size_t)e], 0));
+    c->vae_multi = true;
+    return 0;
+  }
+  void* item(size_t i) {                                      // stream of work item i (and the arena's current stream with it)
+    if (!c->vae_multi) return (void*)caller;
+    c->arena.cur = (int)(i & 1);
+    return (void*)c->arena.streams[i & 1];
+  }
+  int end() {                                                 // join: the caller's stream continues behind the second one; tracking off
+    if (!c->vae_multi) return 0;
+    Arena& a = c->arena;
+    c->vae_multi = false;
+    const long long e = a.next_event();
+    const hipError_t r1 = hipEventRecord(a.pool[(size_t)e], c->vae_stream2), r2 = hipStreamWaitEvent(caller, a.pool[(size_t)e], 0);
+    a.track = false; a.cur = 0; a.free_ev.clear(); c->cache_ev.clear();
+    if (r1 != hipSuccess || r2 != hipSuccess) { dove_set_error("two-stream VAE: joining the streams failed"); return DOVE_ELAUNCH; }
+    return 0;
+  }
+  ~VaeStreams() { (void)end(); }                              // also on an early error return: nothing of this stage stays in flight un-joined
+};
+
 // moments [2L][T][h][w] (dtype) of x [3][F][H][W] (dtype), frame-batched like diffusers' _encode; conv caches are per call
 static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, int W, Tensor* moments, void* stream) {
   const auto& cf = c->cfg;
@@ -1625,7 +1737,11 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   rank_plan(c, true, F, &rp);
   if (rp.total_out != T) { dove_set_error("dove_vae_encode: the rank plan yields %d latent frames, expected %d", rp.total_out, T); return DOVE_EINVAL; }
   c->stat_halo_preposted = c->stat_halo_blocking = c->stat_halo_sent = 0;
+  VaeStreams vs(c, stream);
+  CHK(vs.begin(rp.mine.size()));
+  void* const caller_stream = stream;
   for (size_t i = 0; i < rp.mine.size(); ++i) {
+    stream = vs.item(i);
     const Piece& pc = rp.mine[i];
     c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
     c->halo_send = c->nranks > 1 && i + 1 == rp.mine.size() && c->rank < rp.active - 1;
@@ -1642,6 +1758,8 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
     HIPCHK(hipMemcpyAsync(moments->p + (long long)rp.out_first[i] * h * w * ld, o.p, o.bytes(), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     free_t(c, o);
   }
+  stream = caller_stream;
+  CHK(vs.end());
   free_t(c, xcl);
   clear_caches(c);
   CHK(halo_stage_end(c, stream));
@@ -1729,7 +1847,11 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   rank_plan(c, false, T, &rp);
   if (rp.total_out != F) { dove_set_error("dove_vae_decode: the rank plan yields %d frames, expected %d", rp.total_out, F); return DOVE_EINVAL; }
   c->stat_halo_preposted = c->stat_halo_blocking = c->stat_halo_sent = 0;
+  VaeStreams vs(c, stream);
+  CHK(vs.begin(rp.mine.size()));
+  void* const caller_stream = stream;
   for (size_t i = 0; i < rp.mine.size(); ++i) {
+    stream = vs.item(i);
     const Piece& pc = rp.mine[i];
     c->halo_recv = c->nranks > 1 && i == 0 && c->rank > 0;
     c->halo_send = c->nranks > 1 && i + 1 == rp.mine.size() && c->rank < rp.active - 1;
@@ -1759,6 +1881,8 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
     c->arena.release(tmp);
     free_t(c, o);
   }
+  stream = caller_stream;
+  CHK(vs.end());
   free_t(c, zcl);
   clear_caches(c);
   CHK(halo_stage_end(c, stream));

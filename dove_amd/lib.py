@@ -57,7 +57,7 @@ class PreNoise(C.Structure):
 
 
 # dove_set_option keys (include/dove_hip.h)
-OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP8, OPT_DIT_ATTN_MXFP8, OPT_WEIGHT_SUMS = 1, 2, 3, 4, 5, 6
+OPT_VAE_TILING, OPT_VAE_SAMPLE_HEIGHT, OPT_VAE_SAMPLE_WIDTH, OPT_DIT_LINEAR_MXFP8, OPT_DIT_ATTN_MXFP8, OPT_WEIGHT_SUMS, OPT_VAE_STREAMS = 1, 2, 3, 4, 5, 6, 7
 STAT_HALO_PREPOSTED, STAT_HALO_BLOCKING, STAT_HALO_SENT, STAT_HALO_COMMUNICATORS = 100, 101, 102, 103
 
 

@@ -386,6 +386,12 @@ void dove_destroy(dove_ctx* ctx);
  * w_pair) to its convolutions - every launch computes the reference's per-tap arithmetic (+7.6 % conv MACs), for a caller who wants a
  * checkpoint validated without the one extra bf16 rounding of the summed weights.  The Python facade's switch: pipe.vae.weight_sums. */
 #define DOVE_OPT_WEIGHT_SUMS 6
+/* DOVE_OPT_VAE_STREAMS (1 / 2, default 2; any time; ABI 14): 2 = the frame-batches of an un-tiled, single-rank dove_vae_encode / dove_vae_decode
+ * alternate between the caller's stream and one internal stream, ordered by one event per causal conv (the conv cache is the only dependency
+ * between frame-batches); the caller's stream continues behind both when the stage returns.  Same kernels on the same inputs: bit-identical
+ * to 1; +1.5 % per clip; the arena's high water grows by about a half (dove_workspace_bytes accounts for it).  The Python facade's switch:
+ * pipe.vae.n_streams. */
+#define DOVE_OPT_VAE_STREAMS 7
 /* read-only counters of the LAST dove_vae_encode / dove_vae_decode of a multi-rank context (dove_get_option; ABI 14): halos this rank received
  * from receives posted before the stage's first kernel / posted where they were consumed (the first pass over a (stage, shape) records the
  * list, later passes pre-post it), halos sent; DOVE_STAT_HALO_COMMUNICATORS: 3 = RCCL with one communicator per halo direction + the main

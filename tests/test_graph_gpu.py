@@ -120,6 +120,38 @@ def test_option_weight_sums_off_bit_exact(both):
         ctx.set_option(L.OPT_WEIGHT_SUMS, 1)
 
 
+def test_option_vae_streams_bit_exact(both):
+    """DOVE_OPT_VAE_STREAMS = pipe.vae.n_streams: 2 (the default on both sides) alternates the frame-batches of a stage between the caller's
+    stream and an internal one, ordered by one event per causal conv, with the arena tracking which stream released each block; 1 runs them
+    one after the other.  Same kernels on the same inputs: encode (33 frames = 4 batches) and decode (9 latent frames = 4 batches) must not
+    change a bit between the two, on either side of the C boundary, three times in a row (a missed cross-stream ordering would show as a
+    flaky difference, not a steady one)."""
+    from dove_amd import lib as L
+    pipe, ctx, _ = both
+    g = torch.Generator().manual_seed(21)
+    video = (torch.rand(3, 33, 64, 96, generator=g) * 2 - 1).to(BF).cuda()
+    z = torch.randn(16, 9, 16, 24, generator=g).to(BF).cuda()
+    assert ctx.get_option(L.OPT_VAE_STREAMS) == 2 and pipe.vae.n_streams == 2
+    try:
+        ctx.set_option(L.OPT_VAE_STREAMS, 1)
+        pipe.vae.n_streams = 1
+        m1, d1 = ctx.vae_encode(video), ctx.vae_decode(z, prescale=1 / 0.7, range01=True)
+        mp, dp = pipe.vae.encode(video[None]).latent_dist.parameters[0], pipe.vae.decode(z[None], _prescale=1 / 0.7, _range01=True).sample[0]
+        torch.cuda.synchronize()
+        assert torch.equal(m1, mp) and torch.equal(d1, dp)
+        ctx.set_option(L.OPT_VAE_STREAMS, 2)
+        pipe.vae.n_streams = 2
+        for rep in range(3):
+            m2, d2 = ctx.vae_encode(video), ctx.vae_decode(z, prescale=1 / 0.7, range01=True)
+            mq, dq = pipe.vae.encode(video[None]).latent_dist.parameters[0], pipe.vae.decode(z[None], _prescale=1 / 0.7, _range01=True).sample[0]
+            torch.cuda.synchronize()
+            assert torch.equal(m2, m1) and torch.equal(d2, d1), f"C graph: two streams changed the result (repetition {rep})"
+            assert torch.equal(mq, m1) and torch.equal(dq, d1), f"facade: two streams changed the result (repetition {rep})"
+    finally:
+        ctx.set_option(L.OPT_VAE_STREAMS, 2)
+        pipe.vae.n_streams = 2
+
+
 def test_option_vae_tiling_bit_exact(both):
     """DOVE_OPT_VAE_TILING = pipe.vae.enable_tiling() (`--is_vae_st`, ref :643-645): encode, decode and the whole clip through the C
     graph == the Python facade with the same switch, bit for bit; 3 x 3 tiles in both directions (sample size 96 x 160 -> 48 x 80 px
