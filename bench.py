@@ -478,6 +478,7 @@ def main():
             vsteps = max(1, min(args.steps, 5))
 
             def timed_variant():
+                torch.cuda.empty_cache()        # a variant must not run into the pools the previous configuration left cached (one pool per stream)
                 step()
                 barrier()
                 tv0 = time.perf_counter()

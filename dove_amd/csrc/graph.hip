@@ -183,7 +183,29 @@ struct Arena {
   std::map<size_t, Ev> free_ev;                         // offset -> events (only while `track`)
   bool track = false; int cur = 0; hipStream_t streams[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> pool; size_t pool_next = 0;
-  void reset() { free_.clear(); live.clear(); free_ev.clear(); used = 0; pool_next = 0; track = false; cur = 0; if (cap) free_[0] = cap; }
+  // While tracking, the space is split at `mid`: stream 0 allocates below it, stream 1 above (each falls back to the other half when its own is
+  // full), and free ranges are never merged across it - otherwise the two streams keep carving from ranges the other one just released and every
+  // allocation becomes a cross-stream wait (measured: the streams then run in lock-step and the second stream buys nothing).
+  size_t mid = 0;
+  void reset() { free_.clear(); live.clear(); free_ev.clear(); used = 0; pool_next = 0; track = false; cur = 0; mid = 0; if (cap) free_[0] = cap; }
+  void begin_tracking(hipStream_t s0, hipStream_t s1) {
+    track = true; cur = 0; streams[0] = s0; streams[1] = s1; free_ev.clear();
+    mid = (size_t)ru((long long)(cap / 2), 256);
+    auto it = free_.upper_bound(mid);
+    if (it != free_.begin()) {
+      --it;
+      if (it->first < mid && it->first + it->second > mid) { const size_t end = it->first + it->second; it->second = mid - it->first; free_[mid] = end - mid; }
+    }
+  }
+  void end_tracking() {
+    track = false; cur = 0; free_ev.clear();
+    if (mid) {
+      auto hi = free_.find(mid);
+      if (hi != free_.end() && hi != free_.begin()) { auto lo = std::prev(hi); if (lo->first + lo->second == mid) { lo->second += hi->second; free_.erase(hi); } }
+      mid = 0;
+    }
+  }
+  bool home(size_t off) const { return !track || ((off >= mid) == (cur == 1)); }
   long long next_event() {                              // events are handed out in record order: a larger index on one stream = a later point of it
     if (pool_next == pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); pool.push_back(e); }
     return (long long)pool_next++;
@@ -199,38 +221,40 @@ struct Arena {
   // from the BACK, so they do not fragment the space the big per-layer tensors cycle through
   void* alloc(size_t n, bool from_back = false) {
     n = (size_t)ru((long long)(n ? n : 1), 256);
-    if (from_back) {
-      for (auto it = free_.rbegin(); it != free_.rend(); ++it) {
-        if (it->second >= n) {
-          const size_t off = it->first, sz = it->second;
+    for (int pass = track ? 0 : 1; pass < 2; ++pass) {        // pass 0: the current stream's own half only
+      if (from_back) {
+        for (auto it = free_.rbegin(); it != free_.rend(); ++it) {
+          if (it->second >= n && (pass == 1 || home(it->first))) {
+            const size_t off = it->first, sz = it->second;
+            on_alloc(off);
+            free_.erase(std::next(it).base());
+            if (sz > n) free_[off] = sz - n;                        // the front remainder keeps the range's events (same key)
+            else if (track) free_ev.erase(off);
+            void* p = base + off + (sz - n);
+            live[p] = n;
+            used += n;
+            if (used > high) high = used;
+            return p;
+          }
+        }
+        continue;
+      }
+      for (auto it = free_.begin(); it != free_.end(); ++it) {
+        if (it->second >= n && (pass == 1 || home(it->first))) {
+          const size_t off = it->first, rest = it->second - n;
           on_alloc(off);
-          free_.erase(std::next(it).base());
-          if (sz > n) free_[off] = sz - n;                        // the front remainder keeps the range's events (same key)
-          else if (track) free_ev.erase(off);
-          void* p = base + off + (sz - n);
+          free_.erase(it);
+          if (track) {
+            auto ie = free_ev.find(off);
+            if (ie != free_ev.end()) { const Ev ev = ie->second; free_ev.erase(ie); if (rest) free_ev[off + n] = ev; }
+          }
+          if (rest) free_[off + n] = rest;
+          void* p = base + off;
           live[p] = n;
           used += n;
           if (used > high) high = used;
           return p;
         }
-      }
-      return nullptr;
-    }
-    for (auto it = free_.begin(); it != free_.end(); ++it) {
-      if (it->second >= n) {
-        const size_t off = it->first, rest = it->second - n;
-        on_alloc(off);
-        free_.erase(it);
-        if (track) {
-          auto ie = free_ev.find(off);
-          if (ie != free_ev.end()) { const Ev ev = ie->second; free_ev.erase(ie); if (rest) free_ev[off + n] = ev; }
-        }
-        if (rest) free_[off + n] = rest;
-        void* p = base + off;
-        live[p] = n;
-        used += n;
-        if (used > high) high = used;
-        return p;
       }
     }
     return nullptr;
@@ -245,13 +269,13 @@ struct Arena {
     Ev ev;
     if (track) { const long long e = next_event(); (void)hipEventRecord(pool[(size_t)e], streams[cur]); ev.e[cur] = e; }
     auto nx = free_.lower_bound(off);
-    if (nx != free_.end() && off + n == nx->first) {
+    if (nx != free_.end() && off + n == nx->first && !(mid && nx->first == mid)) {
       if (track) { auto ie = free_ev.find(nx->first); if (ie != free_ev.end()) { Ev old = ie->second; free_ev.erase(ie); merge_ev(old, ev); ev = old; } }
       n += nx->second; nx = free_.erase(nx);
     }
     if (nx != free_.begin()) {
       auto pv = std::prev(nx);
-      if (pv->first + pv->second == off) {
+      if (pv->first + pv->second == off && !(mid && off == mid)) {
         if (track) { auto ie = free_ev.find(pv->first); if (ie != free_ev.end()) { Ev old = ie->second; free_ev.erase(ie); merge_ev(old, ev); ev = old; } }
         off = pv->first; n += pv->second; free_.erase(pv);
       }
@@ -1678,7 +1702,7 @@ struct VaeStreams {
     if (!c->vae_stream2) HIPCHK(hipStreamCreateWithFlags(&c->vae_stream2, hipStreamNonBlocking));
     if (!c->gn_ws2) { void* m; CHK(dev_alloc(c, (size_t)c->gn_ws_rows * 64 * 4, &m)); c->gn_ws2 = (float*)m; }
     Arena& a = c->arena;
-    a.track = true; a.cur = 0; a.streams[0] = caller; a.streams[1] = c->vae_stream2;
+    a.begin_tracking(caller, c->vae_stream2);
     c->cache_ev.clear();
     const long long e = a.next_event();                       // the second stream starts behind what the caller's stream holds so far (the converted clip)
     HIPCHK(hipEventRecord(a.pool[(size_t)e], caller));
@@ -1697,7 +1721,7 @@ struct VaeStreams {
     c->vae_multi = false;
     const long long e = a.next_event();
     const hipError_t r1 = hipEventRecord(a.pool[(size_t)e], c->vae_stream2), r2 = hipStreamWaitEvent(caller, a.pool[(size_t)e], 0);
-    a.track = false; a.cur = 0; a.free_ev.clear(); c->cache_ev.clear();
+    a.end_tracking(); c->cache_ev.clear();
     if (r1 != hipSuccess || r2 != hipSuccess) { dove_set_error("two-stream VAE: joining the streams failed"); return DOVE_ELAUNCH; }
     return 0;
   }
