@@ -259,7 +259,7 @@ struct Arena {
     }
     return nullptr;
   }
-  void release(void* p) {
+  void release(void* p, bool shared = false) {
     if (!p) return;
     auto it = live.find(p);
     if (it == live.end()) return;
@@ -268,6 +268,9 @@ struct Arena {
     used -= n;
     Ev ev;
     if (track) { const long long e = next_event(); (void)hipEventRecord(pool[(size_t)e], streams[cur]); ev.e[cur] = e; }
+    if (track && shared) {                                      // a block BOTH streams read (a conv cache): whoever gets it next runs behind both
+      const long long e = next_event(); (void)hipEventRecord(pool[(size_t)e], streams[cur ^ 1]); ev.e[cur ^ 1] = e;
+    }
     auto nx = free_.lower_bound(off);
     if (nx != free_.end() && off + n == nx->first && !(mid && nx->first == mid)) {
       if (track) { auto ie = free_ev.find(nx->first); if (ie != free_ev.end()) { Ev old = ie->second; free_ev.erase(ie); merge_ev(old, ev); ev = old; } }
@@ -791,19 +794,22 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
   };
   const int tdup_in = o.tdup;
   if (o.tdup == 1 && have && !c->cache_pair[name]) o.tdup = 0;   //  a slid window of a short batch is not a pair: three taps, not two
+  // retained view (below): the next batch's halo IS the tail of this conv's input, complete before the conv runs - the other stream may
+  // start its conv of this name as soon as that input exists (dove_amd/vae.py records its event at the same point)
+  const bool retain = x_owned && x.T >= k && c->arena.cap - c->arena.used > 8 * x.bytes();
+  if (retain) CHK(mark());
   CHK(conv(c, x, pc, o, out, stream));
   c->cache_pair[name] = tdup_in != 0 && x.T >= k;
   const long long frame = (long long)x.H * x.W * x.C;
   hipStream_t s = (hipStream_t)stream;
   void* old_owner = have ? c->cache_owner[name] : nullptr;
   Tensor nc; nc.T = k; nc.H = x.H; nc.W = x.W; nc.C = x.C;
-  if (x_owned && x.T >= k && c->arena.cap - c->arena.used > 8 * x.bytes()) {
+  if (retain) {
     nc.p = x.p + (long long)(x.T - k) * frame;               // retain: a view of x's last k frames, x stays alive
     c->cache[name] = nc; c->cache_owner[name] = x.p;
-    c->arena.release(old_owner);                              // the conv that read the old entry is already enqueued
-    x.p = nullptr;
+    c->arena.release(old_owner, true);                        // the conv that read the old entry is already enqueued (on this stream; the
+    x.p = nullptr;                                            // entry's producer is the other one: Arena::release `shared`)
     if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
-    CHK(mark());
     return 0;
   }
   nc.p = (bf16_t*)c->arena.alloc(nc.bytes(), true);
@@ -818,7 +824,7 @@ int cconv(dove_ctx* c, Tensor& x, bool x_owned, const std::string& name, ConvOpt
     HIPCHK(hipMemcpyAsync(nc.p + (long long)(k - x.T) * frame, x.p, (size_t)x.T * frame * 2, hipMemcpyDeviceToDevice, s));
   }
   c->cache[name] = nc; c->cache_owner[name] = nc.p;
-  c->arena.release(old_owner);
+  c->arena.release(old_owner, true);
   if (x_owned) free_t(c, x);
   if (c->halo_send) CHK(halo_publish(c, nc.p, nc.bytes(), stream));
   CHK(mark());
@@ -1071,7 +1077,7 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
   return 0;
 }
 void clear_caches(dove_ctx* c) {
-  for (auto& kv : c->cache_owner) c->arena.release(kv.second);
+  for (auto& kv : c->cache_owner) c->arena.release(kv.second, true);
   c->cache.clear();
   c->cache_owner.clear();
   c->cache_stride.clear();
