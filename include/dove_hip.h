@@ -17,6 +17,8 @@
 #ifndef DOVE_HIP_H
 #define DOVE_HIP_H
 
+#include <stddef.h> /* size_t */
+
 #ifdef __cplusplus
 extern "C" {
 #endif

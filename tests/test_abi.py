@@ -180,3 +180,26 @@ def test_kernel_dispatch_table():
         covered.add(name((1, 1, N), cout, cin, (), act=kw.get("act", 0), gated=kw.get("gate", False), resid=kw.get("resid_only", False)))
     # the superseded 8-wave generations (conv3x3_halo8, gemm8) no longer exist: five kernels carry every shape
     assert covered == {"igemm_kernel", "igemm_fast_kernel", "conv3x3_halo4x_kernel", "gemm8p_kernel", "smallk_kernel"}, covered
+
+
+def test_header_is_self_contained_c_and_links(tmp_path):
+    """include/dove_hip.h is the whole contract of a non-Python host: it must compile as plain C99 on its own (round 6 found it leaning on a
+    `size_t` somebody else had to declare) and a C program must link against libdove_hip.so and read the ABI version back."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.c"
+    src.write_text('#include "dove_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { dove_conv_desc d; d.struct_size = (unsigned)sizeof d; (void)d;\n'
+                   '  printf("%d %d\\n", dove_abi_version(), DOVE_ABI_VERSION); return dove_abi_version() == DOVE_ABI_VERSION ? 0 : 1; }\n')
+    exe = tmp_path / "host"
+    lib_dir = os.path.join(root, "dove_amd")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-l:libdove_hip.so", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    a, b = out.stdout.split()
+    assert a == b
