@@ -313,19 +313,48 @@ def test_prodshape_attention_18226_48_heads_sampled():
         close(f"prod_attention_48h_running_max head {h}", out3[rows.cuda(), h * 64:(h + 1) * 64], ref.to(BF), rtol=3e-2, afrac=8e-3)
 
 
-def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280():
+def _two_oracles(stage, seed, x_bf16, tmp_path, conv_out_scale=1.0):
+    """(fp32 result, bf16-emulated result, seconds) of one oracle/vae.py stage on ``x_bf16``: the bf16 emulation runs in a CHILD process
+    (tests/oracle_worker.py, half of the host threads) while this process runs the fp32 oracle on the other half."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    from dove_amd import config, weights
+    from oracle.vae import OracleVAE
+    ncpu = os.cpu_count() or 2
+    threads = max(1, min(128, ncpu // 2))
+    src, dst = tmp_path / f"{stage}_in.pt", tmp_path / f"{stage}_bf16.pt"
+    torch.save(x_bf16, src)
+    t0 = time.time()
+    child = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py"), stage, str(seed), "bfloat16",
+                              str(threads), str(src), str(dst), str(conv_out_scale)])
+    try:
+        torch.set_num_threads(threads)
+        v, _t, _s = config.default_configs()
+        wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
+        for k in ("decoder.conv_out.conv.weight", "decoder.conv_out.conv.bias"):
+            wv[k] = wv[k] * conv_out_scale
+        vae = OracleVAE(v, wv)
+        ref32 = vae.encode(x_bf16.float()) if stage == "enc" else vae.decode(x_bf16.float())
+        t32 = time.time() - t0
+        assert child.wait(timeout=1500) == 0, "the bf16-emulated oracle (child process) failed"
+    finally:
+        if child.poll() is None:
+            child.kill()
+    return ref32, torch.load(dst), t32, time.time() - t0, threads
+
+
+def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280(tmp_path):
     """The first oracle comparison of a whole stage at the headline size: `pipe.vae.encode` on a 9 x 720 x 1280 clip (= the first
     frame-batch of the 33-frame clip: diffusers' 9, 8, 8, 8 rule; /root/reference/inference_script.py:408) through the product path
     (im2col'ed conv_in, w_first temporal sums, fused GroupNorm statistics over 33 M-element groups, three stride-2 downsamples, two
     temporal pools) against oracle/vae.py in fp32 on the host cores, with the oracle's bf16 emulation (a rounding at every module output =
     what the reference's bf16 run does) as the yardstick: err_hip <= 1.25 x err_bf16 + 1e-3 on the posterior moments, the gate of the
-    256 x 256 stage tests.  ~73 TFLOP per oracle pass."""
-    import os
-    import time
-
+    256 x 256 stage tests.  ~73 TFLOP per oracle pass; the two oracles run side by side (two processes)."""
     from dove_amd import config, weights
     from dove_amd.vae import AutoencoderKLCogVideoX
-    from oracle.vae import OracleVAE
     from test_parity_gpu import rms_rel, synth_clip
     v, _t, _s = config.default_configs()
     wv = weights.random_state_dict(weights.vae_param_shapes(v), 77)
@@ -335,16 +364,41 @@ def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280():
     got = vae.encode(video.cuda().to(BF)).latent_dist.parameters
     torch.cuda.synchronize()
     assert got.shape == (1, 32, 3, H // 8, W // 8)
-    torch.set_num_threads(min(os.cpu_count() or 1, 128))
-    vb = video.to(BF)                                           # both oracles see the clip the HIP path sees (bf16 boundary tensor)
-    t0 = time.time()
-    ref32 = OracleVAE(v, wv).encode(vb.float())
-    t1 = time.time()
-    refbf = OracleVAE(v, wv, torch.bfloat16).encode(vb)
-    t2 = time.time()
+    del vae
+    torch.cuda.empty_cache()
+    ref32, refbf, t32, tall, threads = _two_oracles("enc", 77, video.to(BF), tmp_path)     # both oracles see the bf16 boundary tensor the HIP path sees
     e_hip, e_bf = rms_rel(got, ref32), rms_rel(refbf, ref32)
-    print(f"[encoder 9x720x1280] fp32 oracle {t1 - t0:.0f} s, bf16-emulated oracle {t2 - t1:.0f} s on {torch.get_num_threads()} threads; "
+    print(f"[encoder 9x720x1280] fp32 oracle {t32:.0f} s, with the bf16-emulated oracle beside it {tall:.0f} s (2 x {threads} threads); "
           f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
+    assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
+
+
+def test_prodshape_decoder_first_latent_batch_vs_oracle_9x720x1280(tmp_path):
+    """... and the decoder: `pipe.vae.decode` of the first latent frame-batch of the headline clip (3 latent frames at 90 x 160 -> 9 frames at
+    720 x 1280: diffusers' 3, 2, 2, 2 rule; `decode_latents`, /root/reference/inference_script.py:500) through the product path - SpatialNorm3D
+    with the odd-T frame map at every level, the sub-pixel upsample convs (w_sub), Upsample3D's time doubling and the frame-pair sums (w_pair) behind
+    it, the first-frame sums (w_first), the tap-split conv_out - against oracle/vae.py in fp32 with its bf16 emulation as the yardstick
+    (err_hip <= 1.25 x err_bf16 + 1e-3 on the un-clamped output; conv_out scaled by 0.25 on both sides so that the output stays inside [-1, 1]
+    like a trained decoder's).  ~155 TFLOP per oracle pass, the two side by side."""
+    from dove_amd import config, weights
+    from dove_amd.vae import AutoencoderKLCogVideoX
+    from test_parity_gpu import CONV_OUT_SCALE, rms_rel
+    v, _t, _s = config.default_configs()
+    wv = weights.random_state_dict(weights.vae_param_shapes(v), 78)
+    for k in ("decoder.conv_out.conv.weight", "decoder.conv_out.conv.bias"):
+        wv[k] = wv[k] * CONV_OUT_SCALE
+    vae = AutoencoderKLCogVideoX(v, wv, "cuda")
+    z = (torch.randn(1, 16, 3, 90, 160, generator=torch.Generator().manual_seed(6)) * 1.4).to(BF)      # latent / scaling_factor: what decode_latents hands over
+    got = vae.decode(z.cuda()).sample
+    torch.cuda.synchronize()
+    assert got.shape == (1, 3, 9, 720, 1280)
+    del vae
+    torch.cuda.empty_cache()
+    ref32, refbf, t32, tall, threads = _two_oracles("dec", 78, z, tmp_path, CONV_OUT_SCALE)
+    sat = float((ref32.abs() >= 1).float().mean())
+    e_hip, e_bf = rms_rel(got, ref32), rms_rel(refbf, ref32)
+    print(f"[decoder 3x90x160 -> 9x720x1280] fp32 oracle {t32:.0f} s, with the bf16-emulated oracle beside it {tall:.0f} s (2 x {threads} threads); "
+          f"decoded (un-clamped, {100 * sat:.1f} % outside [-1, 1]) rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
 
 
