@@ -80,17 +80,19 @@ def _log_wire(group, op, peer):
         _wire_log.append((_comm_label(group), op, int(peer)))
 
 
-def _isend(t, dst, group):
+def _isend(t, dst, group, log=True):
     """-> (tensor to keep alive, work).  ``dst`` is a global rank."""
-    _log_wire(group, "send", dst)
+    if log:
+        _log_wire(group, "send", dst)
     if _direct(group):
         return t, dist.isend(t, dst=dst, group=group)
     h = t.cpu() if t.is_cuda else t                    # .cpu() waits for the producing stream
     return h, dist.isend(_bytes(h), dst=dst, group=group)
 
 
-def _irecv(buf, src, group):
-    _log_wire(group, "recv", src)
+def _irecv(buf, src, group, log=True):
+    if log:
+        _log_wire(group, "recv", src)
     if _direct(group):
         return dist.irecv(buf, src=src, group=group)
     if buf.is_cuda:
@@ -105,18 +107,13 @@ def _send(t, dst, group):
 def _exchange(mine, theirs, peer, group):
     """Symmetric swap with one peer, both directions in flight at once.  On RCCL the pair must be ONE grouped call: two ranks that
     each enqueue recv-then-send separately wait on each other's send forever."""
+    _log_wire(group, "swap", peer)
     if _direct(group):
-        _log_wire(group, "swap", peer)
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, peer, group), dist.P2POp(dist.irecv, theirs, peer, group)]):
             w.wait()
         return
-    _log_wire(group, "swap", peer)
-    saved, globals()["_wire_log"] = _wire_log, None            # the pair of calls below is this ONE swap
-    try:
-        rw = _irecv(theirs, peer, group)
-        keep, sw = _isend(mine, peer, group)
-    finally:
-        globals()["_wire_log"] = saved
+    rw = _irecv(theirs, peer, group, log=False)                 # (the pair of calls is this ONE swap on the log)
+    keep, sw = _isend(mine, peer, group, log=False)
     rw.wait()
     sw.wait()
 
