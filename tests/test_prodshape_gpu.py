@@ -313,9 +313,17 @@ def test_prodshape_attention_18226_48_heads_sampled():
         close(f"prod_attention_48h_running_max head {h}", out3[rows.cuda(), h * 64:(h + 1) * 64], ref.to(BF), rtol=3e-2, afrac=8e-3)
 
 
+# The bf16-emulated oracle's own error against the fp32 oracle on the two real-size stage tests below is a CONSTANT of their seeded setup
+# (weights seed, clip / latent seed, oracle code).  It was measured in round 6 (profiles/r06_real_size_stages_vs_oracle.log) and is recorded
+# here so that the GPU suite pays for ONE oracle pass per stage (95 s / ~210 s on the box's host cores) instead of two; DOVE_TEST_BF16_YARDSTICK=1
+# runs the emulation live beside the fp32 oracle (a child process) and checks the record against it.
+RECORDED_BF16_YARDSTICK = {"enc": 1.757e-2, "dec": 9.382e-3}
+
+
 def _two_oracles(stage, seed, x_bf16, tmp_path, conv_out_scale=1.0):
-    """(fp32 result, bf16-emulated result, seconds) of one oracle/vae.py stage on ``x_bf16``: the bf16 emulation runs in a CHILD process
-    (tests/oracle_worker.py, half of the host threads) while this process runs the fp32 oracle on the other half."""
+    """(fp32 result, bf16-emulated result or None, seconds fp32, seconds total, threads) of one oracle/vae.py stage on ``x_bf16``.  With
+    DOVE_TEST_BF16_YARDSTICK=1 the bf16 emulation runs in a CHILD process (tests/oracle_worker.py, half of the host threads) beside the fp32
+    oracle; otherwise only the fp32 oracle runs."""
     import os
     import subprocess
     import sys
@@ -323,13 +331,16 @@ def _two_oracles(stage, seed, x_bf16, tmp_path, conv_out_scale=1.0):
 
     from dove_amd import config, weights
     from oracle.vae import OracleVAE
+    live = os.environ.get("DOVE_TEST_BF16_YARDSTICK", "0") == "1"
     ncpu = os.cpu_count() or 2
-    threads = max(1, min(128, ncpu // 2))
+    threads = max(1, min(128, ncpu // 2 if live else ncpu))
     src, dst = tmp_path / f"{stage}_in.pt", tmp_path / f"{stage}_bf16.pt"
-    torch.save(x_bf16, src)
     t0 = time.time()
-    child = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py"), stage, str(seed), "bfloat16",
-                              str(threads), str(src), str(dst), str(conv_out_scale)])
+    child = None
+    if live:
+        torch.save(x_bf16, src)
+        child = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py"), stage, str(seed),
+                                  "bfloat16", str(threads), str(src), str(dst), str(conv_out_scale)])
     try:
         torch.set_num_threads(threads)
         v, _t, _s = config.default_configs()
@@ -339,11 +350,23 @@ def _two_oracles(stage, seed, x_bf16, tmp_path, conv_out_scale=1.0):
         vae = OracleVAE(v, wv)
         ref32 = vae.encode(x_bf16.float()) if stage == "enc" else vae.decode(x_bf16.float())
         t32 = time.time() - t0
-        assert child.wait(timeout=1500) == 0, "the bf16-emulated oracle (child process) failed"
+        if child is not None:
+            assert child.wait(timeout=1500) == 0, "the bf16-emulated oracle (child process) failed"
     finally:
-        if child.poll() is None:
+        if child is not None and child.poll() is None:
             child.kill()
-    return ref32, torch.load(dst), t32, time.time() - t0, threads
+    return ref32, (torch.load(dst) if live else None), t32, time.time() - t0, threads
+
+
+def _yardstick(stage, refbf, ref32):
+    """The bf16-emulated reference's rms-rel error against fp32 for this stage test: measured live when the emulation ran, else the record."""
+    from test_parity_gpu import rms_rel
+    rec = RECORDED_BF16_YARDSTICK[stage]
+    if refbf is None:
+        return rec, "recorded"
+    live = rms_rel(refbf, ref32)
+    assert abs(live - rec) <= 0.03 * rec, f"the recorded bf16 yardstick of the {stage} stage test ({rec:.3e}) no longer matches the emulation ({live:.3e}): update it"
+    return live, "live"
 
 
 def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280(tmp_path):
@@ -352,7 +375,7 @@ def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280(tmp_path):
     (im2col'ed conv_in, w_first temporal sums, fused GroupNorm statistics over 33 M-element groups, three stride-2 downsamples, two
     temporal pools) against oracle/vae.py in fp32 on the host cores, with the oracle's bf16 emulation (a rounding at every module output =
     what the reference's bf16 run does) as the yardstick: err_hip <= 1.25 x err_bf16 + 1e-3 on the posterior moments, the gate of the
-    256 x 256 stage tests.  ~73 TFLOP per oracle pass; the two oracles run side by side (two processes)."""
+    256 x 256 stage tests.  ~73 TFLOP per oracle pass; the yardstick is the recorded constant unless DOVE_TEST_BF16_YARDSTICK=1."""
     from dove_amd import config, weights
     from dove_amd.vae import AutoencoderKLCogVideoX
     from test_parity_gpu import rms_rel, synth_clip
@@ -367,9 +390,10 @@ def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280(tmp_path):
     del vae
     torch.cuda.empty_cache()
     ref32, refbf, t32, tall, threads = _two_oracles("enc", 77, video.to(BF), tmp_path)     # both oracles see the bf16 boundary tensor the HIP path sees
-    e_hip, e_bf = rms_rel(got, ref32), rms_rel(refbf, ref32)
-    print(f"[encoder 9x720x1280] fp32 oracle {t32:.0f} s, with the bf16-emulated oracle beside it {tall:.0f} s (2 x {threads} threads); "
-          f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
+    e_hip = rms_rel(got, ref32)
+    e_bf, how = _yardstick("enc", refbf, ref32)
+    print(f"[encoder 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads} threads); "
+          f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e} ({how})")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
 
 
@@ -379,7 +403,7 @@ def test_prodshape_decoder_first_latent_batch_vs_oracle_9x720x1280(tmp_path):
     with the odd-T frame map at every level, the sub-pixel upsample convs (w_sub), Upsample3D's time doubling and the frame-pair sums (w_pair) behind
     it, the first-frame sums (w_first), the tap-split conv_out - against oracle/vae.py in fp32 with its bf16 emulation as the yardstick
     (err_hip <= 1.25 x err_bf16 + 1e-3 on the un-clamped output; conv_out scaled by 0.25 on both sides so that the output stays inside [-1, 1]
-    like a trained decoder's).  ~155 TFLOP per oracle pass, the two side by side."""
+    like a trained decoder's).  ~155 TFLOP per oracle pass; the yardstick is the recorded constant unless DOVE_TEST_BF16_YARDSTICK=1."""
     from dove_amd import config, weights
     from dove_amd.vae import AutoencoderKLCogVideoX
     from test_parity_gpu import CONV_OUT_SCALE, rms_rel
@@ -396,9 +420,10 @@ def test_prodshape_decoder_first_latent_batch_vs_oracle_9x720x1280(tmp_path):
     torch.cuda.empty_cache()
     ref32, refbf, t32, tall, threads = _two_oracles("dec", 78, z, tmp_path, CONV_OUT_SCALE)
     sat = float((ref32.abs() >= 1).float().mean())
-    e_hip, e_bf = rms_rel(got, ref32), rms_rel(refbf, ref32)
-    print(f"[decoder 3x90x160 -> 9x720x1280] fp32 oracle {t32:.0f} s, with the bf16-emulated oracle beside it {tall:.0f} s (2 x {threads} threads); "
-          f"decoded (un-clamped, {100 * sat:.1f} % outside [-1, 1]) rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e}")
+    e_hip = rms_rel(got, ref32)
+    e_bf, how = _yardstick("dec", refbf, ref32)
+    print(f"[decoder 3x90x160 -> 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads} threads); "
+          f"decoded (un-clamped, {100 * sat:.1f} % outside [-1, 1]) rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e} ({how})")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
 
 
