@@ -1,6 +1,6 @@
 """Child process of the real-size oracle comparisons (tests/test_prodshape_gpu.py): runs ONE oracle/vae.py stage on the host cores and saves the
-result, so that the fp32 oracle (parent) and the bf16-emulated oracle (this process) of a 9 x 720 x 1280 frame-batch run side by side instead of
-one after the other.  Test infrastructure only; no GPU.
+result - the bf16-emulated oracle beside the parent's fp32 pass (DOVE_TEST_BF16_YARDSTICK=1), or the fp32 pass itself started by
+tests/conftest.py at the beginning of a GPU session (tests/oracle_prefetch.py) so that it runs while the GPU tests do.  Test infrastructure only; no GPU.
     python tests/oracle_worker.py <enc|dec> <seed> <dtype: float32|bfloat16> <threads> <input.pt> <output.pt> [conv_out_scale]"""
 import os
 import sys
@@ -24,8 +24,12 @@ def main():
         wv[k] = wv[k] * scale
     x = torch.load(src)
     vae = OracleVAE(v, wv, dtype)
-    out = vae.encode(x) if stage == "enc" else vae.decode(x)
-    torch.save(out.float(), dst)
+    out = vae.encode(x.to(dtype)) if stage == "enc" else vae.decode(x.to(dtype))
+    # the checksum of the input that was read travels with the result (tests/oracle_prefetch.py accepts a result only for ITS input);
+    # written under another name and renamed so that a reader never sees a partial file
+    xs = x.double()
+    torch.save({"out": out.float(), "in_sum": float(xs.sum()) + float(xs.abs().sum())}, dst + ".part")
+    os.replace(dst + ".part", dst)
 
 
 if __name__ == "__main__":
