@@ -110,7 +110,7 @@ extern "C" int dove_ncthw_from_cl(const void* x, long long ld, int C, long long 
 // (A direct gather - 27 scattered 4-byte loads per pixel - ran at 0.33 TB/s.)
 __global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __restrict__ p, int ldp, int T, int H, int W, int C,
                                                               const float* __restrict__ bias, float scale, float shift, float lo, float hi,
-                                                              void* __restrict__ y, int dt) {
+                                                              void* __restrict__ y, int dt, int ldy) {
   extern __shared__ __attribute__((aligned(16))) float tile[];
   constexpr int TH = 8, TW = 64, RW = TW + 2, NREC = (TH + 2) * RW;
   const int lrec = ldp + 1, f4n = ldp >> 2;
@@ -141,25 +141,39 @@ __global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __res
         for (int c = 0; c < C; ++c) acc[c] += q[c];
       }
     const long long pix = ((long long)t * H + oy) * W + ox;
+    if (ldy > 0) {                                                         // channels-last bf16 [T][H][W][ldy] (a spatial tile: blended before the layout change)
+      bf16_t* yp = (bf16_t*)y + pix * ldy;
+      for (int c = 0; c < ldy; ++c) yp[c] = c < C ? f2bf(acc[c] + (bias ? bias[c] : 0.f)) : (bf16_t)0;
+      continue;
+    }
     for (int c = 0; c < C; ++c) {
       const float v = bf2f(f2bf(acc[c] + (bias ? bias[c] : 0.f)));          // the conv's bf16 output rounding
       store_any(y, (long long)c * npix + pix, dt, fminf(fmaxf(v * scale + shift, lo), hi));
     }
   }
 }
-extern "C" int dove_conv_out_gather(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, float scale, float shift,
-                                    float lo, float hi, void* y, int dtype, void* stream) {
+static int conv_out_gather_launch(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, float scale, float shift,
+                                  float lo, float hi, void* y, int dtype, int ldy, void* stream) {
   DOVE_CHECK_ARG(p && y, "conv_out_gather: null pointer");
-  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "conv_out_gather: bad dtype %d", dtype);
   DOVE_CHECK_ARG(C >= 1 && C <= 4 && ldp >= 9 * C && ldp <= 36 && ldp % 4 == 0 && T > 0 && H > 0 && W > 0,
                  "conv_out_gather: need 1 <= C <= 4 and 9 C <= ldp <= 36, ldp %% 4 == 0");
   const int lds = 10 * 66 * ((int)ldp + 1) * 4;
   static PerDeviceOnce attr;
   if (auto once_ = attr.guard()) { (void)hipFuncSetAttribute((const void*)conv_out_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 10 * 66 * 37 * 4); }
   dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 7) / 8), (unsigned)T);
-  hipLaunchKernelGGL(conv_out_gather_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, (int)ldp, T, H, W, C, bias, scale, shift, lo, hi, y, dtype);
+  hipLaunchKernelGGL(conv_out_gather_kernel, grid, dim3(256), lds, (hipStream_t)stream, p, (int)ldp, T, H, W, C, bias, scale, shift, lo, hi, y, dtype, ldy);
   DOVE_CHECK_LAUNCH("dove_conv_out_gather");
   return DOVE_OK;
+}
+extern "C" int dove_conv_out_gather(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, float scale, float shift,
+                                    float lo, float hi, void* y, int dtype, void* stream) {
+  DOVE_CHECK_ARG(dtype == DOVE_F32 || dtype == DOVE_BF16, "conv_out_gather: bad dtype %d", dtype);
+  return conv_out_gather_launch(p, ldp, T, H, W, C, bias, scale, shift, lo, hi, y, dtype, 0, stream);
+}
+extern "C" int dove_conv_out_gather_cl(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, void* y, int ldy, void* stream) {
+  DOVE_CHECK_ARG(ldy >= C && ldy <= 32 && ldy % 4 == 0, "conv_out_gather_cl: need C <= ldy <= 32, ldy %% 4 == 0 (got %d)", ldy);
+  DOVE_CHECK_ARG(T <= 65535, "conv_out_gather_cl: more than 65535 frames (%d) in one call", T);
+  return conv_out_gather_launch(p, ldp, T, H, W, C, bias, 1.0f, 0.0f, 0.0f, 0.0f, y, DOVE_BF16, ldy, stream);
 }
 
 // ---- Downsample3D temporal pool: odd T keeps frame 0 and averages pairs (1,2),(3,4)..; even T pairs (0,1).. ----
@@ -310,6 +324,58 @@ extern "C" int dove_gemv_bf16(const void* W, const float* bias, const float* x, 
   hipLaunchKernelGGL(gemv_kernel, dim3((out_features + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)W,
                      bias, x, in_features, out_features, act_in, y);
   DOVE_CHECK_LAUNCH("dove_gemv_bf16");
+  return DOVE_OK;
+}
+
+// ---- diffusers VAE tiling: same-shaped spatial tiles of a channels-last clip -> ONE batch (tile-major), 16-byte chunks ----
+//   out [nb][nt][th][tw][C] <- x [T][H][W][C] frames [t0, t0 + nt), tile n at (oy[n], ox[n]).
+// im2col_cin > 0: x is the im2col'ed clip of dove_cl_im2col3x3_from_ncthw (channel (dy*3+dx)*cin + c = pixel (y+dy-1, x+dx-1)); a tile must
+// see ZERO padding at ITS border (diffusers runs the whole network per tile), so the channels of taps that reach outside the tile are zeroed
+// at the tile's border pixels - the tile then equals the im2col of the cropped tile, bit for bit.
+struct TileOrigins { int n; short oy[64], ox[64]; };
+__global__ void tile_gather_kernel(const bf16_t* __restrict__ x, int H, int W, int C8, int t0, int nt, int th, int tw, TileOrigins org,
+                                   int cin, bf16_t* __restrict__ out) {
+  const long long per = (long long)nt * th * tw * C8, total = per * org.n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per);
+    long long r = i - (long long)n * per;
+    const int c = (int)(r % C8); r /= C8;
+    const int xx = (int)(r % tw); r /= tw;
+    const int yy = (int)(r % th);
+    const int t = (int)(r / th);
+    uint4 v = ((const uint4*)x)[(((long long)(t0 + t) * H + org.oy[n] + yy) * W + org.ox[n] + xx) * C8 + c];
+    if (cin > 0 && (yy == 0 || yy == th - 1 || xx == 0 || xx == tw - 1)) {
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ch = c * 8 + e;
+        if (ch >= 9 * cin) continue;
+        const int tap = ch / cin, dy = tap / 3, dx = tap - dy * 3;
+        const bool outside = (yy == 0 && dy == 0) || (yy == th - 1 && dy == 2) || (xx == 0 && dx == 0) || (xx == tw - 1 && dx == 2);
+        if (outside) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+      }
+      v = uint4{w[0], w[1], w[2], w[3]};
+    }
+    ((uint4*)out)[i] = v;
+  }
+}
+extern "C" int dove_tile_gather_bf16(const void* x, int H, int W, int C, int t0, int nt, int th, int tw, int nb, const int* oy, const int* ox,
+                                     int im2col_cin, void* out, void* stream) {
+  DOVE_CHECK_ARG(x && out && oy && ox, "tile_gather: null pointer");
+  DOVE_CHECK_ARG(C > 0 && C % 8 == 0 && H > 0 && W > 0 && H < 32768 && W < 32768, "tile_gather: need C %% 8 == 0 and H, W < 32768");
+  DOVE_CHECK_ARG(nb >= 1 && nb <= 64, "tile_gather: 1 <= nb <= 64 tiles per call (got %d)", nb);
+  DOVE_CHECK_ARG(nt > 0 && t0 >= 0 && th > 0 && tw > 0 && th <= H && tw <= W, "tile_gather: bad tile shape %d x %d x %d", nt, th, tw);
+  DOVE_CHECK_ARG(im2col_cin >= 0 && 9 * im2col_cin <= C, "tile_gather: im2col_cin %d does not fit %d channels", im2col_cin, C);
+  TileOrigins org; org.n = nb;
+  for (int n = 0; n < nb; ++n) {
+    DOVE_CHECK_ARG(oy[n] >= 0 && ox[n] >= 0 && oy[n] + th <= H && ox[n] + tw <= W, "tile_gather: tile %d at (%d, %d) leaves the %d x %d frame", n, oy[n], ox[n], H, W);
+    org.oy[n] = (short)oy[n]; org.ox[n] = (short)ox[n];
+  }
+  const long long n16 = (long long)nb * nt * th * tw * (C / 8);
+  const unsigned grid = (unsigned)(n16 + 255 < 256ll * 8192 ? (n16 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(tile_gather_kernel, dim3(grid ? grid : 1), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, H, W, C / 8, t0, nt, th, tw, org,
+                     im2col_cin, (bf16_t*)out);
+  DOVE_CHECK_LAUNCH("dove_tile_gather_bf16");
   return DOVE_OK;
 }
 

@@ -127,21 +127,6 @@ __global__ void copy2d_kernel(char* dst, long long dpitch, const char* src, long
     ((uint16_t*)(dst + r * dpitch))[c] = ((const uint16_t*)(src + r * spitch))[c];
   }
 }
-// spatial tiles of one shape -> one batch: out [nb][nt][th][tw][C] <- x [T][H][W][C] frames [t0, t0 + nt), tile n at (oy[n], ox[n]); 16-byte chunks
-struct TileOrigins { int n; short oy[64], ox[64]; };
-__global__ void tile_gather_kernel(const bf16_t* __restrict__ x, int H, int W, int C8, int t0, int nt, int th, int tw, TileOrigins org,
-                                   bf16_t* __restrict__ out) {
-  const long long per = (long long)nt * th * tw * C8, total = per * org.n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i / per);
-    long long r = i - (long long)n * per;
-    const int c = (int)(r % C8); r /= C8;
-    const int xx = (int)(r % tw); r /= tw;
-    const int yy = (int)(r % th);
-    const int t = (int)(r / th);
-    ((uint4*)out)[i] = ((const uint4*)x)[(((long long)(t0 + t) * H + org.oy[n] + yy) * W + org.ox[n] + xx) * C8 + c];
-  }
-}
 // GroupNorm pair exchange of a split frame-batch: msg = (sum, sumsq)[32] + element count; the pair's totals = a + b
 __global__ void gn_msg_kernel(const double* __restrict__ sums, double count, double* __restrict__ msg) {
   const int i = threadIdx.x;
@@ -365,7 +350,6 @@ struct dove_ctx {
   // options (dove_set_option)
   bool opt_tiling = false, opt_linear_mx = false, opt_attn_mx = false, opt_weight_sums = true;
   int sample_h = 480, sample_w = 720;                   // vae/config.json sample_height / sample_width: tile geometry of enable_tiling()
-  bool direct_io_convs = false;                         // inside a spatial tile: conv_in / conv_out in their direct forms (dove_amd/vae.py)
   uint8_t *Q8 = nullptr, *K8 = nullptr, *V8 = nullptr, *Vs8 = nullptr; long long attn8_n = 0;   // MXFP8 attention operands
   int depth = 0;                                        // nesting of stage entry points (dove_sr_clip calls the others)
 };
@@ -993,7 +977,7 @@ struct StageGuard {
   dove_ctx* c;
   explicit StageGuard(dove_ctx* ctx) : c(ctx) {
     if (c && c->depth++ == 0) {
-      clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->direct_io_convs = false; c->nb = 1; set_piece(c, nullptr);
+      clear_caches(c); c->arena.reset(); c->halo_recv = c->halo_send = false; c->nb = 1; set_piece(c, nullptr);
       c->ev_next = 0; c->halo_posted.clear(); c->halo_record.clear(); c->halo_sent = false;
       c->vae_multi = false; c->cache_ev.clear();
     }
@@ -1005,7 +989,7 @@ int encoder(dove_ctx* c, const Tensor& x, Tensor* out, void* stream) {
   const auto& cf = c->cfg;
   Tensor h; float* hs = nullptr;
   Tensor xin = x;
-  CHK(cconv(c, xin, false, (!c->direct_io_convs && c->pc.count("encoder.conv_in.taps")) ? "encoder.conv_in.taps" : "encoder.conv_in", ConvOpt(), &h, stream));
+  CHK(cconv(c, xin, false, c->pc.count("encoder.conv_in.taps") ? "encoder.conv_in.taps" : "encoder.conv_in", ConvOpt(), &h, stream));
   char nm[128];
   int n_tdown = 0;
   for (int r = cf.vae_temporal_compression; r > 1; r >>= 1) ++n_tdown;
@@ -1068,7 +1052,7 @@ int decoder(dove_ctx* c, const Tensor& z, Tensor* out, void* stream) {
   Tensor n;
   CHK(norm_silu(c, h, hs, "decoder.norm_out", &z, &n, stream));
   free_t(c, h);
-  if (c->conv_out_bias && !c->direct_io_convs) {               // tap-split conv_out: fp32 partial planes for dove_conv_out_gather
+  if (c->conv_out_bias) {                                      // tap-split conv_out: fp32 partial planes for dove_conv_out_gather (_cl inside a tile)
     ConvOpt ot; ot.out_f32 = true;
     CHK(cconv(c, n, true, "decoder.conv_out.taps", ot, out, stream));
   } else {
@@ -1572,7 +1556,9 @@ static bool wants_tiling(const dove_ctx* c, bool enc, int H, int W) {
 // tiles of one shape (interior / bottom edge / right edge / corner: 12 + 4 + 3 + 1 at 720x1280) run as ONE batch - dove_conv_desc.nb and the
 // *_nb operators, one launch per operator and shape class instead of one per tile, the largest class first (dove_amd/vae.py _tiled; per tile
 // the arithmetic is that of a tile-by-tile loop, bit for bit).
-static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stream) {
+// im2col_cin > 0 (encode): x is the im2col'ed clip and dove_tile_gather_bf16 zeroes the taps that reach outside a tile, so encoder.conv_in keeps
+// its (3,1,1) form inside tiles; the decoder's tap-split conv_out is finished per tile batch by dove_conv_out_gather_cl (channels-last for the blend).
+static int tiled(dove_ctx* c, const Tensor& x, bool enc, int im2col_cin, Tensor* out, void* stream) {
   TileGeom g; tiling_geometry(c, enc, &g);
   DOVE_CHECK_ARG(g.stride_h > 0 && g.stride_w > 0 && g.lim_h > 0 && g.lim_w > 0, "vae tiling: degenerate tile geometry (sample size %d x %d)", c->sample_h, c->sample_w);
   DOVE_CHECK_ARG(x.C % 8 == 0 && x.H < 32768 && x.W < 32768, "vae tiling: unsupported input layout");
@@ -1599,7 +1585,6 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
   std::vector<void*> class_blocks;
   int t_total = 0;
   for (auto& se : fb) t_total += enc ? enc_batch_frames(c, se.second - se.first) : dec_batch_frames(c, se.second - se.first);
-  c->direct_io_convs = true;
   int rc = 0;
   for (size_t k = 0; k < classes.size() && !rc; ++k) {
     const Cls& cl = classes[k];
@@ -1608,8 +1593,8 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
     constexpr size_t kTileBatchMax = 16;
     for (size_t m0 = 0; m0 < cl.members.size() && !rc; m0 += kTileBatchMax) {
       const int nb = (int)std::min<size_t>(kTileBatchMax, cl.members.size() - m0);
-      TileOrigins org; org.n = nb;
-      for (int n = 0; n < nb; ++n) { org.oy[n] = (short)ii[cl.members[m0 + n].first]; org.ox[n] = (short)jj[cl.members[m0 + n].second]; }
+      int org_y[kTileBatchMax], org_x[kTileBatchMax];
+      for (int n = 0; n < nb; ++n) { org_y[n] = ii[cl.members[m0 + n].first]; org_x[n] = jj[cl.members[m0 + n].second]; }
       clear_caches(c);
       c->nb = nb;
       Tensor cls_out;                                           // [nb][t_total][oh][ow][ld], allocated once the first batch says oh, ow, ld
@@ -1618,17 +1603,20 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
         const int nt = se.second - se.first;
         Tensor xb;
         if ((rc = alloc_t(c, nb * nt, cl.th, cl.tw, x.C, &xb))) break;
-        {
-          const long long n16 = xb.elems() / 8;
-          const unsigned grid = (unsigned)std::min<long long>((n16 + 255) / 256, 8192);
-          hipLaunchKernelGGL(tile_gather_kernel, dim3(grid ? grid : 1), dim3(256), 0, s, x.p, x.H, x.W, x.C / 8, se.first, nt, cl.th, cl.tw, org, xb.p);
-          if (hipGetLastError() != hipSuccess) { rc = DOVE_ELAUNCH; free_t(c, xb); break; }
-        }
+        if ((rc = dove_tile_gather_bf16(x.p, x.H, x.W, x.C, se.first, nt, cl.th, cl.tw, nb, org_y, org_x, im2col_cin, xb.p, stream))) { free_t(c, xb); break; }
         Tensor o;
         rc = enc ? encoder(c, xb, &o, stream) : decoder(c, xb, &o, stream);
         // the first conv does not own its input (a view in the un-tiled paths): release the batch tensor here.  Its conv cache was copied.
         free_t(c, xb);
         if (rc) break;
+        if (!enc && c->conv_out_bias) {                           // fp32 partial planes of the tap-split conv_out -> the tile batch, channels-last
+          Tensor g;
+          if ((rc = alloc_t(c, o.T, o.H, o.W, 8, &g))) { free_t(c, o); break; }
+          rc = dove_conv_out_gather_cl((const float*)o.p, o.C / 2, o.T, o.H, o.W, c->cfg.vae_out_channels, c->conv_out_bias, g.p, 8, stream);
+          free_t(c, o);
+          if (rc) { free_t(c, g); break; }
+          o = g;
+        }
         const int To = o.T / nb;
         if (!cls_out.p) {
           cls_out.T = nb * t_total; cls_out.H = o.H; cls_out.W = o.W; cls_out.C = o.C;
@@ -1654,7 +1642,6 @@ static int tiled(dove_ctx* c, const Tensor& x, bool enc, Tensor* out, void* stre
     }
   }
   c->nb = 1;
-  c->direct_io_convs = false;
   int Ho = 0, Wo = 0;
   if (!rc) {
     for (size_t i = 0; i < rows.size() && !rc; ++i)
@@ -1741,8 +1728,10 @@ static int vae_encode_cl(dove_ctx* c, const void* x, int dtype, int F, int H, in
   CHK(alloc_t(c, F, H, W, c->pc.at("encoder.conv_in").cin_pad, &xcl));
   if (wants_tiling(c, true, H, W)) {
     DOVE_CHECK_ARG(c->nranks == 1, "vae tiling is not combined with the multi-rank halo exchange");
-    CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
-    int rc = tiled(c, xcl, true, moments, stream);
+    const bool taps = c->pc.count("encoder.conv_in.taps") != 0;
+    if (taps) CHK(dove_cl_im2col3x3_from_ncthw(x, dtype, cf.vae_in_channels, F, H, W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+    else CHK(dove_cl_from_ncthw(x, dtype, cf.vae_in_channels, (long long)F * H * W, xcl.C, 1.0f, 0.0f, xcl.p, stream));
+    int rc = tiled(c, xcl, true, taps ? cf.vae_in_channels : 0, moments, stream);
     free_t(c, xcl);
     clear_caches(c);
     if (!rc && (moments->T != 1 + (F - 1) / cf.vae_temporal_compression || moments->H != H / 8 || moments->W != W / 8)) {
@@ -1855,7 +1844,7 @@ extern "C" int dove_vae_decode(dove_ctx* c, const void* z, int dtype, int T, int
   if (wants_tiling(c, false, h, w)) {
     DOVE_CHECK_ARG(c->nranks == 1, "vae tiling is not combined with the multi-rank halo exchange");
     Tensor full;
-    int rc = tiled(c, zcl, false, &full, stream);
+    int rc = tiled(c, zcl, false, 0, &full, stream);
     free_t(c, zcl);
     clear_caches(c);
     CHK(rc);

@@ -389,8 +389,8 @@ __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k
   q.ph = __builtin_amdgcn_readfirstlane(a.sub ? nidx / ctn : 0);
   q.n0 = __builtin_amdgcn_readfirstlane((nidx - q.ph * ctn) * halo8::BN);
   q.t = __builtin_amdgcn_readfirstlane((int)(rest % a.T_out)); rest /= a.T_out;
-  q.ow0 = __builtin_amdgcn_readfirstlane((int)(rest % a.tiles_w) * halo8::TW);
-  q.oh0 = __builtin_amdgcn_readfirstlane((int)(rest / a.tiles_w) * halo8::TH);
+  q.ow0 = __builtin_amdgcn_readfirstlane((a.tx0 + (int)(rest % a.ntx)) * halo8::TW);
+  q.oh0 = __builtin_amdgcn_readfirstlane((a.ty0 + (int)(rest / a.ntx)) * halo8::TH);
   return q;
 }
 // How the three causal taps (frames t - 2, t - 1, t of the instance; before its first frame: the conv cache, else frame 0 replicated) of the
@@ -418,7 +418,7 @@ __device__ __forceinline__ int h4_split(const IgemmArgs& a, int t) {
   return (tl & 1) ? 2 : 3;
 }
 __device__ __forceinline__ int h4_split_ndt(const IgemmArgs& a, int split) { return split == 0 ? a.kt : (split == 1 ? 1 : 2); }
-template <bool kUp>
+template <bool kUp, int kPart = 0>
 __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, const H4Const& k, int id) {
   using namespace halo8;
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
@@ -440,7 +440,8 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
       } else {
         const int hh = px / HWID, hw = px - hh * HWID;
         ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
-        inb = px < HPIX;
+        // partial tiles read 16 columns / 8 rows (+ halo) of the LDS image: the rest is not fetched (out-of-range lanes cost no traffic)
+        inb = px < HPIX && (kPart != 1 || hw < halo8::TW / 2 + 2) && (kPart != 2 || hh < halo8::TH / 2 + 2);
       }
       const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
       s.voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
@@ -480,12 +481,12 @@ __device__ __forceinline__ void h4_set_nxt(H4State& s, const IgemmArgs& a, const
   s.wg_nxt = wsel + (long long)(dtw * 9) * k.wtap_stride + s.n_kc * BK;
   s.nrec_b_nxt = s.n_on ? k.wtap_bytes - s.n_kc * ROWB : 0;
 }
-template <bool kUp>
+template <bool kUp, int kPart = 0>
 __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const H4Const& k) {   // cur <- nxt, nxt <- successor
   s.nrec_b_cur = s.nrec_b_nxt;
   if (++s.n_kc == k.kcn) {
     s.n_kc = 0;
-    if (++s.n_dt == s.ndt) h4_open_tile<kUp>(s, a, k, s.n_tile + k.G);
+    if (++s.n_dt == s.ndt) h4_open_tile<kUp, kPart>(s, a, k, s.n_tile + k.G);
   }
   h4_set_nxt(s, a, k);
 }
@@ -501,11 +502,21 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // the matrix pipe alone sustains 2.0-2.1 PF on them against 1.88 PF (half the accumulator traffic per MAC; profiles/r04_mfma_shape_and_order.log).
 // Results are BIT-IDENTICAL to the 32 x 32 x 16 walk (same K order inside the pipe: every form of the kernel and the full-size VAE,
 // profiles/r04_halo_m16.log), 4.3-6.7 % faster at the headline shapes, -14.8 ms per clip.
-template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false>
+// kPart (round 6): PARTIAL tiles.  A 16 x 32 tile whose image ends within its first 16 columns (kPart 1: the last tile column when W % 32 is 1..16)
+// or within its first 8 rows (kPart 2: the last tile row when H % 16 is 1..8) spends half of its MFMAs on pixels that do not exist - 6.25 % of a
+// 360-px-wide VAE tile, 2.2 % of the 360-row level of the 720p clip.  A partial launch walks only that tile column / row (IgemmArgs.tx0 / ty0 /
+// ntx / nty) with HALF the register tile: 4 pixel blocks per wave instead of 8 - kPart 1: tile rows 4 w .. 4 w + 3, columns 0..15 (blocks 2 p);
+// kPart 2: tile rows 2 w, 2 w + 1, all 32 columns (blocks 0..3) - 32 MFMAs per step, the same LDS image, weight ring, staging schedule and
+// epilogue; every output pixel accumulates in the same K order as in a full tile, so results are bit-identical to the one-launch form.
+template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false, int kPart = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
   static_assert(!(kUp && kSub), "the sub-pixel form runs on the plain halo geometry of the low-res grid");
+  static_assert(kPart == 0 || (kM16 && !kUp && !kSub && !kTiming && kPipe), "partial tiles: the 16 x 16 x 32 walk of the plain conv only");
+  constexpr int RPW = kPart == 2 ? 2 : 4;                       // tile rows per wave
+  constexpr int NS = kPart ? 4 : 8;                             // pixel blocks (16 px) per wave; slot s is block (kPart == 1 ? 2 s : s)
+  static_assert(!kPart || CFG::HPS <= 2, "partial tiles: a step has issue slots for two halo rounds");
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
   constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
   constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, NT = CFG::NT;
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   // Everything a step needs from the staging side is per-group scalar state prepared at the group boundary; LDS slots
   // and buffers are compile-time functions of (tap, group parity), so a step carries ~10 scalar instructions.
   H4Const kc;
-  kc.ntiles = a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
+  kc.ntiles = a.T_out * a.nty * a.ntx * a.tiles_n;
   kc.G = (int)gridDim.x;
   kc.kcn = a.Cin / BK;
   kc.frame_elems = (long long)a.H_in * a.W_in * a.Cin;
@@ -588,7 +599,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       boff[i][kk] = B0 + row * ROWB + (((kk * 2 + hi) ^ ((row >> 2) & 3)) << 4);
     }
   // activation fragment bases (padded 80-B halo rows -> base + immediate for every tap and either buffer)
-  const int abase0 = kM16 ? ((4 * wave) * HWID + l15) * APITCH + q4 * 16 : ((4 * wave) * HWID + l31) * APITCH + hi * 16;
+  const int abase0 = kM16 ? ((RPW * wave) * HWID + l15) * APITCH + q4 * 16 : ((4 * wave) * HWID + l31) * APITCH + hi * 16;
   int abaseU[3];
 #pragma unroll
   for (int dw = 0; dw < 3; ++dw)
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   // ---- prologue (once per workgroup): whole first halo + the first BAHEAD weight taps ----
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  h4_open_tile<kUp>(st, a, kc, (int)blockIdx.x);
+  h4_open_tile<kUp, kPart>(st, a, kc, (int)blockIdx.x);
   h4_set_nxt(st, a, kc);
   publish(st);
   {
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   stage_b(std::integral_constant<int, 0>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 1>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 2>{}, nrec_b_nxt);
-  h4_advance<kUp>(st, a, kc);
+  h4_advance<kUp, kPart>(st, a, kc);
   publish(st);                                                  // cur = group 0 of the first tile, nxt = its successor
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -730,6 +741,42 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       // first half: cout blocks 0-3 (wl) x the 8 pixel blocks.  Behind every pair of MFMAs ONE other instruction, in a fixed order
       // (sched_barrier-fenced: the MFMA mask of sched_group_barrier does not see an asm MFMA): the 4 cout-high fragments this step's
       // second half needs, then the step's LDS-DMAs (2 weight halves + NH halo rounds)
+      if (kPart) {
+        // partial tile: 16 MFMAs per half (4 cout blocks x the wave's 4 pixel blocks), ONE other instruction behind each of them, same order
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int ib = g >> 2, blk = kPart == 1 ? 2 * (g & 3) : (g & 3);
+          mfma16(ib * 8 + blk, wl[ib], xs[SP][blk]);
+          if (g < 4) wh[g] = *(const bf16x8*)(smem + b16_addr(SlotCur{}, 4 + g));
+          if (g == 4) {
+            if (stap == NT) b_wp = wg_nxt;
+            stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I0{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+          }
+          if (g == 5) {
+            stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I1{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
+            b_wp += wtap_stride;
+          }
+          if (g == 6 && NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
+          if (g == 7 && NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int ib = g >> 2, blk = kPart == 1 ? 2 * (g & 3) : (g & 3);
+          mfma16(32 + ib * 8 + blk, wh[ib], xs[SP][blk]);
+          if (g < 4) {
+            const int nb_ = kPart == 1 ? 2 * g : g;                 // the next step's four activation fragments ...
+            int ad;
+            if (tap < NT - 1) ad = a16_addr(std::integral_constant<int, (tap + 1) % NT>{}, Par{}, nb_);
+            else ad = a16_addr(I0{}, NPar{}, nb_);
+            xs[SP ^ 1][nb_] = *(const bf16x8*)(smem + ad);
+          } else if (g < 8) {
+            wl[g - 4] = *(const bf16x8*)(smem + b16_addr(SlotNxt{}, g - 4));   // ... and its four cout-low weight fragments
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+      }
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         mfma16(2 * g, wl[(2 * g) >> 3], xs[SP][(2 * g) & 7]);
@@ -846,7 +893,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       // The tile's first fragments are read HERE, not carried over from the previous tile's last step like the 32 x 32 x 16 walk does: 12
       // fragments alive across the epilogue are 48 registers the epilogue does not have (one exposed LDS latency per tile of >= 72 steps)
 #pragma unroll
-      for (int idx = 0; idx < 8; ++idx) xs[0][idx] = *(const bf16x8*)(smem + a16_addr(I0{}, I0{}, idx));
+      for (int sl = 0; sl < NS; ++sl) {
+        const int idx = kPart == 1 ? 2 * sl : sl;
+        xs[0][idx] = *(const bf16x8*)(smem + a16_addr(I0{}, I0{}, idx));
+      }
 #pragma unroll
       for (int ib = 0; ib < 4; ++ib) wl[ib] = *(const bf16x8*)(smem + b16_addr(I0{}, ib));
     }
@@ -854,13 +904,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       if (kSub) abaseN0 = abaseT[0];                            // group(I0)'s last step prefetches this tile's next group
       group(I0{});
       __builtin_amdgcn_sched_barrier(0);
-      h4_advance<kUp>(st, a, kc);
+      h4_advance<kUp, kPart>(st, a, kc);
       publish(st);
       __builtin_amdgcn_sched_barrier(0);
       if (kSub) abaseN0 = (g + 2 >= ng_tile) ? next_base0 : abaseT[0];   // ... the tile's last group the NEXT tile's first
       group(I1{});
       __builtin_amdgcn_sched_barrier(0);
-      h4_advance<kUp>(st, a, kc);
+      h4_advance<kUp, kPart>(st, a, kc);
       publish(st);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -919,8 +969,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         };
         if (kPipe) wr(0, 0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const int oh = c.oh0 + 4 * wave + p;
+        for (int p = 0; p < RPW; ++p) {
+          const int oh = c.oh0 + RPW * wave + p;
           const long long pix0 = kSub ? ((long long)c.t * a.H_out + 2 * oh + (c.ph >> 1)) * a.W_out + 2 * c.ow0 + (c.ph & 1)
                                       : ((long long)c.t * a.H_out + oh) * a.W_out + c.ow0;
           const bool okh = kSub ? oh < a.H_in : oh < a.H_out;
@@ -946,7 +996,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the next block's accumulators go into the slice NOW: its reads above are complete, and the write latency then runs under
             // this block's bias / residual / statistics arithmetic and stores instead of in front of the next block's reads
-            if (kPipe && (p < 3 || h < 1)) wr(h ? p + 1 : p, h ^ 1);
+            if (kPipe && (p < RPW - 1 || h < 1)) wr(h ? p + 1 : p, h ^ 1);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
@@ -1620,7 +1670,7 @@ extern "C" int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream) {
   DOVE_CHECK_ARG(d->nb >= 0 && d->nb <= 4096 && (long long)desc_nb(d) * d->t_out < (1 << 20), "conv_igemm: bad instance count nb = %d", d->nb);
   DOVE_CHECK_ARG(d->cache_stride == 0 || (d->cache && d->cache_stride >= (long long)(d->kt - 1) * d->h_in * d->w_in * d->cin),
                  "conv_igemm: cache_stride (%lld) is smaller than one instance's cache", d->cache_stride);
-  DOVE_CHECK_ARG(desc_nb(d) == 1 || (!d->gate && !d->out_f32), "conv_igemm: nb > 1 is not combined with gate / out_f32");
+  DOVE_CHECK_ARG(desc_nb(d) == 1 || !d->gate, "conv_igemm: nb > 1 is not combined with gate");
   DOVE_CHECK_ARG(d->reserved2 == 0 && d->tdup >= 0 && d->tdup <= 2, "conv_igemm: bad tdup %d", d->tdup);
   DOVE_CHECK_ARG(!d->tdup || (d->kt == 3 && d->w_pair), "conv_igemm: tdup declares frame pairs of a kt == 3 conv and needs w_pair");
   DOVE_CHECK_ARG(!d->tdup || d->cache || d->w_first, "conv_igemm: tdup without a conv cache needs w_first too (frames whose three taps read one frame)");
@@ -1765,9 +1815,11 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       a.cpg_log = d->cout_store == 128 ? 2 : (d->cout_store == 256 ? 3 : 4);
       a.sub = 1;
       a.w = (const bf16_t*)d->w_sub;                            // [4 phases][2x2 taps][cout_pad][cin]
+      a.ty0 = a.tx0 = 0;
       a.tiles_w = (d->w_in + halo8::TW - 1) / halo8::TW;        // tiles of the LOW-RES grid, one per phase and cout tile
       a.tiles_h = (d->h_in + halo8::TH - 1) / halo8::TH;
       a.tiles_n = 4 * (d->cout_pad / 128);
+      a.nty = a.tiles_h; a.ntx = a.tiles_w;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attrs;
@@ -1794,11 +1846,14 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
       a.tiles_n = d->cout_pad / 128;
+      a.ty0 = a.tx0 = 0; a.nty = a.tiles_h; a.ntx = a.tiles_w;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attr4;
       if (auto once_ = attr4.guard()) {
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
@@ -1835,7 +1890,29 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       } else
 #endif
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
-      else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
+      else {
+        // PARTIAL tiles (conv3x3_halo4x_kernel's kPart): when the image ends within the first half of its last tile column (W % 32 in 1..16) /
+        // tile row (H % 16 in 1..8), that column / row leaves the main launch and runs with half the register tile: up to three launches
+        // over disjoint tile rectangles, every (tile, wave) row of gn_partial still written exactly once, results bit-identical.
+        //   main: rows [0, R) x columns [0, C);  right (kPart 1): rows [0, R) x column C;  bottom (kPart 2): row R x ALL columns (a corner
+        //   tile that is partial both ways has <= 8 x 16 pixels: inside kPart 2's 8 x 32)
+        const int wrem = d->w_out % halo8::TW, hrem = d->h_out % halo8::TH;
+        const bool wpart = wrem >= 1 && wrem <= halo8::TW / 2, hpart = hrem >= 1 && hrem <= halo8::TH / 2;
+        const int R = a.tiles_h - (hpart ? 1 : 0), C = a.tiles_w - (wpart ? 1 : 0);
+        auto launch = [&](int part, int ty0, int nty, int tx0, int ntx) {
+          if (nty <= 0 || ntx <= 0) return;
+          IgemmArgs b = a;
+          b.ty0 = ty0; b.nty = nty; b.tx0 = tx0; b.ntx = ntx;
+          const long long g = (long long)b.T_out * nty * ntx * b.tiles_n;
+          const unsigned gr = g > cus ? (unsigned)cus : (unsigned)g;
+          if (part == 0) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 0>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
+          else if (part == 1) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 1>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
+          else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 2>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
+        };
+        launch(0, 0, R, 0, C);
+        if (wpart) launch(1, 0, R, C, 1);
+        if (hpart) launch(2, R, 1, 0, a.tiles_w);
+      }
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
       return DOVE_OK;
     }

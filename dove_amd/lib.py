@@ -116,6 +116,8 @@ SIGNATURES = {
     "dove_comm_init_custom": [_VP, _I, _I, XFER_FN, XFER_FN, _VP],
     "dove_comm_set_group": [_VP, GROUP_FN, GROUP_FN],
     "dove_shard_frames": [_VP, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "dove_conv_out_gather_cl": [_VP, _LL, _I, _I, _I, _I, _VP, _VP, _I, _VP],
+    "dove_tile_gather_bf16": [_VP, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _VP, _VP],
     "dove_linear_mxfp8": [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _I, _I, _LL, _LL, _LL, _I, _VP],
 }
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []), "dove_comm_destroy": (None, [C.c_void_p]),

@@ -492,6 +492,35 @@ def conv_out_gather(p: torch.Tensor, Cc: int, bias, dtype, scale=1.0, shift=0.0,
     return y
 
 
+def conv_out_gather_cl(p: torch.Tensor, Cc: int, bias, ld: int = 8) -> torch.Tensor:
+    """The same gather for a spatial TILE (dove_conv_out_gather_cl): p [T,H,W,ldp] fp32 partial planes -> [T,H,W,ld] bf16 channels-last
+    (channels >= Cc zero, no range map): tiles are cross-faded channels-last before the clip changes layout.  T may be nb x frames."""
+    L.require_cuda(p, bias)
+    assert p.dtype == torch.float32 and p.dim() == 4
+    T, H, W, ldp = p.shape
+    y = torch.empty(T, H, W, ld, dtype=torch.bfloat16, device=p.device)
+    L.check(L.load().dove_conv_out_gather_cl(L.ptr(p), ldp, T, H, W, Cc, L.ptr(bias), L.ptr(y), ld, L.stream_ptr()), "dove_conv_out_gather_cl")
+    return y
+
+
+def tile_gather(x: torch.Tensor, t0: int, nt: int, th: int, tw: int, origins, im2col_cin: int = 0) -> torch.Tensor:
+    """Same-shaped spatial tiles of a channels-last clip x [T,H,W,C] -> one tile-major batch [nb*nt, th, tw, C] (dove_tile_gather_bf16):
+    frames [t0, t0+nt), tile n at origins[n] = (oy, ox).  ``im2col_cin`` > 0: x is the im2col'ed clip (cl_im2col3x3_from_ncthw) and the
+    channels of taps that reach outside a tile are zeroed at its border (diffusers' tiles see zero padding at their own border)."""
+    import ctypes as C
+    L.require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 4
+    T, H, W, Cc = x.shape
+    nb = len(origins)
+    oy = (C.c_int * nb)(*[int(o[0]) for o in origins])
+    ox = (C.c_int * nb)(*[int(o[1]) for o in origins])
+    assert 0 <= t0 and t0 + nt <= T
+    y = torch.empty(nb * nt, th, tw, Cc, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().dove_tile_gather_bf16(L.ptr(x), H, W, Cc, t0, nt, th, tw, nb, oy, ox, im2col_cin, L.ptr(y), L.stream_ptr()),
+            "dove_tile_gather_bf16")
+    return y
+
+
 def cl_from_ncthw(x: torch.Tensor, cp: int, scale=1.0, shift=0.0) -> torch.Tensor:
     """[C,T,H,W] fp32/bf16 -> [T,H,W,cp] bf16 (zero-padded channels)."""
     L.require_cuda(x)

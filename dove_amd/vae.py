@@ -289,8 +289,8 @@ class AutoencoderKLCogVideoX:
                         weight_sums=self.weight_sums), tmode
 
     def _encoder(self, x, cache, split_in=False):
-        """``split_in``: x is the im2col'ed input of ``ops.cl_im2col3x3_from_ncthw`` (untiled encode: a spatial tile must see zero
-        padding at ITS border, so the tiled path keeps the direct conv)."""
+        """``split_in``: x is the im2col'ed input of ``ops.cl_im2col3x3_from_ncthw`` (a spatial tile: through ``ops.tile_gather``, which
+        zeroes the taps that reach outside the tile)."""
         h = self._cconv(x, "encoder.conv_in.taps" if split_in and self._conv_in_split else "encoder.conv_in", cache)
         nb = len(self.boc)
         for i in range(nb):
@@ -304,8 +304,8 @@ class AutoencoderKLCogVideoX:
         return self._cconv(h, "encoder.conv_out", cache)
 
     def _decoder(self, z, cache, split_out=False):
-        """``split_out``: return the tap-split conv_out's fp32 partial planes [T,H,W,32] for ``ops.conv_out_gather`` instead of the
-        conv_out result (untiled single-process decode only: the tile blend and the sharded gather want the real output)."""
+        """``split_out``: return the tap-split conv_out's fp32 partial planes [T,H,W,32] for ``ops.conv_out_gather`` (``_cl`` inside a
+        spatial tile) instead of the conv_out result (the sharded decode's gather wants the real output)."""
         h = self._cconv(z, "decoder.conv_in", cache)
         for j in range(2):
             h = self._resnet(h, f"decoder.mid_block.resnets.{j}", cache, zq=z)
@@ -328,10 +328,12 @@ class AutoencoderKLCogVideoX:
         smin_h, smin_w = c.get("sample_height", 480) // 2, c.get("sample_width", 720) // 2
         return dict(smin_h=smin_h, smin_w=smin_w, lmin_h=int(smin_h / down), lmin_w=int(smin_w / down), of_h=1 / 6, of_w=1 / 5)
 
-    def _tiled(self, x_cl, tile_h, tile_w, stride_h, stride_w, blend_h, blend_w, lim_h, lim_w, batch, fn):
+    def _tiled(self, x_cl, tile_h, tile_w, stride_h, stride_w, blend_h, blend_w, lim_h, lim_w, batch, fn, im2col_cin=0):
         """Tile loop of diffusers tiled_encode/tiled_decode on a channels-last [T,H,W,C] tensor: each tile runs the whole
         frame-batched network with its own conv caches (GroupNorm statistics become per tile); tiles are cross-faded
-        IN PLACE with their already blended upper / left neighbours, cropped and concatenated."""
+        IN PLACE with their already blended upper / left neighbours, cropped and concatenated.  ``im2col_cin`` > 0: x_cl is the im2col'ed
+        clip (encoder.conv_in in its (3,1,1) form); ops.tile_gather zeroes the taps that reach outside a tile at its border, so a tile
+        still sees zero padding at ITS border."""
         T, H, W, _ = x_cl.shape
         ii, jj = list(range(0, H, stride_h)), list(range(0, W, stride_w))
         rows = [[None] * len(jj) for _ in ii]
@@ -387,8 +389,8 @@ class AutoencoderKLCogVideoX:
                                 if helper is not None:
                                     cache.stream = st
                                 with torch.cuda.stream(st):
-                                    xb = torch.stack([x_cl[s:e, ii[a]:ii[a] + th, jj[b]:jj[b] + tw] for a, b in members])   # [nb, t, th, tw, C]
-                                    o = fn(xb.view(nb * (e - s), th, tw, xb.shape[-1]), cache)
+                                    xb = ops.tile_gather(x_cl, s, e - s, th, tw, [(ii[a], jj[b]) for a, b in members], im2col_cin)   # [nb * t, th, tw, C]
+                                    o = fn(xb, cache)
                                     parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
                         finally:
                             self._nb = 1
@@ -411,7 +413,7 @@ class AutoencoderKLCogVideoX:
                 for b, j in enumerate(jj):
                     cache, parts = {}, []
                     for s, e in frame_batches(T, batch):
-                        parts.append(fn(x_cl[s:e, i:i + tile_h, j:j + tile_w].contiguous(), cache))
+                        parts.append(fn(ops.tile_gather(x_cl, s, e - s, min(tile_h, H - i), min(tile_w, W - j), [(i, j)], im2col_cin), cache))
                     rows[a][b] = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
         out_rows = []
         for i, row in enumerate(rows):
@@ -425,19 +427,26 @@ class AutoencoderKLCogVideoX:
             out_rows.append(torch.cat(out_row, dim=2))
         return torch.cat(out_rows, dim=1).contiguous()
 
-    def _tiled_encode(self, x_cl):
+    def _tiled_encode(self, x_cl, im2col_cin=0):
         p = self._tiling_params()
         st_h, st_w = int(p["smin_h"] * (1 - p["of_h"])), int(p["smin_w"] * (1 - p["of_w"]))
         bl_h, bl_w = int(p["lmin_h"] * p["of_h"]), int(p["lmin_w"] * p["of_w"])
+        fn = (lambda xb, cache: self._encoder(xb, cache, split_in=True)) if im2col_cin else self._encoder
         return self._tiled(x_cl, p["smin_h"], p["smin_w"], st_h, st_w, bl_h, bl_w, p["lmin_h"] - bl_h, p["lmin_w"] - bl_w,
-                           self.enc_batch, self._encoder)
+                           self.enc_batch, fn, im2col_cin)
 
     def _tiled_decode(self, z_cl):
         p = self._tiling_params()
         st_h, st_w = int(p["lmin_h"] * (1 - p["of_h"])), int(p["lmin_w"] * (1 - p["of_w"]))
         bl_h, bl_w = int(p["smin_h"] * p["of_h"]), int(p["smin_w"] * p["of_w"])
+        fn = self._decoder
+        if self._conv_out_split:
+            # the tap-split conv_out inside a tile: the 9-tap shifted sum is per frame, i.e. per tile (taps beyond the tile border add
+            # nothing = the tile's own zero padding), and stays channels-last for the blend (8 channels: 3 real)
+            cout, bias = self.config["out_channels"], self.conv_out_bias
+            fn = lambda zb, cache: ops.conv_out_gather_cl(self._decoder(zb, cache, split_out=True), cout, bias, 8)   # noqa: E731
         return self._tiled(z_cl, p["lmin_h"], p["lmin_w"], st_h, st_w, bl_h, bl_w, p["smin_h"] - bl_h, p["smin_w"] - bl_w,
-                           self.dec_batch, self._decoder)
+                           self.dec_batch, fn)
 
     # ---- two-stream execution of the frame-batches ------------------------------------------------------------
     def _run_batches(self, x_cl, batch, fn, post=None):
@@ -485,7 +494,11 @@ class AutoencoderKLCogVideoX:
         moments = []
         for b in range(x.shape[0]):
             if tiled:
-                moments.append(self._tiled_encode(ops.cl_from_ncthw(x[b], cin_pad)))
+                if self._conv_in_split:
+                    moments.append(self._tiled_encode(ops.cl_im2col3x3_from_ncthw(x[b], self.pc["encoder.conv_in.taps"].cin_pad),
+                                                      im2col_cin=x.shape[1]))
+                else:
+                    moments.append(self._tiled_encode(ops.cl_from_ncthw(x[b], cin_pad)))
                 continue
             if self._conv_in_split:
                 x_cl = ops.cl_im2col3x3_from_ncthw(x[b], self.pc["encoder.conv_in.taps"].cin_pad)

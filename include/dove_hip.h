@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define DOVE_ABI_VERSION 14
+#define DOVE_ABI_VERSION 15
 
 /* dtype codes for boundary tensors */
 #define DOVE_F32 0
@@ -78,7 +78,7 @@ typedef struct dove_conv_desc {
    * (instance b's first frames read ITS cache frames, cache + b * cache_stride).  The spatial tiles of diffusers' tiled_encode /
    * tiled_decode (`--is_vae_st`, /root/reference/inference_script.py:642-645) are such instances: each tile sees zero padding at its
    * own border and keeps its own conv cache and GroupNorm scope, so same-shaped tiles run as ONE launch instead of one per tile.
-   * Results are those of nb separate calls.  0 / 1 = one instance.  Not combined with gate / out_f32. */
+   * Results are those of nb separate calls.  0 / 1 = one instance.  Not combined with gate. */
   int nb;
   /* elements between two instances' cache frames; 0 = (kt-1) * h_in * w_in * cin (a dense [nb][kt-1][h][w][cin] array).  A cache that is
    * a view of the previous frame-batch's input [nb][t_prev][h][w][cin] passes t_prev * h_in * w_in * cin. */
@@ -249,6 +249,18 @@ int dove_patchify(const void* x, int dtype, int T, int C, int H, int W, int pt, 
                   void* stream);
 int dove_unpatchify(const void* tokens, long long ld, int T, int C, int H, int W, int pt, int p, void* y, int dtype,
                     void* stream);
+/* The same gather for a SPATIAL TILE of diffusers' tiled_decode (`--is_vae_st`, /root/reference/inference_script.py:642-645): the tile is
+ * cross-faded with its neighbours in the channels-last layout before the clip changes layout, so the result stays channels-last:
+ * y[t][oy][ox][c] = bf16(bias[c] + sum ...) for c < C, 0 for C <= c < ldy; bf16 [T,H,W,ldy], C <= ldy <= 32, ldy % 4 == 0; no range map.
+ * T may be nb x frames (tile-major batch): frames are independent.  (ABI 15) */
+int dove_conv_out_gather_cl(const float* p, long long ldp, int T, int H, int W, int C, const float* bias, void* y, int ldy, void* stream);
+/* Spatial tiles of diffusers' tiled_encode / tiled_decode as ONE tile-major batch (dove_conv_desc.nb): out [nb][nt][th][tw][C] <-
+ * x [T][H][W][C] bf16 channels-last, frames [t0, t0 + nt), tile n at (oy[n], ox[n]) (HOST arrays, nb <= 64), C % 8 == 0.
+ * im2col_cin > 0: x is the im2col'ed clip of dove_cl_im2col3x3_from_ncthw with C = im2col_cin input channels; the channels of taps that
+ * reach outside the TILE are zeroed at the tile's border pixels (each tile sees zero padding at its own border), so that the batch equals
+ * the im2col of the cropped tiles bit for bit and encoder.conv_in runs in its (3,1,1) form inside tiles too.  (ABI 15) */
+int dove_tile_gather_bf16(const void* x, int H, int W, int C, int t0, int nt, int th, int tw, int nb, const int* oy, const int* ox,
+                          int im2col_cin, void* out, void* stream);
 /* AutoencoderKLCogVideoX.blend_v / blend_h of the spatial-tiling path (`enable_tiling`, ref :644-645): in-place linear
  * cross-fade of the first `extent` rows (axis 0) / columns (axis 1) of tile b with the last ones of its neighbour a;
  * channels-last tiles [T,H,W,ld], ld multiple of 4. */

@@ -148,6 +148,38 @@ def conv_out_gather(p, Cc, bias, dtype, scale=1.0, shift=0.0, lo=-math.inf, hi=m
     return (v * scale + shift).clamp(lo, hi).permute(1, 0, 2, 3).contiguous().to(dtype)
 
 
+def conv_out_gather_cl(p, Cc, bias, ld=8):
+    """dove_conv_out_gather_cl: the same 9-tap shifted sum, channels-last bf16 [T,H,W,ld] (channels >= Cc zero), no range map."""
+    v = conv_out_gather(p, Cc, bias, BF)                                   # [Cc, T, H, W]
+    T, H, W, _ = p.shape
+    y = torch.zeros(T, H, W, ld, dtype=BF)
+    y[..., :Cc] = v.permute(1, 2, 3, 0)
+    return y
+
+
+def tile_gather(x, t0, nt, th, tw, origins, im2col_cin=0):
+    """dove_tile_gather_bf16: tiles of a channels-last clip as one tile-major batch; for an im2col'ed clip the taps that reach outside a
+    tile are zeroed at its border pixels."""
+    tiles = []
+    for oy, ox in origins:
+        t = x[t0:t0 + nt, oy:oy + th, ox:ox + tw].clone()
+        if im2col_cin:
+            c = im2col_cin
+            for dy in range(3):
+                for dx in range(3):
+                    k = (dy * 3 + dx) * c
+                    if dy == 0:
+                        t[:, 0, :, k:k + c] = 0
+                    if dy == 2:
+                        t[:, th - 1, :, k:k + c] = 0
+                    if dx == 0:
+                        t[:, :, 0, k:k + c] = 0
+                    if dx == 2:
+                        t[:, :, tw - 1, k:k + c] = 0
+        tiles.append(t)
+    return torch.cat(tiles, dim=0).contiguous()
+
+
 def linear(x, pc, **kw):
     N = x.shape[0]
     out = kw.pop("out", None)
@@ -528,7 +560,7 @@ def attention_bias(qkv, bias, heads):
     return torch.einsum("hqk,hkd->hqd", p, v).permute(1, 0, 2).reshape(N, D).to(BF)
 
 
-ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "ulysses_place", "qkv_post_mx", "attention_mx",
+ALL = ["rmsnorm", "gated_gelu", "attention_bias", "mx_quant", "pack_linear_mx", "linear_mx", "groupnorm_sums", "groupnorm_sums_of", "groupnorm_from_sums", "groupnorm_stats_of", "blend_edge", "preprocess_u8", "postprocess_u8", "conv", "conv_out_gather", "conv_out_gather_cl", "tile_gather", "linear", "groupnorm_stats", "groupnorm_apply", "layernorm_modulate", "qkv_post", "attention", "vt_quad_swap", "ulysses_place", "qkv_post_mx", "attention_mx",
        "cl_from_ncthw", "cl_im2col3x3_from_ncthw", "ncthw_from_cl", "avgpool_time", "posterior_sample", "axpby", "patchify", "unpatchify", "gemv"]
 
 

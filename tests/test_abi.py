@@ -35,7 +35,7 @@ def test_binding_covers_header():
 
 
 def test_version_and_error_channel(lib):
-    assert lib.dove_abi_version() == 14
+    assert lib.dove_abi_version() == 15
     # argument validation happens before any HIP call, so it is safe without a GPU
     rc = lib.dove_axpby(None, None, None, 0, 0, 1.0, 1.0, None)
     assert rc == -1 and b"axpby" in lib.dove_last_error()

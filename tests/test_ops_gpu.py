@@ -606,6 +606,48 @@ def test_conv_fused_gn_stats(cin, cout, k, T, H, W, up, resid):
     assert getattr(ops.conv(x.cuda(), pc_g, out=y, **kw), "gn_stats", None) is None    # re-used output drops stale stats
 
 
+@pytest.mark.parametrize("cin,cout,k,T,H,W,cache,resid", [
+    (128, 128, (3, 3, 3), 3, 24, 40, True, True),        # H % 16 = 8 and W % 32 = 8: main + right column (kPart 1) + bottom row (kPart 2)
+    (64, 256, (3, 3, 3), 2, 33, 96, False, False),        # only the bottom row is partial (H % 16 = 1), two cout tiles, w_first frames
+    (128, 128, (3, 3), 5, 48, 45, False, True),           # only the right column (W % 32 = 13: the 30 x 45 latent tile's width), kt = 1
+    (256, 256, (3, 3, 3), 2, 20, 16, True, False),        # ONE tile column that is partial (W = 16): no main launch at all
+    (128, 128, (3, 3, 3), 2, 8 + 16, 360, True, False),   # the 240 x 360 VAE tile's width: 11 full columns + 8 pixels
+])
+def test_conv_partial_tiles_bit_identical_to_full_tiles(cin, cout, k, T, H, W, cache, resid):
+    """conv3x3_halo4x's PARTIAL-tile launches (kPart 1 / 2: the last tile column / row when the image ends within its first half run with half
+    the register tile, as up to three launches over disjoint tile rectangles) against the SAME conv on full tiles only: the image embedded,
+    top-left, in a zero frame whose size is a multiple of 16 x 32 - the zeros are the conv's own zero padding and add exact zeros, so the
+    cropped result must be bit-identical; fused GroupNorm statistics of the partial form == a separate pass over its output."""
+    pc_c, pc_g = pack(cout, cin, k)
+    Hp, Wp = -(-H // 16) * 16, -(-W // 32) * 32
+    assert (H % 16 in range(1, 9)) or (W % 32 in range(1, 17))
+    x = rnd(T, H, W, cin, seed=71)
+    xp = torch.zeros(T, Hp, Wp, cin, dtype=BF)
+    xp[:, :H, :W] = x
+    kw, kwp = {}, {}
+    if cache and len(k) == 3:
+        c = rnd(2, H, W, cin, seed=72)
+        cp = torch.zeros(2, Hp, Wp, cin, dtype=BF)
+        cp[:, :H, :W] = c
+        kw["cache"], kwp["cache"] = c.cuda(), cp.cuda()
+    if resid:
+        r = rnd(T, H, W, cout, seed=73)
+        rp = torch.zeros(T, Hp, Wp, cout, dtype=BF)
+        rp[:, :H, :W] = r
+        kw["resid"], kwp["resid"] = r.cuda(), rp.cuda()
+    assert ops.conv_kernel_name(x.shape, pc_g, resid=resid) == "conv3x3_halo4x_kernel"
+    y = ops.conv(x.cuda(), pc_g, gn_eps=1e-6, **kw)
+    yp = ops.conv(xp.cuda(), pc_g, **kwp)
+    torch.cuda.synchronize()
+    assert torch.equal(y, yp[:, :H, :W].contiguous()), float((y.float() - yp[:, :H, :W].float()).abs().max())
+    close("partial_tiles_vs_emu", y, E.conv(x, pc_c, cache=kw["cache"].cpu() if "cache" in kw else None, resid=kw["resid"].cpu() if resid else None))
+    fused = getattr(y, "gn_stats", None)
+    assert fused is not None
+    ref = ops.groupnorm_stats(y, 1e-6)
+    torch.cuda.synchronize()
+    assert torch.allclose(fused[0].cpu(), ref.cpu(), rtol=2e-4, atol=2e-5), (fused[0].cpu() - ref.cpu()).abs().max()
+
+
 def test_conv_and_linear_fullsize_properties():
     """Headline shapes (128->128 3x3x3 conv on 8x720x1280; 18 226 x 3072 -> 9216 linear): determinism, exact
     power-of-two homogeneity (op(2x) == 2 op(x) without bias: every product and partial sum scales exactly), temporal
@@ -702,6 +744,40 @@ def test_layout_and_glue():
         ref = E.gemv(Wm, bias, xv, act)
         assert torch.allclose(got.cpu(), ref, rtol=1e-4, atol=1e-4), (got.cpu() - ref).abs().max()
     torch.cuda.synchronize()
+
+
+def test_tile_gather_and_im2col_tile_borders():
+    """dove_tile_gather_bf16 (ABI 15): same-shaped tiles of a channels-last clip as one tile-major batch, bit for bit; on an im2col'ed clip the
+    batch equals the im2col of the CROPPED tiles (zero padding at each tile's own border: what diffusers' tiled_encode hands conv_in;
+    /root/reference/inference_script.py:642-645), for interior tiles and tiles that touch the clip border alike."""
+    x = torch.randn(3, 7, 40, 56, generator=torch.Generator().manual_seed(61)).clamp(-1, 1).to(BF)
+    cl = ops.cl_from_ncthw(x.cuda(), 32)
+    origins = [(0, 0), (8, 24), (16, 32), (3, 5)]
+    got = ops.tile_gather(cl, 2, 4, 24, 24, origins)
+    ref = E.tile_gather(cl.cpu(), 2, 4, 24, 24, origins)
+    assert got.shape == (16, 24, 24, 32) and torch.equal(got.cpu(), ref)
+    im = ops.cl_im2col3x3_from_ncthw(x.cuda(), 32)
+    got = ops.tile_gather(im, 2, 4, 24, 24, origins, im2col_cin=3)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), E.tile_gather(im.cpu(), 2, 4, 24, 24, origins, im2col_cin=3))
+    want = torch.cat([E.cl_im2col3x3_from_ncthw(x[:, 2:6, oy:oy + 24, ox:ox + 24], 32) for oy, ox in origins], dim=0)
+    assert torch.equal(got.cpu(), want)
+    with pytest.raises(RuntimeError, match="leaves the"):
+        ops.tile_gather(cl, 0, 2, 24, 24, [(20, 0)])
+
+
+def test_conv_out_gather_channels_last():
+    """dove_conv_out_gather_cl (ABI 15): the tap-split conv_out's 9-tap shifted sum for a spatial tile batch, channels-last bf16 with zeroed
+    pad channels, equal to the NCTHW gather's values (the conv's own bf16 output rounding, no range map)."""
+    for (T, H, W) in ((3, 9, 70), (2, 17, 64)):
+        p = torch.randn(T, H, W, 32, generator=torch.Generator().manual_seed(62))
+        bias = torch.randn(3, generator=torch.Generator().manual_seed(63))
+        got = ops.conv_out_gather_cl(p.cuda(), 3, bias.cuda(), 8)
+        ref_nc = ops.conv_out_gather(p.cuda(), 3, bias.cuda(), BF)
+        torch.cuda.synchronize()
+        assert got.shape == (T, H, W, 8) and bool((got[..., 3:] == 0).all())
+        assert torch.equal(got[..., :3].permute(3, 0, 1, 2).contiguous(), ref_nc)
+        close("conv_out_gather_cl", got, E.conv_out_gather_cl(p, 3, bias, 8))
 
 
 @pytest.mark.parametrize("ld,axis", [(32, 0), (32, 1), (4, 0), (4, 1)])
