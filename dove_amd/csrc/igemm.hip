@@ -351,6 +351,25 @@ struct Halo4xSubCfg {
   static constexpr int inflight(int tap, int nr) { return issued((tap + NT - 1) % NT, nr); }
 };
 
+// PARTIAL tiles (conv3x3_halo4x_kernel's kPart): a step has 32 MFMAs (~560 cycles), so a weight tap staged 3 steps ahead would be read ~0.7 us
+// after its LDS-DMA was issued - less than the ~1.1 us such a load takes to land, and every step would wait for its weights (measured: the
+// first cut with the full tile's ring gained nothing on the 128 -> 128 class).  Half of the LDS image is unused by a partial tile (18 x 18 or
+// 10 x 34 halo pixels = 7 rounds instead of 12), which pays for a 9-slot ring staged SIX steps ahead: slot(tap, parity) = tap.
+struct Halo4xPartCfg {
+  static constexpr int BR = 9, BAHEAD = 6, HPS = 2, DS0 = 4, NT = 9;
+  static constexpr int A_BYTES = 9 * 4096;                      // halo buffer: 7 rounds of 4 KB staged; 9 so that the epilogue's four 8.5 KB slices fit
+  static constexpr int ESL = 9216;
+  static constexpr int LDS_BYTES = 2 * A_BYTES + BR * halo8::B_BYTES;          // 147456
+  static constexpr int nh(int tap, int nr) { return (HPS * tap + HPS <= nr) ? HPS : ((HPS * tap < nr) ? nr - HPS * tap : 0); }
+  static constexpr int round0(int tap) { return HPS * tap; }
+  static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
+  static constexpr int inflight(int tap, int nr) {
+    int n = 0;
+    for (int d = 1; d <= BAHEAD - 2; ++d) n += issued((tap + 9 - d) % 9, nr);
+    return n;
+  }
+};
+
 // Staging-side state of the persistent halo4x walk.  Plain structs + force-inlined functions (not by-reference lambda
 // closures nested three deep: those left the counters in scratch memory, where the compiler treats them as per-lane
 // values and builds every buffer descriptor through a waterfall loop).
@@ -438,10 +457,11 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
         ih = (q.oh0 >> 1) - 1 + hh; iw = (q.ow0 >> 1) - 1 + hw;
         inb = px < UHW * UHH;
       } else {
-        const int hh = px / HWID, hw = px - hh * HWID;
+        // partial tiles: an 18 x 18 (kPart 1: 16 columns) / 10 x 34 (kPart 2: 8 rows) halo image, 7 rounds
+        constexpr int HW = kPart == 1 ? halo8::TW / 2 + 2 : HWID, HH = kPart == 2 ? halo8::TH / 2 + 2 : HHGT;
+        const int hh = px / HW, hw = px - hh * HW;
         ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
-        // partial tiles read 16 columns / 8 rows (+ halo) of the LDS image: the rest is not fetched (out-of-range lanes cost no traffic)
-        inb = px < HPIX && (kPart != 1 || hw < halo8::TW / 2 + 2) && (kPart != 2 || hh < halo8::TH / 2 + 2);
+        inb = px < HW * HH;
       }
       const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
       s.voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
@@ -511,14 +531,20 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false, int kPart = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
-  using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
+  using CFG = typename std::conditional<kPart != 0, Halo4xPartCfg, typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type>::type;
   static_assert(!(kUp && kSub), "the sub-pixel form runs on the plain halo geometry of the low-res grid");
   static_assert(kPart == 0 || (kM16 && !kUp && !kSub && !kTiming && kPipe), "partial tiles: the 16 x 16 x 32 walk of the plain conv only");
+  // LDS image of a partial tile (these shadow the halo8 constants): 18-pixel halo rows (kPart 1) / 10 halo rows (kPart 2), smaller halo buffers
+  constexpr int HWID = kPart == 1 ? halo8::TW / 2 + 2 : halo8::HWID;
+  constexpr int HROWS = kPart == 2 ? halo8::TH / 2 + 2 : halo8::HHGT;
+  constexpr int A_BYTES = kPart ? Halo4xPartCfg::A_BYTES : halo8::A_BYTES;
+  constexpr int ESL = kPart ? Halo4xPartCfg::ESL : 12288;
   constexpr int RPW = kPart == 2 ? 2 : 4;                       // tile rows per wave
   constexpr int NS = kPart ? 4 : 8;                             // pixel blocks (16 px) per wave; slot s is block (kPart == 1 ? 2 s : s)
   static_assert(!kPart || CFG::HPS <= 2, "partial tiles: a step has issue slots for two halo rounds");
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
-  constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (ASLOTS + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12
+  constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (HWID * HROWS * 5 + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12 (partial tiles: 7)
+  static_assert(NR * 4096 <= A_BYTES, "halo rounds overflow the halo buffer");
   constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, NT = CFG::NT;
   constexpr int B0 = 2 * A_BYTES;                               // LDS: halo buffer 0 | halo buffer 1 | weight ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -618,15 +644,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     stage_halo_round(std::integral_constant<int, 2>{}, I0{}); stage_halo_round(std::integral_constant<int, 3>{}, I0{});
     if (!kUp) {
       stage_halo_round(std::integral_constant<int, 4>{}, I0{}); stage_halo_round(std::integral_constant<int, 5>{}, I0{});
-      stage_halo_round(std::integral_constant<int, 6>{}, I0{}); stage_halo_round(std::integral_constant<int, 7>{}, I0{});
-      stage_halo_round(std::integral_constant<int, 8>{}, I0{}); stage_halo_round(std::integral_constant<int, 9>{}, I0{});
-      stage_halo_round(std::integral_constant<int, 10>{}, I0{}); stage_halo_round(std::integral_constant<int, 11>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 6>{}, I0{});
+      if (NR > 7) {
+        stage_halo_round(std::integral_constant<int, (NR > 7 ? 7 : 0)>{}, I0{});
+        stage_halo_round(std::integral_constant<int, (NR > 7 ? 8 : 0)>{}, I0{}); stage_halo_round(std::integral_constant<int, (NR > 7 ? 9 : 0)>{}, I0{});
+        stage_halo_round(std::integral_constant<int, (NR > 7 ? 10 : 0)>{}, I0{}); stage_halo_round(std::integral_constant<int, (NR > 7 ? 11 : 0)>{}, I0{});
+      }
     }
   }
+  static_assert(kUp || NR == 7 || NR == 12, "the prologue stages 7 or 12 halo rounds");
   b_wp = wg_nxt;
   stage_b(std::integral_constant<int, 0>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 1>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 2>{}, nrec_b_nxt);
+  if (BAHEAD == 6) {                                            // partial tiles: six weight taps ahead
+    stage_b(std::integral_constant<int, 3>{}, nrec_b_nxt);
+    stage_b(std::integral_constant<int, (BAHEAD == 6 ? 4 : 0)>{}, nrec_b_nxt);
+    stage_b(std::integral_constant<int, (BAHEAD == 6 ? 5 : 0)>{}, nrec_b_nxt);
+  }
+  static_assert(BAHEAD == 3 || BAHEAD == 6, "the prologue stages 3 or 6 weight taps");
   h4_advance<kUp, kPart>(st, a, kc);
   publish(st);                                                  // cur = group 0 of the first tile, nxt = its successor
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -925,7 +961,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     if (kTiming) tm2 = __builtin_amdgcn_s_memtime();
     {
       constexpr int EROW = 272;                              // 64 fp32 per pixel + 16 pad
-      char* const eslice = smem + A_BYTES + wave * 12288;      // (a tile's last group has parity 1)
+      char* const eslice = smem + A_BYTES + wave * ESL;        // (a tile's last group has parity 1)
       // lane byte offsets inside one output row segment (32 pixels from ow0, channels from n0): buffer addressing, so a
       // column past the image edge is an out-of-range offset (dropped by the hardware) and a row past it a zero-length
       // descriptor - the epilogue has no divergent control flow and no per-store 64-bit address arithmetic

@@ -101,16 +101,19 @@ def _bare_vmcnt_waits(walk):
     return bare
 
 
-@pytest.mark.parametrize("variant,taps", [("ILb0ELb0ELb1ELb0ELb1E", 9), ("ILb1ELb0ELb1ELb0ELb1E", 9), ("ILb0ELb0ELb1ELb1ELb1E", 4)],
-                         ids=["direct", "upsample-in-addressing", "sub-pixel"])
-def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, taps):
+@pytest.mark.parametrize("variant,taps,per_step", [("ILb0ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb1ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb0ELb0ELb1ELb1ELb1ELi0E", 4, 64),
+                                                    ("ILb0ELb0ELb1ELb0ELb1ELi1E", 9, 32), ("ILb0ELb0ELb1ELb0ELb1ELi2E", 9, 32)],
+                         ids=["direct", "upsample-in-addressing", "sub-pixel", "partial-columns", "partial-rows"])
+def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, taps, per_step):
     """conv3x3_halo4x runs ONE wave per SIMD on the whole 512-register file: its 8 x 8 accumulator tile of 16 x 16 blocks is the 256 AGPRs
     (asm MFMAs with the accumulator tied and constrained to the AGPR file - as builtins the allocator rotated the quads through VGPRs and
     spilled), everything else must fit the 256 VGPRs WITHOUT scratch and without a single accumulator move inside the tap walk.  Its operand
     ring is kept in flight by hand-counted `s_waitcnt vmcnt(n)` in asm; a wait the compiler adds on its own between the first and the last
     MFMA means it lost track of the queue and drains the ring there (what happened to gemm8p in round 3).  The unrolled body is two groups
     of `taps` spatial-tap steps x 64 MFMAs of v_mfma_f32_16x16x32_bf16 (9 taps; 4 in the sub-pixel form of the upsample-fused conv,
-    dove_conv_desc.w_sub), each step with its 16 fragment reads pinned between MFMA pairs."""
+    dove_conv_desc.w_sub), each step with its 16 fragment reads pinned between MFMA pairs.  The PARTIAL-tile variants (kPart 1 / 2: the last
+    tile column / row of an image that ends within its first half) walk the same steps with half the register tile: 32 MFMAs and 12 fragment
+    reads per step, 128 accumulator registers."""
     text = igemm_asm
     name = f"_Z21conv3x3_halo4x_kernel{variant}Ev9IgemmArgs"
 
@@ -120,11 +123,11 @@ def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, t
         return int(m.group(1))
 
     assert prop("private_seg_size") == 0, f"{name}: scratch in use"
-    assert prop("num_agpr") == 256 and prop("num_vgpr") <= 256, f"{name}: register budget {prop('num_vgpr')} + {prop('num_agpr')}"
+    assert prop("num_agpr") == 4 * per_step and prop("num_vgpr") <= 256, f"{name}: register budget {prop('num_vgpr')} + {prop('num_agpr')}"
     body = _kernel_body(text.split("\n"), name)
     assert not any("scratch_" in l for l in body), f"{name}: scratch instructions"
     mf = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
-    assert len(mf) == 2 * taps * 64, f"{name}: expected 2 groups x {taps} taps x 64 MFMAs, found {len(mf)}"
+    assert len(mf) == 2 * taps * per_step, f"{name}: expected 2 groups x {taps} taps x {per_step} MFMAs, found {len(mf)}"
     assert not any("v_mfma_f32_32x32x16_bf16" in l for l in body), f"{name}: a 32x32x16 MFMA in the 16x16x32 walk"
     walk = body[mf[0]:mf[-1]]
     bare = _bare_vmcnt_waits(walk)
@@ -135,7 +138,8 @@ def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, t
     for i in mf:
         ops_ = [t.strip() for t in body[i].split("v_mfma_f32_16x16x32_bf16")[1].split(",")]
         assert ops_[0].startswith("a[") and ops_[0] == ops_[3].split()[0], f"{name}: `{body[i].strip()}`"
-    assert sum("ds_read_b128" in l for l in walk) >= 2 * taps * 16 - 12, f"{name}: 16 fragment reads per step expected"
+    reads = 16 if per_step == 64 else 12
+    assert sum("ds_read_b128" in l for l in walk) >= 2 * taps * reads - 12, f"{name}: {reads} fragment reads per step expected"
 
 
 def test_gemm8p_k_walk_keeps_its_operand_stream_in_flight(igemm_asm):
