@@ -351,24 +351,23 @@ struct Halo4xSubCfg {
   static constexpr int inflight(int tap, int nr) { return issued((tap + NT - 1) % NT, nr); }
 };
 
-// PARTIAL tiles (conv3x3_halo4x_kernel's kPart): a step has 32 MFMAs (~560 cycles), so a weight tap staged 3 steps ahead would be read ~0.7 us
-// after its LDS-DMA was issued - less than the ~1.1 us such a load takes to land, and every step would wait for its weights (measured: the
-// first cut with the full tile's ring gained nothing on the 128 -> 128 class).  Half of the LDS image is unused by a partial tile (18 x 18 or
-// 10 x 34 halo pixels = 7 rounds instead of 12), which pays for a 9-slot ring staged SIX steps ahead: slot(tap, parity) = tap.
-struct Halo4xPartCfg {
-  static constexpr int BR = 9, BAHEAD = 6, HPS = 2, DS0 = 4, NT = 9;
-  static constexpr int A_BYTES = 9 * 4096;                      // halo buffer: 7 rounds of 4 KB staged; 9 so that the epilogue's four 8.5 KB slices fit
-  static constexpr int ESL = 9216;
-  static constexpr int LDS_BYTES = 2 * A_BYTES + BR * halo8::B_BYTES;          // 147456
-  static constexpr int nh(int tap, int nr) { return (HPS * tap + HPS <= nr) ? HPS : ((HPS * tap < nr) ? nr - HPS * tap : 0); }
-  static constexpr int round0(int tap) { return HPS * tap; }
-  static constexpr int issued(int tap, int nr) { return 2 + nh(tap, nr); }
-  static constexpr int inflight(int tap, int nr) {
-    int n = 0;
-    for (int d = 1; d <= BAHEAD - 2; ++d) n += issued((tap + 9 - d) % 9, nr);
-    return n;
-  }
+// Tile GEOMETRY of a halo4x launch (conv3x3_halo4x_kernel's kPart).  The register tile is always 4 waves x 8 pixel blocks of 16 pixels x 128 couts;
+// what changes is how the 32 blocks are laid over the image:
+//   kPart 0   16 rows x 32 columns   wave w: rows 4 w .. 4 w + 3, block idx -> (row idx >> 1, columns 16 (idx & 1) ..)      halo 18 x 34
+//   kPart 1   32 rows x 16 columns   wave w: rows 8 w .. 8 w + 7, block idx -> (row idx, columns 0 .. 15)                    halo 34 x 18
+// (An 8 x 64 geometry for a partial last tile ROW was built and measured too, commit history of round 6: under the rounds rule of halo4x_plan it
+// never wins a product shape, and its GroupNorm partial sums cannot reproduce the 16 x 32 form's bit for bit - two waves share a slot - so it is gone.)
+template <int kPart> struct H4Geo {
+  static constexpr int TH = kPart == 1 ? 32 : 16, TW = kPart == 1 ? 16 : 32;
+  static constexpr int HWID = TW + 2, HROWS = TH + 2, HPIX = HWID * HROWS;               // 612 halo pixels either way
+  static constexpr int NR = (HPIX * 5 + 255) / 256;                                      // 12 halo rounds of 256 x 16 B
+  static constexpr int A_BYTES = NR * 4096;                                              // 49152
+  static constexpr int RPW = TH / 4;                                                     // tile rows per wave
+  static constexpr int LDS_BYTES = 2 * A_BYTES + 6 * halo8::B_BYTES;                     // 147456
+  static __device__ __forceinline__ constexpr int prow(int idx) { return kPart == 1 ? idx : idx >> 1; }
+  static __device__ __forceinline__ constexpr int pcol(int idx) { return kPart == 1 ? 0 : (idx & 1); }
 };
+constexpr int H4_MAX_ROUNDS = 12;
 
 // Staging-side state of the persistent halo4x walk.  Plain structs + force-inlined functions (not by-reference lambda
 // closures nested three deep: those left the counters in scratch memory, where the compiler treats them as per-lane
@@ -379,7 +378,7 @@ struct H4Const {
   long long frame_elems, wtap_stride;
 };
 struct H4State {
-  unsigned voffA[12];                                         // lane offsets of the 12 halo rounds (spatial tile of nxt)
+  unsigned voffA[H4_MAX_ROUNDS];                              // lane offsets of the halo rounds (spatial tile of nxt)
   int n_tile, n_dt, n_kc, n_oh0, n_ow0;                       // group `nxt`: tile, frame tap, channel chunk
   bool n_on;                                                  // nxt's tile exists (else: zero-length descriptors)
   int t;                                                      // output frame of nxt's tile WITHIN its instance (dove_conv_desc.nb)
@@ -400,6 +399,7 @@ __device__ __forceinline__ const bf16_t* h4_pin64(const bf16_t* p) {
   return (const bf16_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
                          (unsigned)__builtin_amdgcn_readfirstlane((int)v));
 }
+template <int kPart = 0>
 __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k, int id) {
   unsigned rest = xcd_remap((unsigned)(id < k.ntiles ? id : k.ntiles - 1), (unsigned)k.ntiles);
   H4Tile q;
@@ -408,8 +408,9 @@ __device__ __forceinline__ H4Tile h4_decode(const IgemmArgs& a, const H4Const& k
   q.ph = __builtin_amdgcn_readfirstlane(a.sub ? nidx / ctn : 0);
   q.n0 = __builtin_amdgcn_readfirstlane((nidx - q.ph * ctn) * halo8::BN);
   q.t = __builtin_amdgcn_readfirstlane((int)(rest % a.T_out)); rest /= a.T_out;
-  q.ow0 = __builtin_amdgcn_readfirstlane((a.tx0 + (int)(rest % a.ntx)) * halo8::TW);
-  q.oh0 = __builtin_amdgcn_readfirstlane((a.ty0 + (int)(rest / a.ntx)) * halo8::TH);
+  // the launch walks ntx x nty tiles of ITS geometry from the origin (tx0, ty0), which is given in 16 x 32 tiles
+  q.ow0 = __builtin_amdgcn_readfirstlane(a.tx0 * halo8::TW + (int)(rest % a.ntx) * H4Geo<kPart>::TW);
+  q.oh0 = __builtin_amdgcn_readfirstlane(a.ty0 * halo8::TH + (int)(rest / a.ntx) * H4Geo<kPart>::TH);
   return q;
 }
 // How the three causal taps (frames t - 2, t - 1, t of the instance; before its first frame: the conv cache, else frame 0 replicated) of the
@@ -443,11 +444,11 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
   s.n_tile = id;
   s.n_on = id < k.ntiles;
-  const H4Tile q = h4_decode(a, k, id);
+  const H4Tile q = h4_decode<kPart>(a, k, id);
   if (q.oh0 != s.n_oh0 || q.ow0 != s.n_ow0) {                // lane offsets are redone only on a new spatial tile
     s.n_oh0 = q.oh0; s.n_ow0 = q.ow0;
 #pragma unroll
-    for (int r = 0; r < 12; ++r) {
+    for (int r = 0; r < (kUp ? 12 : H4Geo<kPart>::NR); ++r) {
       const int sl = r * 256 + k.tid;
       const int px = sl / 5, c = sl - px * 5;
       int ih, iw;
@@ -457,11 +458,10 @@ __device__ __forceinline__ void h4_open_tile(H4State& s, const IgemmArgs& a, con
         ih = (q.oh0 >> 1) - 1 + hh; iw = (q.ow0 >> 1) - 1 + hw;
         inb = px < UHW * UHH;
       } else {
-        // partial tiles: an 18 x 18 (kPart 1: 16 columns) / 10 x 34 (kPart 2: 8 rows) halo image, 7 rounds
-        constexpr int HW = kPart == 1 ? halo8::TW / 2 + 2 : HWID, HH = kPart == 2 ? halo8::TH / 2 + 2 : HHGT;
+        constexpr int HW = H4Geo<kPart>::HWID;                 // halo image of the launch's tile geometry
         const int hh = px / HW, hw = px - hh * HW;
         ih = q.oh0 - 1 + hh; iw = q.ow0 - 1 + hw;
-        inb = px < HW * HH;
+        inb = px < H4Geo<kPart>::HPIX;
       }
       const bool ok = inb && (c < 4) && ((unsigned)ih < (unsigned)a.H_in) && ((unsigned)iw < (unsigned)a.W_in);
       s.voffA[r] = ok ? (unsigned)(((ih * a.W_in + iw) * a.Cin + c * 8) * 2) : 0x80000000u;
@@ -522,29 +522,27 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // the matrix pipe alone sustains 2.0-2.1 PF on them against 1.88 PF (half the accumulator traffic per MAC; profiles/r04_mfma_shape_and_order.log).
 // Results are BIT-IDENTICAL to the 32 x 32 x 16 walk (same K order inside the pipe: every form of the kernel and the full-size VAE,
 // profiles/r04_halo_m16.log), 4.3-6.7 % faster at the headline shapes, -14.8 ms per clip.
-// kPart (round 6): PARTIAL tiles.  A 16 x 32 tile whose image ends within its first 16 columns (kPart 1: the last tile column when W % 32 is 1..16)
-// or within its first 8 rows (kPart 2: the last tile row when H % 16 is 1..8) spends half of its MFMAs on pixels that do not exist - 6.25 % of a
-// 360-px-wide VAE tile, 2.2 % of the 360-row level of the 720p clip.  A partial launch walks only that tile column / row (IgemmArgs.tx0 / ty0 /
-// ntx / nty) with HALF the register tile: 4 pixel blocks per wave instead of 8 - kPart 1: tile rows 4 w .. 4 w + 3, columns 0..15 (blocks 2 p);
-// kPart 2: tile rows 2 w, 2 w + 1, all 32 columns (blocks 0..3) - 32 MFMAs per step, the same LDS image, weight ring, staging schedule and
-// epilogue; every output pixel accumulates in the same K order as in a full tile, so results are bit-identical to the one-launch form.
+// kPart (round 6): the launch's TILE GEOMETRY (H4Geo).  A 16 x 32 tile whose image ends within its first 16 columns (the last tile column when
+// W % 32 is 1..16) spends half of its MFMAs on pixels that do not exist - 6.25 % of a 360-px-wide tile of the tiled VAE.  That column can be
+// walked by a second launch in 32 x 16 tiles (kPart 1): the same 512-pixel register tile, LDS-DMA halo image (34 x 18 halo pixels), weight ring,
+// step schedule and epilogue, only the block -> pixel map differs; a launch covers a rectangle of the image (IgemmArgs tx0 / ty0 / ntx / nty
+// origin and tile counts, h_lim / w_lim its end).  Every output pixel accumulates in the same K order as in a 16 x 32 tile and every
+// gn_partial slot sums the same pixels in the same order, so outputs AND statistics are bit-identical to the one-launch form.  (First form,
+// commit 93c1943: the last column on HALF a register tile - 32 MFMAs per step against the same weight stream - cost 0.9 of a full tile: a
+// step is then bound by the 64-B requests of the weight tiles.)
 template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false, int kPart = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
-  using CFG = typename std::conditional<kPart != 0, Halo4xPartCfg, typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type>::type;
+  using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
+  using GEO = H4Geo<kPart>;
   static_assert(!(kUp && kSub), "the sub-pixel form runs on the plain halo geometry of the low-res grid");
-  static_assert(kPart == 0 || (kM16 && !kUp && !kSub && !kTiming && kPipe), "partial tiles: the 16 x 16 x 32 walk of the plain conv only");
-  // LDS image of a partial tile (these shadow the halo8 constants): 18-pixel halo rows (kPart 1) / 10 halo rows (kPart 2), smaller halo buffers
-  constexpr int HWID = kPart == 1 ? halo8::TW / 2 + 2 : halo8::HWID;
-  constexpr int HROWS = kPart == 2 ? halo8::TH / 2 + 2 : halo8::HHGT;
-  constexpr int A_BYTES = kPart ? Halo4xPartCfg::A_BYTES : halo8::A_BYTES;
-  constexpr int ESL = kPart ? Halo4xPartCfg::ESL : 12288;
-  constexpr int RPW = kPart == 2 ? 2 : 4;                       // tile rows per wave
-  constexpr int NS = kPart ? 4 : 8;                             // pixel blocks (16 px) per wave; slot s is block (kPart == 1 ? 2 s : s)
-  static_assert(!kPart || CFG::HPS <= 2, "partial tiles: a step has issue slots for two halo rounds");
+  static_assert(kPart == 0 || (kM16 && !kUp && !kSub && !kTiming && kPipe), "tile geometry 1: the 16 x 16 x 32 walk of the plain conv only");
+  // LDS image of the launch's tile geometry (these shadow the halo8 constants of the 16 x 32 tile)
+  constexpr int HWID = GEO::HWID, A_BYTES = GEO::A_BYTES, RPW = GEO::RPW;
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
-  constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : (HWID * HROWS * 5 + 255) / 256;   // halo rounds of 256 x 16 B: 4 / 12 (partial tiles: 7)
-  static_assert(NR * 4096 <= A_BYTES, "halo rounds overflow the halo buffer");
+  constexpr int NR = kUp ? (UHW * UHH * 5 + 255) / 256 : GEO::NR;   // halo rounds of 256 x 16 B: 4 / 12
+  static_assert(NR * 4096 <= A_BYTES && NR <= H4_MAX_ROUNDS, "halo rounds overflow the halo buffer");
+  static_assert(2 * A_BYTES + CFG::BR * B_BYTES <= 160 * 1024, "LDS image larger than a CU's 160 KB");
   constexpr int BR = CFG::BR, BAHEAD = CFG::BAHEAD, NT = CFG::NT;
   constexpr int B0 = 2 * A_BYTES;                               // LDS: halo buffer 0 | halo buffer 1 | weight ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -585,12 +583,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   // (a struct captured by the step lambdas' closures is not promoted to registers)
   H4State st;
   st.n_oh0 = -1; st.n_ow0 = -1;
-  unsigned voffA[12];
+  unsigned voffA[H4_MAX_ROUNDS];
   const bf16_t *h_base = a.x, *wg_nxt = a.w;
   int h_nrec = 0, nrec_b_cur = 0, nrec_b_nxt = 0;
   auto publish = [&](const H4State& q) {
 #pragma unroll
-    for (int r = 0; r < 12; ++r) voffA[r] = q.voffA[r];
+    for (int r = 0; r < NR; ++r) voffA[r] = q.voffA[r];
     h_base = q.h_base; wg_nxt = q.wg_nxt; h_nrec = q.h_nrec; nrec_b_cur = q.nrec_b_cur; nrec_b_nxt = q.nrec_b_nxt;
   };
   const bf16_t* b_wp = a.w;                                   // running pointer of the weight stream
@@ -644,25 +642,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     stage_halo_round(std::integral_constant<int, 2>{}, I0{}); stage_halo_round(std::integral_constant<int, 3>{}, I0{});
     if (!kUp) {
       stage_halo_round(std::integral_constant<int, 4>{}, I0{}); stage_halo_round(std::integral_constant<int, 5>{}, I0{});
-      stage_halo_round(std::integral_constant<int, 6>{}, I0{});
-      if (NR > 7) {
-        stage_halo_round(std::integral_constant<int, (NR > 7 ? 7 : 0)>{}, I0{});
-        stage_halo_round(std::integral_constant<int, (NR > 7 ? 8 : 0)>{}, I0{}); stage_halo_round(std::integral_constant<int, (NR > 7 ? 9 : 0)>{}, I0{});
-        stage_halo_round(std::integral_constant<int, (NR > 7 ? 10 : 0)>{}, I0{}); stage_halo_round(std::integral_constant<int, (NR > 7 ? 11 : 0)>{}, I0{});
-      }
+      stage_halo_round(std::integral_constant<int, 6>{}, I0{}); stage_halo_round(std::integral_constant<int, 7>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 8>{}, I0{}); stage_halo_round(std::integral_constant<int, 9>{}, I0{});
+      stage_halo_round(std::integral_constant<int, 10>{}, I0{}); stage_halo_round(std::integral_constant<int, 11>{}, I0{});
     }
   }
-  static_assert(kUp || NR == 7 || NR == 12, "the prologue stages 7 or 12 halo rounds");
+  static_assert(kUp || NR == 12, "the prologue stages 12 halo rounds");
   b_wp = wg_nxt;
   stage_b(std::integral_constant<int, 0>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 1>{}, nrec_b_nxt);
   stage_b(std::integral_constant<int, 2>{}, nrec_b_nxt);
-  if (BAHEAD == 6) {                                            // partial tiles: six weight taps ahead
-    stage_b(std::integral_constant<int, 3>{}, nrec_b_nxt);
-    stage_b(std::integral_constant<int, (BAHEAD == 6 ? 4 : 0)>{}, nrec_b_nxt);
-    stage_b(std::integral_constant<int, (BAHEAD == 6 ? 5 : 0)>{}, nrec_b_nxt);
-  }
-  static_assert(BAHEAD == 3 || BAHEAD == 6, "the prologue stages 3 or 6 weight taps");
   h4_advance<kUp, kPart>(st, a, kc);
   publish(st);                                                  // cur = group 0 of the first tile, nxt = its successor
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -718,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     const int p = idx >> 1, j = idx & 1;
     if (kSub) return abaseT[tap & 3] + gb + (p * HWID + 16 * j) * APITCH;
     if (kUp) return abaseU[dw] + gb + (((p + dh + 1) >> 1) * UHW + 8 * j) * APITCH;
-    return abase0 + gb + ((p + dh) * HWID + dw + 16 * j) * APITCH;
+    return abase0 + gb + ((GEO::prow(idx) + dh) * HWID + dw + 16 * GEO::pcol(idx)) * APITCH;
   };
   auto a16_addr_next0 = [&](auto bufc, int idx) -> int {          // kSub: tap 0 of group nxt (possibly another tile, another phase)
     constexpr int gb = decltype(bufc)::value * A_BYTES;
@@ -777,42 +766,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       // first half: cout blocks 0-3 (wl) x the 8 pixel blocks.  Behind every pair of MFMAs ONE other instruction, in a fixed order
       // (sched_barrier-fenced: the MFMA mask of sched_group_barrier does not see an asm MFMA): the 4 cout-high fragments this step's
       // second half needs, then the step's LDS-DMAs (2 weight halves + NH halo rounds)
-      if (kPart) {
-        // partial tile: 16 MFMAs per half (4 cout blocks x the wave's 4 pixel blocks), ONE other instruction behind each of them, same order
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int ib = g >> 2, blk = kPart == 1 ? 2 * (g & 3) : (g & 3);
-          mfma16(ib * 8 + blk, wl[ib], xs[SP][blk]);
-          if (g < 4) wh[g] = *(const bf16x8*)(smem + b16_addr(SlotCur{}, 4 + g));
-          if (g == 4) {
-            if (stap == NT) b_wp = wg_nxt;
-            stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I0{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
-          }
-          if (g == 5) {
-            stage_b_half(std::integral_constant<int, (stap + NT * par) % BR>{}, I1{}, stap < NT ? nrec_b_cur : nrec_b_nxt);
-            b_wp += wtap_stride;
-          }
-          if (g == 6 && NH >= 1) stage_halo_round(std::integral_constant<int, (NH >= 1 ? R0 : 0)>{}, NPar{});
-          if (g == 7 && NH >= 2) stage_halo_round(std::integral_constant<int, (NH >= 2 ? R0 + 1 : 0)>{}, NPar{});
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-          const int ib = g >> 2, blk = kPart == 1 ? 2 * (g & 3) : (g & 3);
-          mfma16(32 + ib * 8 + blk, wh[ib], xs[SP][blk]);
-          if (g < 4) {
-            const int nb_ = kPart == 1 ? 2 * g : g;                 // the next step's four activation fragments ...
-            int ad;
-            if (tap < NT - 1) ad = a16_addr(std::integral_constant<int, (tap + 1) % NT>{}, Par{}, nb_);
-            else ad = a16_addr(I0{}, NPar{}, nb_);
-            xs[SP ^ 1][nb_] = *(const bf16x8*)(smem + ad);
-          } else if (g < 8) {
-            wl[g - 4] = *(const bf16x8*)(smem + b16_addr(SlotNxt{}, g - 4));   // ... and its four cout-low weight fragments
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        return;
-      }
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         mfma16(2 * g, wl[(2 * g) >> 3], xs[SP][(2 * g) & 7]);
@@ -895,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   const unsigned long long tm_start = kTiming ? __builtin_amdgcn_s_memtime() : 0;
   for (int tile = (int)blockIdx.x; tile < ntiles; tile += G) {
     if (kTiming) tm0 = __builtin_amdgcn_s_memtime();
-    const H4Tile c = h4_decode(a, kc, tile);
+    const H4Tile c = h4_decode<kPart>(a, kc, tile);
     f32x4 bias_r[2][2];                                       // this lane's 8 channels in each 64-channel half
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -929,10 +882,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
       // The tile's first fragments are read HERE, not carried over from the previous tile's last step like the 32 x 32 x 16 walk does: 12
       // fragments alive across the epilogue are 48 registers the epilogue does not have (one exposed LDS latency per tile of >= 72 steps)
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-        const int idx = kPart == 1 ? 2 * sl : sl;
-        xs[0][idx] = *(const bf16x8*)(smem + a16_addr(I0{}, I0{}, idx));
-      }
+      for (int idx = 0; idx < 8; ++idx) xs[0][idx] = *(const bf16x8*)(smem + a16_addr(I0{}, I0{}, idx));
 #pragma unroll
       for (int ib = 0; ib < 4; ++ib) wl[ib] = *(const bf16x8*)(smem + b16_addr(I0{}, ib));
     }
@@ -961,16 +911,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     if (kTiming) tm2 = __builtin_amdgcn_s_memtime();
     {
       constexpr int EROW = 272;                              // 64 fp32 per pixel + 16 pad
-      char* const eslice = smem + A_BYTES + wave * ESL;        // (a tile's last group has parity 1)
+      char* const eslice = smem + A_BYTES + wave * 12288;      // (a tile's last group has parity 1)
       // lane byte offsets inside one output row segment (32 pixels from ow0, channels from n0): buffer addressing, so a
       // column past the image edge is an out-of-range offset (dropped by the hardware) and a row past it a zero-length
       // descriptor - the epilogue has no divergent control flow and no per-store 64-bit address arithmetic
+      // A wave's 128 pixels leave in four groups p of 32 (pixel blocks 2 p and 2 p + 1), a group as 4 x 8 lanes-of-pixels `it x e_px`:
+      //   16 x 32 tiles: group p = tile row 4 w + p, pixel 8 it + e_px of its 32 columns
+      //   32 x 16 tiles: group p = tile rows 8 w + 2 p (it < 2) and + 1 (it >= 2), column 8 (it & 1) + e_px
       unsigned o_off[4], r_off[4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int px = it * 8 + e_px;
+        if (kPart == 1) {
+          const int col = px & 15, row = px >> 4;
+          const bool okw = c.ow0 + col < a.w_lim;
+          o_off[it] = okw ? (unsigned)(((row * a.W_out + col) * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
+          r_off[it] = okw ? (unsigned)(((row * a.W_out + col) * (int)a.ldr + e_ch * 8) * 2) : 0x80000000u;
+          continue;
+        }
         // kSub: the tile is 16 x 32 LOW-RES pixels of one phase: output pixel (2 y + py, 2 x + px) - every other pixel of a 64-pixel row segment
-        const bool okw = kSub ? c.ow0 + px < a.W_in : c.ow0 + px < a.W_out;
+        const bool okw = kSub ? c.ow0 + px < a.W_in : c.ow0 + px < a.w_lim;
         o_off[it] = okw ? (unsigned)(((kSub ? 2 * px : px) * (int)a.ldo + e_ch * 8) * 2) : 0x80000000u;
         r_off[it] = okw ? (unsigned)((px * (int)a.ldr + e_ch * 8) * 2) : 0x80000000u;
       }
@@ -1003,23 +963,72 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
               *(f32x4*)(eslice + l31 * EROW + (i2 * 32 + 8 * gq + 4 * hi) * 4) = o;
             }
         };
+        // GroupNorm partial sums -> gn_partial.  A row of gn_partial belongs to (16 x 32 tile, wave slot 0..3) of the conv's tile grid whatever
+        // the launch's geometry, and holds the sums over THAT slot's pixels (tile rows 4 s .. 4 s + 3) in the 16 x 32 form's order.  A wave of
+        // a 32 x 16 tile holds rows 8 w .. 8 w + 7 = slots 2 (w & 1) and 2 (w & 1) + 1 of 16 x 32 tile (ty + (w >> 1), tx): its groups
+        // p = 0, 1 are the first slot's rows, p = 2, 3 the second's, each lane meets a slot's pixels in the same order as the 16 x 32
+        // form's lane does (the columns that form pads with zeros add exact zeros) - the statistics are bit-identical.  Slots of tiles this
+        // launch does not own (past h_lim / the grid) are left alone.
+        auto gn_flush = [&](int half) {                          // half: 0 / 1 = first / second 4-row slot of a 32 x 16 tile's wave
+          const int cpg_log = a.cpg_log;                       // 2, 3 or 4 channels-per-group bits (Cout 128 / 256 / 512)
+          const int gty = (c.oh0 >> 4) + (kPart == 1 ? wave >> 1 : 0), gtx = c.ow0 >> 5;
+          const int slot = kPart == 1 ? 2 * (wave & 1) + half : wave;
+          const long long tix = ((long long)c.t * a.tiles_h + gty) * a.tiles_w + gtx;
+          const long long row = ((kSub ? tix * 4 + c.ph : tix) << 2) + slot;      // kSub: a row per phase (the four phases write the same channels)
+          float* dst = a.gn_partial + row * 64;
+          const bool own = kPart != 1 || (gty < a.tiles_h && gty * 16 < a.h_lim);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float sv[2], qv[2];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+              sv[q2] = gs[h][q2][0] + gs[h][q2][1];
+              qv[q2] = gq[h][q2][0] + gq[h][q2][1];
+#pragma unroll
+              for (int m = 8; m < 64; m <<= 1) { sv[q2] += __shfl_xor(sv[q2], m); qv[q2] += __shfl_xor(qv[q2], m); }
+              gs[h][q2] = f32x2{0.f, 0.f}; gq[h][q2] = f32x2{0.f, 0.f};
+            }
+            const int ch0 = c.n0 + h * 64 + e_ch * 8;          // first of this lane's 8 channels
+            if (cpg_log == 2) {                                // 4 channels per group: each quad is a group
+              if (e_px == 0 && own) {
+                dst[(ch0 >> 2) * 2] = sv[0]; dst[(ch0 >> 2) * 2 + 1] = qv[0];
+                dst[((ch0 >> 2) + 1) * 2] = sv[1]; dst[((ch0 >> 2) + 1) * 2 + 1] = qv[1];
+              }
+            } else {
+              float s8 = sv[0] + sv[1], q8 = qv[0] + qv[1];    // 8 channels per group: the lane's two quads
+              if (cpg_log == 4) { s8 += __shfl_xor(s8, 1); q8 += __shfl_xor(q8, 1); }   // 16: two neighbouring lanes
+              const bool writer = e_px == 0 && (cpg_log == 3 || (e_ch & 1) == 0);
+              if (writer && own) { dst[(ch0 >> cpg_log) * 2] = s8; dst[(ch0 >> cpg_log) * 2 + 1] = q8; }
+            }
+          }
+        };
         if (kPipe) wr(0, 0);
 #pragma unroll
-        for (int p = 0; p < RPW; ++p) {
-          const int oh = c.oh0 + RPW * wave + p;
+        for (int p = 0; p < 4; ++p) {
+          const int oh = c.oh0 + RPW * wave + (kPart == 1 ? 2 * p : p);
           const long long pix0 = kSub ? ((long long)c.t * a.H_out + 2 * oh + (c.ph >> 1)) * a.W_out + 2 * c.ow0 + (c.ph & 1)
                                       : ((long long)c.t * a.H_out + oh) * a.W_out + c.ow0;
-          const bool okh = kSub ? oh < a.H_in : oh < a.H_out;
+          const bool okh = kSub ? oh < a.H_in : oh < a.h_lim;
+          // bytes a group's descriptor spans: one 32-pixel row segment (kSub: 64 pixels, every other one), 32 x 16 tiles: two rows of the image
+          const int span_px = kSub ? 2 * halo8::TW : (kPart == 1 ? a.W_out + 16 : halo8::TW);
           const auto srd_o = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + pix0 * a.ldo + c.n0), (short)0,
-                                                               okh ? (int)((kSub ? 2 * TW : TW) * a.ldo * 2) : 0, 0x00020000);
+                                                               okh ? (int)(span_px * a.ldo * 2) : 0, 0x00020000);
           const auto srd_r = __builtin_amdgcn_make_buffer_rsrc((void*)(kRes ? a.resid + pix0 * a.ldr + c.n0 : a.out), (short)0,
-                                                               (kRes && okh) ? (int)(TW * a.ldr * 2) : 0, 0x00020000);
+                                                               (kRes && okh) ? (int)((kPart == 1 ? a.W_out + 16 : halo8::TW) * a.ldr * 2) : 0, 0x00020000);
+          // this group's lane offsets: a 32 x 16 tile drops the group's second row when it is past the launch's end
+          unsigned oo[4], ro[4];
+          const bool ok1 = oh + 1 < a.h_lim;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            if (kPart == 1) { oo[it] = (it >= 2 && !ok1) ? 0x80000000u : o_off[it]; ro[it] = (it >= 2 && !ok1) ? 0x80000000u : r_off[it]; }
+            else { oo[it] = o_off[it]; ro[it] = r_off[it]; }
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             u32x4 rr[4];
             if (kRes) {                                      // residual first: its latency hides under the LDS pass
 #pragma unroll
-              for (int it = 0; it < 4; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)r_off[it], h * 128, 0);
+              for (int it = 0; it < 4; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(srd_r, (int)ro[it], h * 128, 0);
             }
             if (!kPipe) wr(p, h);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private slice: no barrier needed
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // the next block's accumulators go into the slice NOW: its reads above are complete, and the write latency then runs under
             // this block's bias / residual / statistics arithmetic and stores instead of in front of the next block's reads
-            if (kPipe && (p < RPW - 1 || h < 1)) wr(h ? p + 1 : p, h ^ 1);
+            if (kPipe && (p < 3 || h < 1)) wr(h ? p + 1 : p, h ^ 1);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               f32x4 x0 = lo[it] + bias_r[h][0], x1 = hi4[it] + bias_r[h][1];
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
               }
               const u32x4 v = {pack_bf2(x0[0], x0[1]), pack_bf2(x0[2], x0[3]), pack_bf2(x1[0], x1[1]), pack_bf2(x1[2], x1[3])};
               if (kGn) {
-                const bool valid = okh && o_off[it] != 0x80000000u;     // pixels past the image edge are not part of the tensor
+                const bool valid = okh && oo[it] != 0x80000000u;        // pixels past the image edge are not part of the tensor
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const uint32_t w = valid ? v[e] : 0u;
@@ -1054,7 +1063,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
                   gq[h][e >> 1] += f * f;
                 }
               }
-              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)o_off[it], h * 128, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(v, srd_o, (int)oo[it], h * 128, 0);
               // store-data hazard (found on MI355X): the 16-B store reads its data VGPRs for the last lanes a few cycles after
               // issue; the next iteration's first VALU writes re-used them and its fp32 intermediates were stored instead
               __builtin_amdgcn_sched_barrier(0);
@@ -1062,37 +1071,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+          if (kGn && kPart == 1 && p == 1) gn_flush(0);          // rows 8 w .. 8 w + 3 are complete: the first of the wave's two slots
         }
-        if (kGn) {
-          // lane totals -> totals over the wave's 128 pixels (lanes that differ in e_px), then one (sum, sumsq) per group
-          const int cpg_log = a.cpg_log;                       // 2, 3 or 4 channels-per-group bits (Cout 128 / 256 / 512)
-          const long long tix = ((long long)c.t * a.tiles_h + (c.oh0 >> 4)) * a.tiles_w + (c.ow0 >> 5);
-          const long long row = ((kSub ? tix * 4 + c.ph : tix) << 2) + wave;      // kSub: a row per phase (the four phases write the same channels)
-          float* dst = a.gn_partial + row * 64;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float sv[2], qv[2];
-#pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-              sv[q2] = gs[h][q2][0] + gs[h][q2][1];
-              qv[q2] = gq[h][q2][0] + gq[h][q2][1];
-#pragma unroll
-              for (int m = 8; m < 64; m <<= 1) { sv[q2] += __shfl_xor(sv[q2], m); qv[q2] += __shfl_xor(qv[q2], m); }
-            }
-            const int ch0 = c.n0 + h * 64 + e_ch * 8;          // first of this lane's 8 channels
-            if (cpg_log == 2) {                                // 4 channels per group: each quad is a group
-              if (e_px == 0) {
-                dst[(ch0 >> 2) * 2] = sv[0]; dst[(ch0 >> 2) * 2 + 1] = qv[0];
-                dst[((ch0 >> 2) + 1) * 2] = sv[1]; dst[((ch0 >> 2) + 1) * 2 + 1] = qv[1];
-              }
-            } else {
-              float s8 = sv[0] + sv[1], q8 = qv[0] + qv[1];    // 8 channels per group: the lane's two quads
-              if (cpg_log == 4) { s8 += __shfl_xor(s8, 1); q8 += __shfl_xor(q8, 1); }   // 16: two neighbouring lanes
-              const bool writer = e_px == 0 && (cpg_log == 3 || (e_ch & 1) == 0);
-              if (writer) { dst[(ch0 >> cpg_log) * 2] = s8; dst[(ch0 >> cpg_log) * 2 + 1] = q8; }
-            }
-          }
-        }
+        if (kGn) gn_flush(kPart == 1 ? 1 : 0);
       };
       if (a.gn_partial) {
         if (a.resid) emit(std::true_type{}, std::true_type{});
@@ -1659,6 +1640,28 @@ extern "C" long long dove_conv_gn_partial_rows(const dove_conv_desc* d) {
   return (long long)desc_nb(d) * d->t_out * th * tw * 4;      // instance-major: instance b owns rows [b * rows / nb, (b + 1) * rows / nb)
 }
 
+// PARTIAL last tile column of a K_HALO4X conv (conv3x3_halo4x_kernel's kPart, H4Geo): when the image ends within the first half of its last
+// tile column (W % 32 in 1..16), that column can leave the main launch and be walked in 32 x 16 tiles by a second launch:
+//   main (16 x 32 tiles): columns [0, wm);   column (32 x 16 tiles): columns [wm, W)          outputs and gn_partial bit-identical
+// It does so only when the two launches together take fewer ROUNDS of the persistent grid than the one launch: a launch costs whole rounds
+// (a workgroup's tiles are a static share), so moving 4 % of the tiles into a launch of its own pays for a 68-round conv (the 240 x 360 tile
+// class of the tiled VAE: 62 + 3 rounds, -4.3 %) and would cost a round for a 15-round one (profiles/r06_partial_tile_ab.log).
+static bool halo4x_plan(const dove_conv_desc* d) {
+  const int tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW, tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
+  const int wrem = d->w_out % halo8::TW;
+  if (wrem < 1 || wrem > halo8::TW / 2) return false;
+  const int cus = cu_count();
+  const long long per = (long long)desc_nb(d) * d->t_out * (d->cout_pad / 128);
+  auto rounds = [&](long long tiles) { return (tiles * per + cus - 1) / cus; };
+  return rounds((long long)tiles_h * (tiles_w - 1)) + rounds((d->h_out + 31) / 32) < rounds((long long)tiles_h * tiles_w);
+}
+/* partial-tile launches a conv call makes besides its main launch: 1 = the last tile column in 32 x 16 tiles (0 for every call that does not
+ * dispatch to conv3x3_halo4x's plain form).  Reporting / tests. */
+extern "C" int dove_conv_partial_launches(const dove_conv_desc* d) {
+  if (!desc_size_ok(d, "conv_partial_launches") || select_kernel(d) != K_HALO4X) return 0;
+  return halo4x_plan(d) ? 1 : 0;
+}
+
 static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern);
 #ifdef DOVE_TIMING_BUILD
 static bool halo_m16() {                                       // DOVE_HALO_M16=0 selects the predecessor walk; read per call (the A/B tool toggles it)
@@ -1855,7 +1858,7 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       a.tiles_w = (d->w_in + halo8::TW - 1) / halo8::TW;        // tiles of the LOW-RES grid, one per phase and cout tile
       a.tiles_h = (d->h_in + halo8::TH - 1) / halo8::TH;
       a.tiles_n = 4 * (d->cout_pad / 128);
-      a.nty = a.tiles_h; a.ntx = a.tiles_w;
+      a.nty = a.tiles_h; a.ntx = a.tiles_w; a.h_lim = d->h_out; a.w_lim = d->w_out;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attrs;
@@ -1882,14 +1885,13 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
       a.tiles_w = (d->w_out + halo8::TW - 1) / halo8::TW;
       a.tiles_h = (d->h_out + halo8::TH - 1) / halo8::TH;
       a.tiles_n = d->cout_pad / 128;
-      a.ty0 = a.tx0 = 0; a.nty = a.tiles_h; a.ntx = a.tiles_w;
+      a.ty0 = a.tx0 = 0; a.nty = a.tiles_h; a.ntx = a.tiles_w; a.h_lim = d->h_out; a.w_lim = d->w_out;
       const long long g4 = (long long)a.T_out * a.tiles_h * a.tiles_w * a.tiles_n;
       DOVE_CHECK_ARG(g4 > 0 && g4 < (1ll << 31), "conv_igemm: grid too large");
       static PerDeviceOnce attr4;
       if (auto once_ = attr4.guard()) {
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, H4Geo<1>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<true, false, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
 #ifdef DOVE_TIMING_BUILD
         (void)hipFuncSetAttribute((const void*)conv3x3_halo4x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Halo4xCfg::LDS_BYTES);
@@ -1927,27 +1929,20 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
 #endif
       if (kern == K_HALO4X_UP) hipLaunchKernelGGL((conv3x3_halo4x_kernel<true, false, true, false, true>), dim3(grid), dim3(256), Halo4xCfg::LDS_BYTES, s, a);
       else {
-        // PARTIAL tiles (conv3x3_halo4x_kernel's kPart): when the image ends within the first half of its last tile column (W % 32 in 1..16) /
-        // tile row (H % 16 in 1..8), that column / row leaves the main launch and runs with half the register tile: up to three launches
-        // over disjoint tile rectangles, every (tile, wave) row of gn_partial still written exactly once, results bit-identical.
-        //   main: rows [0, R) x columns [0, C);  right (kPart 1): rows [0, R) x column C;  bottom (kPart 2): row R x ALL columns (a corner
-        //   tile that is partial both ways has <= 8 x 16 pixels: inside kPart 2's 8 x 32)
-        const int wrem = d->w_out % halo8::TW, hrem = d->h_out % halo8::TH;
-        const bool wpart = wrem >= 1 && wrem <= halo8::TW / 2, hpart = hrem >= 1 && hrem <= halo8::TH / 2;
-        const int R = a.tiles_h - (hpart ? 1 : 0), C = a.tiles_w - (wpart ? 1 : 0);
-        auto launch = [&](int part, int ty0, int nty, int tx0, int ntx) {
+        // a partial last tile column goes to a launch of its own in 32 x 16 tiles when that saves a round: see halo4x_plan
+        const bool wpart = halo4x_plan(d);
+        const int wm = wpart ? (a.tiles_w - 1) * halo8::TW : d->w_out, cols_main = wpart ? a.tiles_w - 1 : a.tiles_w;
+        auto launch = [&](int part, int nty, int tx0, int ntx, int w_lim) {
           if (nty <= 0 || ntx <= 0) return;
           IgemmArgs b = a;
-          b.ty0 = ty0; b.nty = nty; b.tx0 = tx0; b.ntx = ntx;
+          b.ty0 = 0; b.nty = nty; b.tx0 = tx0; b.ntx = ntx; b.h_lim = d->h_out; b.w_lim = w_lim;
           const long long g = (long long)b.T_out * nty * ntx * b.tiles_n;
           const unsigned gr = g > cus ? (unsigned)cus : (unsigned)g;
-          if (part == 0) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 0>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
-          else if (part == 1) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 1>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
-          else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 2>), dim3(gr), dim3(256), Halo4xCfg::LDS_BYTES, s, b);
+          if (part == 0) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 0>), dim3(gr), dim3(256), H4Geo<0>::LDS_BYTES, s, b);
+          else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 1>), dim3(gr), dim3(256), H4Geo<1>::LDS_BYTES, s, b);
         };
-        launch(0, 0, R, 0, C);
-        if (wpart) launch(1, 0, R, C, 1);
-        if (hpart) launch(2, R, 1, 0, a.tiles_w);
+        launch(0, a.tiles_h, 0, cols_main, wm);
+        if (wpart) launch(1, (d->h_out + 31) / 32, cols_main, 1, d->w_out);
       }
       DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x)");
       return DOVE_OK;

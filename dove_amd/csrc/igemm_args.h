@@ -61,10 +61,11 @@ struct IgemmArgs {
   // w_pair = [2][9][Cout_pad][Cin]: W0 + W1 and W1 + W2, fp32 sums rounded once at pack time.  See h4_split
   const bf16_t* w_pair;
   int tdup;
-  // conv3x3_halo4x: the rectangle of 16 x 32 tiles this launch walks, tile rows [ty0, ty0 + nty) x tile columns [tx0, tx0 + ntx) of the
-  // tiles_h x tiles_w grid (a conv is one launch over the whole grid, or the grid minus its last tile column / row plus the partial-tile
-  // launches for those: see conv3x3_halo4x_kernel's kPart)
+  // conv3x3_halo4x: the rectangle this launch walks - origin (ty0, tx0) in 16 x 32 tiles of the conv's tiles_h x tiles_w grid, nty x ntx tiles
+  // of the LAUNCH's geometry (a conv is one launch over the whole grid, or the grid minus its last tile column plus a 32 x 16-tile
+  // launch for that column: see conv3x3_halo4x_kernel's kPart)
   int ty0, tx0, nty, ntx;
+  int h_lim, w_lim;    // rows / columns of the output this launch owns end here (the image's H_out / W_out, or where a partial-tile launch takes over)
   int sub;             // conv3x3_halo4x<kSub>: sub-pixel form of the upsample-fused conv - `w` = dove_conv_desc.w_sub, tiling over the LOW-RES grid
 };
 

@@ -123,6 +123,7 @@ SIGNATURES = {
 PLAIN = {"dove_last_error": (C.c_char_p, []), "dove_abi_version": (C.c_int, []), "dove_comm_destroy": (None, [C.c_void_p]),
          "dove_conv_gn_partial_rows": (C.c_longlong, [C.POINTER(ConvDesc)]),
          "dove_conv_kernel_name": (C.c_char_p, [C.POINTER(ConvDesc)]),
+         "dove_conv_partial_launches": (C.c_int, [C.POINTER(ConvDesc)]),
          "dove_attention_head_paths": (C.c_int, [C.POINTER(C.c_float), _I, C.POINTER(C.c_int)]),
          "dove_attention_path_name": (C.c_char_p, [_I]),
          "dove_device_info": (C.c_int, [_I, C.c_char_p, _I, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),

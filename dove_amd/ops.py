@@ -119,10 +119,13 @@ def set_profiler(records: list | None):
 
 
 def conv_kernel_name(x_shape, pc: PackedConv, *, stride=1, pad=(None, None), up=0, tmode=0, t_out=None, hw_out=None, act=0, gated=False,
-                     resid=False) -> str:
-    """Kernel a conv / linear of this shape dispatches to (dove_conv_kernel_name; pure function of the descriptor, no GPU needed)."""
+                     resid=False, nb=1, partial=False):
+    """Kernel a conv / linear of this shape dispatches to (dove_conv_kernel_name; pure function of the descriptor, no GPU needed).
+    ``partial=True``: the partial-tile launch mask of the call instead (dove_conv_partial_launches: 1 = last tile column, 2 = last tile row);
+    ``x_shape`` is per instance, ``nb`` instances."""
     T, H, W, Cx = x_shape
     d = L.ConvDesc()
+    d.nb = nb
     ph = (pc.kh - 1) // 2 if pad[0] is None else pad[0]
     pw = (pc.kw - 1) // 2 if pad[1] is None else pad[1]
     t_out = T if t_out is None else t_out
@@ -138,6 +141,8 @@ def conv_kernel_name(x_shape, pc: PackedConv, *, stride=1, pad=(None, None), up=
     d.resid = 1 if (resid or gated) else None                  # only tested for NULL-ness by the selection rule
     d.w_sub = 1 if (up == 1 and pc.kt == 1 and pc.kh == 3 and pc.kw == 3) else None
     d.gate = 1 if gated else None
+    if partial:
+        return int(L.load().dove_conv_partial_launches(C.byref(d)))
     return L.load().dove_conv_kernel_name(C.byref(d)).decode()
 
 

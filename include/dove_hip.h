@@ -119,6 +119,11 @@ int dove_conv_igemm_bf16(const dove_conv_desc* d, void* stream);
  * smallk_kernel) - for reporting (bench.py's per-kernel roofline) and for tests that pin which production shape
  * runs where; the rule is a pure function of the descriptor (no environment switches) */
 const char* dove_conv_kernel_name(const dove_conv_desc* d);
+/* Partial-tile launches a call makes besides its main launch (reporting / tests; ABI 15): 1 = the last 16 x 32 tile column is walked in
+ * 32 x 16 tiles by a second launch - taken when the image ends within the first half of that column (W % 32 in 1..16) AND the two launches
+ * need fewer rounds of the persistent grid than one launch (the 240 x 360 tiles of the tiled VAE).  Outputs and fused GroupNorm partial
+ * sums do not depend on it (bit-identical). */
+int dove_conv_partial_launches(const dove_conv_desc* d);
 /* rows of gn_partial this call would write, 0 if its kernel does not fuse the statistics (caller then runs
  * dove_groupnorm_stats_bf16 on the output as before) */
 long long dove_conv_gn_partial_rows(const dove_conv_desc* d);

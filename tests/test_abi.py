@@ -203,3 +203,29 @@ def test_header_is_self_contained_c_and_links(tmp_path):
     assert out.returncode == 0, (out.stdout, out.stderr)
     a, b = out.stdout.split()
     assert a == b
+
+
+def test_conv_partial_launch_plan():
+    """dove_conv_partial_launches is a pure host function of the descriptor (no GPU): the last tile column of a conv3x3_halo4x call goes to
+    a launch of its own (32 x 16 tiles) only when the image ends within the first half of it AND the two launches need fewer rounds of the
+    256 persistent workgroups than one launch.  The 240 x 360 tiles of diffusers' tiled VAE (12 interior tiles in one call,
+    /root/reference/inference_script.py:642-645) qualify; the 720p clip's own levels and small calls keep the one launch."""
+    from dove_amd import ops
+
+    def pc(cin, cout, kt=3):
+        return ops.PackedConv(w=None, bias=None, kt=kt, kh=3, kw=3, cin=cin, cin_pad=cin, cout=cout, cout_pad=cout)
+
+    def plan(shape, p, nb=1):
+        assert ops.conv_kernel_name(shape, p, nb=nb) == "conv3x3_halo4x_kernel"
+        return ops.conv_kernel_name(shape, p, nb=nb, partial=True)
+
+    assert plan((8, 240, 360, 128), pc(128, 128), 12) == 1          # 68 rounds -> 62 + 3
+    assert plan((9, 240, 360, 128), pc(128, 128), 12) == 1
+    assert plan((8, 240, 360, 128), pc(128, 128), 1) == 0           # one tile at a time: 6 rounds either way
+    assert plan((8, 720, 1280, 128), pc(128, 128)) == 0             # ends on tile boundaries
+    assert plan((8, 360, 640, 256), pc(256, 256)) == 0
+    assert plan((3, 30, 45, 512), pc(512, 512), 12) == 0            # W % 32 = 13, but one round more, not fewer
+    assert plan((3, 24, 40, 128), pc(128, 128)) == 0                # test-sized: one round
+    assert plan((16, 512, 40, 128), pc(128, 128, 1)) == 1
+    assert plan((16, 512, 52, 128), pc(128, 128, 1)) == 0           # W % 32 = 20: the column is more than half full
+    assert ops.conv_kernel_name((300, 1, 1, 3072), pc(3072, 3072, 1), partial=True) == 0     # not a halo conv at all

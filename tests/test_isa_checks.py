@@ -102,8 +102,8 @@ def _bare_vmcnt_waits(walk):
 
 
 @pytest.mark.parametrize("variant,taps,per_step", [("ILb0ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb1ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb0ELb0ELb1ELb1ELb1ELi0E", 4, 64),
-                                                    ("ILb0ELb0ELb1ELb0ELb1ELi1E", 9, 32), ("ILb0ELb0ELb1ELb0ELb1ELi2E", 9, 32)],
-                         ids=["direct", "upsample-in-addressing", "sub-pixel", "partial-columns", "partial-rows"])
+                                                    ("ILb0ELb0ELb1ELb0ELb1ELi1E", 9, 64)],
+                         ids=["direct", "upsample-in-addressing", "sub-pixel", "tiles-32x16"])
 def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, taps, per_step):
     """conv3x3_halo4x runs ONE wave per SIMD on the whole 512-register file: its 8 x 8 accumulator tile of 16 x 16 blocks is the 256 AGPRs
     (asm MFMAs with the accumulator tied and constrained to the AGPR file - as builtins the allocator rotated the quads through VGPRs and
@@ -111,9 +111,9 @@ def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, t
     ring is kept in flight by hand-counted `s_waitcnt vmcnt(n)` in asm; a wait the compiler adds on its own between the first and the last
     MFMA means it lost track of the queue and drains the ring there (what happened to gemm8p in round 3).  The unrolled body is two groups
     of `taps` spatial-tap steps x 64 MFMAs of v_mfma_f32_16x16x32_bf16 (9 taps; 4 in the sub-pixel form of the upsample-fused conv,
-    dove_conv_desc.w_sub), each step with its 16 fragment reads pinned between MFMA pairs.  The PARTIAL-tile variants (kPart 1 / 2: the last
-    tile column / row of an image that ends within its first half) walk the same steps with half the register tile: 32 MFMAs and 12 fragment
-    reads per step, 128 accumulator registers."""
+    dove_conv_desc.w_sub), each step with its 16 fragment reads pinned between MFMA pairs.  The tile-geometry variant (kPart 1: the last
+    tile column of an image that ends within its first half, walked in 32 x 16 tiles) is the same walk with another block -> pixel map and
+    LDS image: the same budget and counts."""
     text = igemm_asm
     name = f"_Z21conv3x3_halo4x_kernel{variant}Ev9IgemmArgs"
 

@@ -606,46 +606,62 @@ def test_conv_fused_gn_stats(cin, cout, k, T, H, W, up, resid):
     assert getattr(ops.conv(x.cuda(), pc_g, out=y, **kw), "gn_stats", None) is None    # re-used output drops stale stats
 
 
-@pytest.mark.parametrize("cin,cout,k,T,H,W,cache,resid", [
-    (128, 128, (3, 3, 3), 3, 24, 40, True, True),        # H % 16 = 8 and W % 32 = 8: main + right column (kPart 1) + bottom row (kPart 2)
-    (64, 256, (3, 3, 3), 2, 33, 96, False, False),        # only the bottom row is partial (H % 16 = 1), two cout tiles, w_first frames
-    (128, 128, (3, 3), 5, 48, 45, False, True),           # only the right column (W % 32 = 13: the 30 x 45 latent tile's width), kt = 1
-    (256, 256, (3, 3, 3), 2, 20, 16, True, False),        # ONE tile column that is partial (W = 16): no main launch at all
-    (128, 128, (3, 3, 3), 2, 8 + 16, 360, True, False),   # the 240 x 360 VAE tile's width: 11 full columns + 8 pixels
+@pytest.mark.parametrize("cin,cout,k,nb,T,H,W,cache,resid,mask,emu", [
+    (128, 128, (3, 3), 1, 16, 512, 40, False, True, 1, True),        # last tile column (W % 32 = 8) in 32 x 16 tiles: 4 -> 3 rounds
+    (64, 256, (3, 3, 3), 1, 8, 500, 45, True, False, 1, True),       # ragged height too (500 = 15 x 32 + 20: the last 32 x 16 tile is cut), W % 32 = 13
+    (128, 128, (3, 3, 3), 12, 8, 240, 360, True, True, 1, False),    # THE case it was built for: 12 tiles of 240 x 360, 8 frames (tiled VAE, level 0)
+    (256, 128, (3, 3, 3), 12, 8, 240, 360, False, False, 1, False),  # ... its 256 -> 128 conv on a first frame-batch (w_first groups)
+    (128, 128, (3, 3, 3), 1, 3, 24, 40, True, True, 0, True),        # small calls keep the one launch (a launch costs whole rounds)
 ])
-def test_conv_partial_tiles_bit_identical_to_full_tiles(cin, cout, k, T, H, W, cache, resid):
-    """conv3x3_halo4x's PARTIAL-tile launches (kPart 1 / 2: the last tile column / row when the image ends within its first half run with half
-    the register tile, as up to three launches over disjoint tile rectangles) against the SAME conv on full tiles only: the image embedded,
-    top-left, in a zero frame whose size is a multiple of 16 x 32 - the zeros are the conv's own zero padding and add exact zeros, so the
-    cropped result must be bit-identical; fused GroupNorm statistics of the partial form == a separate pass over its output."""
+def test_conv_partial_tiles_bit_identical_to_full_tiles(cin, cout, k, nb, T, H, W, cache, resid, mask, emu):
+    """conv3x3_halo4x's PARTIAL-tile launch (the last 16 x 32 tile column walked in 32 x 16 tiles when the image ends within the first half of
+    it and the two launches need fewer rounds of the persistent grid: dove_conv_partial_launches, asserted) against the SAME conv on full
+    tiles only: the image embedded, top-left, in a zero frame whose size is a multiple of 16 x 32 -
+    the zeros are the conv's own zero padding and add exact zeros, so the cropped result must be bit-identical; the fused GroupNorm
+    PARTIAL SUMS of the two-launch form are bit-identical to the one-launch form's too (every (tile, wave slot) row sums the same pixels in
+    the same order: checked against the same call with the plan's gate closed by splitting the instances), and == a separate pass."""
     pc_c, pc_g = pack(cout, cin, k)
     Hp, Wp = -(-H // 16) * 16, -(-W // 32) * 32
-    assert (H % 16 in range(1, 9)) or (W % 32 in range(1, 17))
-    x = rnd(T, H, W, cin, seed=71)
-    xp = torch.zeros(T, Hp, Wp, cin, dtype=BF)
+    assert ops.conv_kernel_name((T, H, W, cin), pc_g, resid=resid, nb=nb) == "conv3x3_halo4x_kernel"
+    assert ops.conv_kernel_name((T, H, W, cin), pc_g, resid=resid, nb=nb, partial=True) == mask
+    assert ops.conv_kernel_name((T, Hp, Wp, cin), pc_g, resid=resid, nb=nb, partial=True) == 0
+    g = torch.Generator(device="cuda").manual_seed(71)
+    x = torch.randn(nb * T, H, W, cin, device="cuda", generator=g).to(BF)
+    xp = torch.zeros(nb * T, Hp, Wp, cin, dtype=BF, device="cuda")
     xp[:, :H, :W] = x
     kw, kwp = {}, {}
     if cache and len(k) == 3:
-        c = rnd(2, H, W, cin, seed=72)
-        cp = torch.zeros(2, Hp, Wp, cin, dtype=BF)
-        cp[:, :H, :W] = c
-        kw["cache"], kwp["cache"] = c.cuda(), cp.cuda()
+        c = torch.randn(*((nb, 2) if nb > 1 else (2,)), H, W, cin, device="cuda", generator=g).to(BF)
+        cp = torch.zeros(*c.shape[:-3], Hp, Wp, cin, dtype=BF, device="cuda")
+        cp[..., :H, :W, :] = c
+        kw["cache"], kwp["cache"] = c, cp
     if resid:
-        r = rnd(T, H, W, cout, seed=73)
-        rp = torch.zeros(T, Hp, Wp, cout, dtype=BF)
+        r = torch.randn(nb * T, H, W, cout, device="cuda", generator=g).to(BF)
+        rp = torch.zeros(nb * T, Hp, Wp, cout, dtype=BF, device="cuda")
         rp[:, :H, :W] = r
-        kw["resid"], kwp["resid"] = r.cuda(), rp.cuda()
-    assert ops.conv_kernel_name(x.shape, pc_g, resid=resid) == "conv3x3_halo4x_kernel"
-    y = ops.conv(x.cuda(), pc_g, gn_eps=1e-6, **kw)
-    yp = ops.conv(xp.cuda(), pc_g, **kwp)
+        kw["resid"], kwp["resid"] = r, rp
+    y = ops.conv(x, pc_g, gn_eps=1e-6, nb=nb, **kw)
+    yp = ops.conv(xp, pc_g, nb=nb, **kwp)
     torch.cuda.synchronize()
-    assert torch.equal(y, yp[:, :H, :W].contiguous()), float((y.float() - yp[:, :H, :W].float()).abs().max())
-    close("partial_tiles_vs_emu", y, E.conv(x, pc_c, cache=kw["cache"].cpu() if "cache" in kw else None, resid=kw["resid"].cpu() if resid else None))
+    ycrop = yp[:, :H, :W]
+    assert torch.equal(y, ycrop), float((y.float() - ycrop.float()).abs().max())
+    del xp, yp, ycrop, kwp
+    if emu:
+        close("partial_tiles_vs_emu", y, E.conv(x.cpu(), pc_c, cache=kw["cache"].cpu() if "cache" in kw else None, resid=kw["resid"].cpu() if resid else None))
     fused = getattr(y, "gn_stats", None)
     assert fused is not None
-    ref = ops.groupnorm_stats(y, 1e-6)
+    ref = ops.groupnorm_stats(y, 1e-6, nb) if nb > 1 else ops.groupnorm_stats(y, 1e-6)
     torch.cuda.synchronize()
     assert torch.allclose(fused[0].cpu(), ref.cpu(), rtol=2e-4, atol=2e-5), (fused[0].cpu() - ref.cpu()).abs().max()
+    if nb > 1 and mask:
+        # one instance at a time the gate stays closed (one launch): same output bits AND the same statistics bits per instance
+        assert ops.conv_kernel_name((T, H, W, cin), pc_g, resid=resid, nb=1, partial=True) == 0
+        for b in (0, nb - 1):
+            kb = {k_: (v[b] if k_ == "cache" else v[b * T:(b + 1) * T]) for k_, v in kw.items()}
+            yb = ops.conv(x[b * T:(b + 1) * T], pc_g, gn_eps=1e-6, **kb)
+            torch.cuda.synchronize()
+            assert torch.equal(yb, y[b * T:(b + 1) * T])
+            assert torch.equal(yb.gn_stats[0].view(-1), fused[0][b].view(-1)), "fused GroupNorm statistics differ between the one- and two-launch forms"
 
 
 def test_conv_and_linear_fullsize_properties():
