@@ -17,6 +17,8 @@ from oracle.vae import OracleVAE  # noqa: E402
 def main():
     stage, seed, dtype, threads, src, dst = sys.argv[1], int(sys.argv[2]), getattr(torch, sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6]
     scale = float(sys.argv[7]) if len(sys.argv) > 7 else 1.0
+    import time
+    t0 = time.time()
     torch.set_num_threads(threads)
     v, _t, _s = config.default_configs()
     wv = weights.random_state_dict(weights.vae_param_shapes(v), seed)
@@ -28,7 +30,7 @@ def main():
     # the checksum of the input that was read travels with the result (tests/oracle_prefetch.py accepts a result only for ITS input);
     # written under another name and renamed so that a reader never sees a partial file
     xs = x.double()
-    torch.save({"out": out.float(), "in_sum": float(xs.sum()) + float(xs.abs().sum())}, dst + ".part")
+    torch.save({"out": out.float(), "in_sum": float(xs.sum()) + float(xs.abs().sum()), "seconds": time.time() - t0}, dst + ".part")
     os.replace(dst + ".part", dst)
 
 

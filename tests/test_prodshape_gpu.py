@@ -400,7 +400,7 @@ def test_prodshape_encoder_first_frame_batch_vs_oracle_9x720x1280(tmp_path):
     ref32, refbf, t32, tall, threads, src = _two_oracles("enc", oracle_prefetch.ENC_SEED, video, tmp_path)     # both oracles see the bf16 boundary tensor the HIP path sees
     e_hip = rms_rel(got, ref32)
     e_bf, how = _yardstick("enc", refbf, ref32)
-    print(f"[encoder 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads} threads, {src}); "
+    print(f"[encoder 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads}{'' if isinstance(threads, str) else ' threads'}, {src}); "
           f"posterior moments rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e} ({how})")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
 
@@ -431,7 +431,7 @@ def test_prodshape_decoder_first_latent_batch_vs_oracle_9x720x1280(tmp_path):
     sat = float((ref32.abs() >= 1).float().mean())
     e_hip = rms_rel(got, ref32)
     e_bf, how = _yardstick("dec", refbf, ref32)
-    print(f"[decoder 3x90x160 -> 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads} threads, {src}); "
+    print(f"[decoder 3x90x160 -> 9x720x1280] fp32 oracle {t32:.0f} s of {tall:.0f} s ({threads}{'' if isinstance(threads, str) else ' threads'}, {src}); "
           f"decoded (un-clamped, {100 * sat:.1f} % outside [-1, 1]) rms-rel vs fp32: hip {e_hip:.3e}  bf16-emulated reference {e_bf:.3e} ({how})")
     assert e_hip <= 1.25 * e_bf + 1e-3, (e_hip, e_bf)
 
