@@ -421,9 +421,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": DOM + " (persistent LDS-halo implicit-GEMM 3x3(x3) conv, bf16 MFMA 16x16x32)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": pmc_src, "launches": len(dom) // max(prof_steps, 1), "avg_launch_ms": dom_ms / max(len(dom), 1),
-                         "launch_is": "one dove_conv_igemm_bf16 call = the main launch + (where an image ends within the first half of its last tile "
-                                      "row / column: the 360- and 180-row levels) the partial-tile launches of that call; rocprofv3: the sum over "
-                                      "conv3x3_halo4x_kernel<...> instantiations / calls",
+                         "launch_is": "one dove_conv_igemm_bf16 call = ONE kernel launch at every shape of the untiled clip (dove_conv_partial_launches "
+                                      "is 0 for them: profiles/pmc_traffic.json kernel_launches == launches); only the tiled variant's 240 x 360 "
+                                      "tile class adds a second launch (conv3x3_halo4x_kernel<..., 1>) for its partial last tile column",
                          "durations_from": prof_note,
                          "avg_launch_ms_timed_region": (dom_ms_timed / len(dom_timed)) if dom_timed else None,
                          "avg_launch_gflop": dom_fl / max(len(dom), 1) / 1e9,
