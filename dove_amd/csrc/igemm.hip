@@ -530,13 +530,19 @@ __device__ __forceinline__ void h4_advance(H4State& s, const IgemmArgs& a, const
 // gn_partial slot sums the same pixels in the same order, so outputs AND statistics are bit-identical to the one-launch form.  (First form,
 // commit 93c1943: the last column on HALF a register tile - 32 MFMAs per step against the same weight stream - cost 0.9 of a full tile: a
 // step is then bound by the 64-B requests of the weight tiles.)
-template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false, int kPart = 0>
+// kFill (TIMING build only, tools/gn_fusion_cost.py): the COST SIDE of a consumer-side GroupNorm + SiLU fusion measured inside the product walk.
+// In steps 2..7 of every group each thread reads the two halo rounds of the next group that have just landed (its own 16-byte slots), runs the
+// instruction mix of normalise + SiLU + pack on their 16 elements (unpack, fma, mul, exp, add, rcp, mul, cvt: 124 VALU, 2 of 8 transcendental,
+// eight independent chains) and writes the ORIGINAL bytes back, so the conv's result is unchanged and the usual tests still hold - what changes
+// is the issue stream: +5 instructions behind most MFMA pairs of six of the nine steps, 2 ds_read_b128 and 2 ds_write_b128 per step.
+template <bool kUp, bool kTiming, bool kPipe = true, bool kSub = false, bool kM16 = false, int kPart = 0, bool kFill = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs a) {
   using namespace halo8;
   using CFG = typename std::conditional<kSub, Halo4xSubCfg, Halo4xCfg>::type;
   using GEO = H4Geo<kPart>;
   static_assert(!(kUp && kSub), "the sub-pixel form runs on the plain halo geometry of the low-res grid");
   static_assert(kPart == 0 || (kM16 && !kUp && !kSub && !kTiming && kPipe), "tile geometry 1: the 16 x 16 x 32 walk of the plain conv only");
+  static_assert(!kFill || (kM16 && !kUp && !kSub && !kTiming && kPart == 0), "kFill: the product walk of the plain conv only");
   // LDS image of the launch's tile geometry (these shadow the halo8 constants of the 16 x 32 tile)
   constexpr int HWID = GEO::HWID, A_BYTES = GEO::A_BYTES, RPW = GEO::RPW;
   constexpr int UHW = halo8::TW / 2 + 2, UHH = halo8::TH / 2 + 2;
@@ -727,6 +733,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
     asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[k]) : "v"(w), "v"(x));
   };
 
+  // ---- kFill: see the kernel's header ----
+  u32x4 fd[2];                                     // the two rounds' 16 bytes per lane (8 bf16 each)
+  float ff[8], ft[8];
+  unsigned fp4[4];
+  float f_scale = 1.0f + (float)lane * 0.0009765625f, f_shift = (float)(lane & 7) * 0.03125f;
+  asm volatile("" : "+v"(f_scale), "+v"(f_shift));
+  auto fill_op = [&](int q, int rnd) {             // op q (0..63) of round rnd: stage q >> 3 of element q & 7 (eight independent chains)
+    const int e = q & 7, stg = q >> 3;
+    const unsigned dw = rnd ? fd[1][e >> 1] : fd[0][e >> 1];
+    switch (stg) {
+      case 0: if (e & 1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(ff[e]) : "v"(dw)); else asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(ff[e]) : "v"(dw)); break;
+      case 1: asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(ff[e]) : "v"(f_scale), "v"(f_shift)); break;   // per-channel scale / shift live in registers
+      case 2: asm volatile("v_mul_f32 %0, %1, %2" : "=v"(ft[e]) : "s"(-1.4426950408889634f), "v"(ff[e])); break;
+      case 3: asm volatile("v_exp_f32 %0, %0" : "+v"(ft[e])); break;
+      case 4: asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(ft[e])); break;
+      case 5: asm volatile("v_rcp_f32 %0, %0" : "+v"(ft[e])); break;
+      case 6: asm volatile("v_mul_f32 %0, %0, %1" : "+v"(ff[e]) : "v"(ft[e])); break;
+      default: if (!(e & 1)) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(fp4[e >> 1]) : "v"(ff[e]), "v"(ff[e + 1])); break;
+    }
+  };
+  auto fill_slot = [&](int slot, int tap_, int nbuf) {   // slot 0..31 of step tap_; nbuf = the halo buffer of group nxt
+    if (!kFill || tap_ < 2 || tap_ > 7) return;
+    char* const base = smem + nbuf * A_BYTES + (2 * (tap_ - 2)) * 4096 + wave * 1024 + lane * 16;
+    if (slot == 0) fd[0] = *(const u32x4*)base;
+    if (slot == 1) fd[1] = *(const u32x4*)(base + 4096);
+    if (slot >= 6 && slot < 32) {                  // 26 slots x 5 ops >= 2 rounds x 64 ops (the last two slots also carry the write-back)
+      for (int j = 0; j < 5; ++j) {
+        const int q = (slot - 6) * 5 + j;
+        if (q < 128) fill_op(q & 63, q >> 6);
+      }
+    }
+    if (slot == 30) { asm volatile("" :: "v"(fp4[0]), "v"(fp4[1]), "v"(fp4[2]), "v"(fp4[3])); *(u32x4*)base = fd[0]; }
+    if (slot == 31) { asm volatile("" :: "v"(fp4[0]), "v"(fp4[1]), "v"(fp4[2]), "v"(fp4[3])); *(u32x4*)(base + 4096) = fd[1]; }
+  };
+
   bf16x8 xa[4], wa[4], xb[4], wb[4];              // fragment sets: a = k-half 0, b = k-half 1
   bf16x8 xs[2][8], wl[4], wh[4];                  // kM16: activation sets (alternating per step), cout-low / cout-high weight fragments
   if (kSub) sub_bases(h4_decode(a, kc, (int)blockIdx.x).ph, abaseT);
@@ -785,6 +826,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         if (g == 9 && NH >= 4) stage_halo_round(std::integral_constant<int, (NH >= 4 ? R0 + 3 : 0)>{}, NPar{});
         if (g == 10 && NH >= 5) stage_halo_round(std::integral_constant<int, (NH >= 5 ? R0 + 4 : 0)>{}, NPar{});
         if (g == 11 && NH >= 6) stage_halo_round(std::integral_constant<int, (NH >= 6 ? R0 + 5 : 0)>{}, NPar{});
+        fill_slot(g, tap, 1 - par);
         __builtin_amdgcn_sched_barrier(0);
       }
       // second half: cout blocks 4-7 (wh); behind the first 12 pairs the next step's 8 activation + 4 cout-low weight fragments
@@ -802,6 +844,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
         } else if (g < 12) {
           wl[g - 8] = *(const bf16x8*)(smem + b16_addr(SlotNxt{}, g - 8));
         }
+        fill_slot(16 + g, tap, 1 - par);
         __builtin_amdgcn_sched_barrier(0);
       }
       return;
@@ -1941,6 +1984,18 @@ static int conv_dispatch(const dove_conv_desc* d, void* stream, ConvKernel kern)
           if (part == 0) hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 0>), dim3(gr), dim3(256), H4Geo<0>::LDS_BYTES, s, b);
           else hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 1>), dim3(gr), dim3(256), H4Geo<1>::LDS_BYTES, s, b);
         };
+#ifdef DOVE_TIMING_BUILD
+        if (const char* e = getenv("DOVE_HALO_FILL"); e && atoi(e) == 1) {     // tools/gn_fusion_cost.py: the product walk + the fusion's instruction mix
+          static PerDeviceOnce attrf;
+          if (auto once_ = attrf.guard())
+            (void)hipFuncSetAttribute((const void*)(conv3x3_halo4x_kernel<false, false, true, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H4Geo<0>::LDS_BYTES);
+          IgemmArgs b = a;
+          b.ty0 = 0; b.nty = a.tiles_h; b.tx0 = 0; b.ntx = a.tiles_w; b.h_lim = d->h_out; b.w_lim = d->w_out;
+          hipLaunchKernelGGL((conv3x3_halo4x_kernel<false, false, true, false, true, 0, true>), dim3(grid), dim3(256), H4Geo<0>::LDS_BYTES, s, b);
+          DOVE_CHECK_LAUNCH("dove_conv_igemm_bf16(halo4x, kFill)");
+          return DOVE_OK;
+        }
+#endif
         launch(0, a.tiles_h, 0, cols_main, wm);
         if (wpart) launch(1, (d->h_out + 31) / 32, cols_main, 1, d->w_out);
       }

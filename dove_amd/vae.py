@@ -112,7 +112,7 @@ class AutoencoderKLCogVideoX:
         # enable_tiling(): run all tiles of one shape as one batch (False: one tile at a time, the round-3 loop - kept for the A/B)
         self.tile_batching = True
         self.tile_streams = 2
-        self.tile_batch_streams = 2       # inside a tile class: frame-batches alternate between two streams (1: one after the other)
+        self.tile_batch_streams = 2       # inside a tile class: frame-batches go round-robin to this many streams (1: one after the other)
         self._tile_helpers = []
         self._tile_stream = None
         self.tile_batch_max = 16
@@ -372,21 +372,26 @@ class AutoencoderKLCogVideoX:
                     # tile_batch_streams = 2: the class's frame-batches alternate between its own stream and a helper, ordered only by the
                     # per-conv events of StreamCache (what _run_batches does for the untiled clip): the small launches of a 240x360 tile leave
                     # more of the chip idle at their ends than a 720x1280 frame's, and the other batch's kernels fill it
-                    helper = None
+                    helpers = []
                     if self.tile_batch_streams > 1 and len(fbs) > 1 and base is not None:
                         slot = 0 if base is main else 1
+                        nh = min(self.tile_batch_streams, len(fbs)) - 1
                         while len(self._tile_helpers) <= slot:
-                            self._tile_helpers.append(torch.cuda.Stream(device=self.device))
-                        helper = self._tile_helpers[slot]
-                        helper.wait_stream(base)
-                        x_cl.record_stream(helper)
-                    cache, parts = (StreamCache() if helper is not None else {}), []
+                            self._tile_helpers.append([])
+                        while len(self._tile_helpers[slot]) < nh:
+                            self._tile_helpers[slot].append(torch.cuda.Stream(device=self.device))
+                        helpers = self._tile_helpers[slot][:nh]
+                        for hs in helpers:
+                            hs.wait_stream(base)
+                            x_cl.record_stream(hs)
+                    lanes = [base] + helpers                    # frame-batch bi runs on lanes[bi % len(lanes)]
+                    cache, parts = (StreamCache() if helpers else {}), []
                     self._nb = nb
                     with torch.cuda.stream(base):
                         try:
                             for bi, (s, e) in enumerate(fbs):
-                                st = helper if (helper is not None and bi % 2 == 1) else base
-                                if helper is not None:
+                                st = lanes[bi % len(lanes)]
+                                if helpers:
                                     cache.stream = st
                                 with torch.cuda.stream(st):
                                     xb = ops.tile_gather(x_cl, s, e - s, th, tw, [(ii[a], jj[b]) for a, b in members], im2col_cin)   # [nb * t, th, tw, C]
@@ -394,9 +399,9 @@ class AutoencoderKLCogVideoX:
                                     parts.append(o.view(nb, o.shape[0] // nb, *o.shape[1:]))
                         finally:
                             self._nb = 1
-                            if helper is not None:
-                                base.wait_stream(helper)
-                        if helper is not None:
+                            for hs in helpers:
+                                base.wait_stream(hs)
+                        if helpers:
                             for o_ in parts:
                                 o_.record_stream(base)
                         out = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0].contiguous()                # [nb, T', oh, ow, C]

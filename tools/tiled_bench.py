@@ -44,12 +44,12 @@ def tile_flop_ratio(H, W, th, tw, sh, sw):
 
 res = {}
 outs = {}
-for mode in (["untiled", "tiled_loop", "tiled_1stream", "tiled_class_streams_only", "tiled"] if args.mode == "both" else [args.mode]):
+for mode in (["untiled", "tiled_loop", "tiled_1stream", "tiled_class_streams_only", "tiled", "tiled_3batch_streams", "tiled_4batch_streams"] if args.mode == "both" else [args.mode]):
     if mode.startswith("tiled"):
         vae.enable_slicing(); vae.enable_tiling()
         vae.tile_batching = mode != "tiled_loop"       # tiled_loop: one tile at a time (the round-3 path)
         vae.tile_streams = 1 if mode == "tiled_1stream" else 2
-        vae.tile_batch_streams = 2 if mode == "tiled" else 1     # round 6: frame-batches of a class alternate between two streams
+        vae.tile_batch_streams = {"tiled": 2, "tiled_3batch_streams": 3, "tiled_4batch_streams": 4}.get(mode, 1)     # round 6: frame-batches of a class go round-robin to k streams
     else:
         vae.disable_tiling()
     enc_ms, m = timed(lambda: vae.encode(video).latent_dist.parameters)
