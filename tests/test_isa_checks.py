@@ -101,8 +101,8 @@ def _bare_vmcnt_waits(walk):
     return bare
 
 
-@pytest.mark.parametrize("variant,taps,per_step", [("ILb0ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb1ELb0ELb1ELb0ELb1ELi0E", 9, 64), ("ILb0ELb0ELb1ELb1ELb1ELi0E", 4, 64),
-                                                    ("ILb0ELb0ELb1ELb0ELb1ELi1E", 9, 64)],
+@pytest.mark.parametrize("variant,taps,per_step", [("ILb0ELb0ELb1ELb0ELb1ELi0ELb0E", 9, 64), ("ILb1ELb0ELb1ELb0ELb1ELi0ELb0E", 9, 64), ("ILb0ELb0ELb1ELb1ELb1ELi0ELb0E", 4, 64),
+                                                    ("ILb0ELb0ELb1ELb0ELb1ELi1ELb0E", 9, 64)],
                          ids=["direct", "upsample-in-addressing", "sub-pixel", "tiles-32x16"])
 def test_halo4x_one_wave_per_simd_budget_and_counted_waits(igemm_asm, variant, taps, per_step):
     """conv3x3_halo4x runs ONE wave per SIMD on the whole 512-register file: its 8 x 8 accumulator tile of 16 x 16 blocks is the 256 AGPRs
