@@ -8,6 +8,7 @@ pass.  Test infrastructure only: nothing under dove_amd/ imports this.
 The seeded inputs live here so that the prefetch and the tests cannot drift apart; a result is only accepted when the checksum of the input
 the worker read equals the checksum of the tensor the test handed to the HIP path."""
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -49,8 +50,10 @@ def start(stages, conv_out_scale):
         threads = max(2, ncpu * (2 if stage == "enc" else 3) // 16)
         seed = ENC_SEED if stage == "enc" else DEC_SEED
         scale = 1.0 if stage == "enc" else conv_out_scale
-        proc = subprocess.Popen([sys.executable, os.path.join(_HERE, "oracle_worker.py"), stage, str(seed), "float32", str(threads), src, dst, str(scale)],
-                                preexec_fn=lambda: os.nice(10), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cmd = [sys.executable, os.path.join(_HERE, "oracle_worker.py"), stage, str(seed), "float32", str(threads), src, dst, str(scale)]
+        if shutil.which("nice"):                                 # (not preexec_fn: the parent has OpenMP threads by now)
+            cmd = ["nice", "-n", "10"] + cmd
+        proc = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         _state[stage] = dict(proc=proc, src=src, dst=dst, t0=time.time(), threads=threads)
 
 
