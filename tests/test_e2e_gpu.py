@@ -235,6 +235,14 @@ def test_vae_tile_batching_bit_identical_gpu():
     assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(d1).all())
     assert torch.equal(p1, p0), f"batched tiled encode differs from the tile loop: max {float((p1.float() - p0.float()).abs().max())}"
     assert torch.equal(d1, d0), f"batched tiled decode differs from the tile loop: max {float((d1.float() - d0.float()).abs().max())}"
+    # the frame-batches of a class on 1 / 3 streams instead of the default 2 (per-conv events order them): the same bits
+    default = vae.tile_batch_streams
+    try:
+        for k in (1, 3):
+            vae.tile_batch_streams = k
+            assert torch.equal(vae.encode(xb).latent_dist.parameters, p1) and torch.equal(vae.decode(z).sample, d1), f"tile_batch_streams = {k} changes bits"
+    finally:
+        vae.tile_batch_streams = default
 
 
 def test_two_stream_vae_is_bit_identical(setup):
