@@ -235,14 +235,20 @@ def test_vae_tile_batching_bit_identical_gpu():
     assert bool(torch.isfinite(p1).all()) and bool(torch.isfinite(d1).all())
     assert torch.equal(p1, p0), f"batched tiled encode differs from the tile loop: max {float((p1.float() - p0.float()).abs().max())}"
     assert torch.equal(d1, d0), f"batched tiled decode differs from the tile loop: max {float((d1.float() - d0.float()).abs().max())}"
-    # the frame-batches of a class on 1 / 3 streams instead of the default 2 (per-conv events order them): the same bits
+    # the frame-batches of a class on 1 / 2 / 3 streams (per-conv events order them; 25 frames = three frame-batches, 7 latent frames = three): the same bits
+    xb3 = synth_clip(25, 312, 304, seed=9).cuda().to(torch.bfloat16)
+    z3 = torch.randn(1, 16, 7, 39, 38, generator=torch.Generator().manual_seed(5)).cuda().to(torch.bfloat16)
     default = vae.tile_batch_streams
+    outs = {}
     try:
-        for k in (1, 3):
+        for k in (1, 2, 3):
             vae.tile_batch_streams = k
-            assert torch.equal(vae.encode(xb).latent_dist.parameters, p1) and torch.equal(vae.decode(z).sample, d1), f"tile_batch_streams = {k} changes bits"
+            outs[k] = (vae.encode(xb3).latent_dist.parameters.clone(), vae.decode(z3).sample.clone())
+            torch.cuda.synchronize()
     finally:
         vae.tile_batch_streams = default
+    for k in (2, 3):
+        assert torch.equal(outs[k][0], outs[1][0]) and torch.equal(outs[k][1], outs[1][1]), f"tile_batch_streams = {k} changes bits"
 
 
 def test_two_stream_vae_is_bit_identical(setup):
