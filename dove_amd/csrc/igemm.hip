@@ -737,8 +737,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_halo4x_kernel(const IgemmArgs 
   u32x4 fd[2];                                     // the two rounds' 16 bytes per lane (8 bf16 each)
   float ff[8], ft[8];
   unsigned fp4[4];
-  float f_scale = 1.0f + (float)lane * 0.0009765625f, f_shift = (float)(lane & 7) * 0.03125f;
-  asm volatile("" : "+v"(f_scale), "+v"(f_shift));
+  float f_scale = 1.0f, f_shift = 0.0f;
+  if (kFill) {                                     // opaque per-lane values (a real fusion holds the lane's channel scale / shift here)
+    f_scale = 1.0f + (float)lane * 0.0009765625f; f_shift = (float)(lane & 7) * 0.03125f;
+    asm volatile("" : "+v"(f_scale), "+v"(f_shift));
+  }
   auto fill_op = [&](int q, int rnd) {             // op q (0..63) of round rnd: stage q >> 3 of element q & 7 (eight independent chains)
     const int e = q & 7, stg = q >> 3;
     const unsigned dw = rnd ? fd[1][e >> 1] : fd[0][e >> 1];
